@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X: `python bench.py --gpus N --steps K --warmup W`.
+
+Workload (BASELINE.json configs[1]): batch=256 random 224x224 crops through the
+EfficientNet-B0 classifier, fp32, inputs resident in HBM before the timed region.  One
+step = one forward over one 256-crop batch per GPU; frames shard with no data-path
+collective, so N GPUs run N independent batches ("weak" scaling) and `value` is the
+whole-job crops/s.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      depthwise-conv kernel family against the HBM roofline: algorithmic bytes
+                (25.11 MB per crop) x crops per launch-set / the 16 depthwise
+                launches' duration, measured with HIP events on the library's stream
+                inside the timed region
+  cpu_baseline  the CPU oracle (torch-CPU fp32 restatement of the reference path) timed
+                on this host's cores on a bounded sample, rank 0 at N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+BATCH = 256
+
+
+def cpu_baseline(sd_np, sample_crops=32, chunk=16):
+    """Times oracle/b0_ref.forward (the checker, used here only as the CPU baseline)."""
+    import torch
+
+    import rtdfd_amd
+    from oracle import b0_ref
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = rtdfd_amd.weights.to_torch(sd_np)
+    torch.manual_seed(1)
+    x = torch.randn(chunk, 3, 224, 224)
+    b0_ref.forward(sd, x[:2])                       # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    while done < sample_crops:
+        b0_ref.forward(sd, x)
+        done += chunk
+    dt = time.perf_counter() - t0
+    # reference-style batch 1 (how backend_server.py drives it), a few calls
+    t1 = time.perf_counter()
+    for _ in range(4):
+        b0_ref.forward(sd, x[:1])
+    dt1 = (time.perf_counter() - t1) / 4
+    return {"value": round(done / dt, 2), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} crops as {done // chunk} batches of {chunk}, torch-CPU fp32 oracle; "
+                      f"batch-1 latency {dt1 * 1e3:.0f} ms",
+            "batch1_crops_per_s": round(1.0 / dt1, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+
+    import rtdfd_amd
+    from rtdfd_amd import b0_arch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    sd = rtdfd_amd.weights.seeded_state_dict(0)
+    h = rtdfd_amd._lib.Handle(rtdfd_amd.weights.pack_b0(sd), device=local_rank, max_batch=args.batch)
+
+    # synthetic crops of configs[1]: torch.manual_seed(1); randn(256,3,224,224) (seed + rank on other ranks)
+    g = torch.Generator().manual_seed(1 + rank)
+    x = torch.randn(args.batch, 3, 224, 224, generator=g).numpy()
+    xd = h.alloc(x.nbytes).upload(x)
+    yd = h.alloc(args.batch * 4)
+
+    def barrier():
+        h.sync()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        h.sync()
+
+    for _ in range(args.warmup):
+        h.classify_device(xd.ptr, args.batch, yd.ptr)
+    barrier()
+    h.profile_begin()                      # HIP events after every launch, on the library's stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h.classify_device(xd.ptr, args.batch, yd.ptr)
+    h.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    steps_seen, layers = h.profile_end()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    logits = yd.download((args.batch, 1))
+    if not np.all(np.isfinite(logits)):
+        sys.exit("non-finite logits in the timed run")
+
+    crops = args.batch * args.steps * world
+    value = crops / dt
+
+    dw_ms = sum(ms for name, ms in layers if name.endswith(".dw")) / max(steps_seen, 1)
+    all_ms = sum(ms for _, ms in layers) / max(steps_seen, 1)
+    dw_bytes = b0_arch.depthwise_bytes_per_image() * args.batch       # per step = 16 launches
+    achieved = dw_bytes / (dw_ms * 1e-3) / 1e9 if dw_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("dw_hbm_bytes_per_step")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "face-crops/sec (224x224 crops through EfficientNet-B0 classify)",
+        "value": round(value, 1), "unit": "crops/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (torch.manual_seed(1) randn crops, seeded random-init weights)",
+        "config": {"workload": "configs[1]: batch=256 random 224x224 crops, EfficientNet-B0 fp32 inference",
+                   "batch_per_gpu": args.batch, "parallelism": f"frame-shard x{world}, no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "dfd::dw_kernel<K,S,CB,TH,TW,RP> (16 depthwise launches per step)",
+                     "algorithmic_bytes_per_step": dw_bytes, "ms_per_step": round(dw_ms, 4),
+                     "share_of_step": round(dw_ms / all_ms, 4) if all_ms else None},
+        "kernel_ms_per_step": round(all_ms, 3),
+    }
+    if rank == 0:
+        if args.layers:
+            agg = {}
+            for name, ms in layers:
+                key = name.split(".")[-1] if "." in name else name
+                agg[key] = agg.get(key, 0.0) + ms / max(steps_seen, 1)
+            print("per-launch ms/step:", file=sys.stderr)
+            for name, ms in layers:
+                print(f"  {name:10s} {ms / max(steps_seen, 1):8.4f}", file=sys.stderr)
+            print("by kind:", {k: round(v, 3) for k, v in agg.items()}, file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(out), flush=True)
+    xd.free()
+    yd.free()
+    h.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,97 @@
+/*
+ * dfd_hip.h - C ABI of libdfd_hip.so, the MI355X (gfx950) implementation of the
+ * per-frame deepfake inference hot path.
+ *
+ * The reference (KrishTanna28/Real-Time-Video-Deepfake-Detection) is pure Python
+ * and has no FFI of its own; each entry point below names the
+ * reference call site whose arithmetic it replaces.  The ctypes binding that a
+ * maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative dfd_status on failure;
+ *     nothing throws or aborts across this boundary; the message for the last
+ *     failure on a handle is dfd_last_error(handle) (dfd_last_error(NULL) for
+ *     failures of dfd_create itself);
+ *   - the caller owns every host buffer; pointers are borrowed for the call only;
+ *   - "_device" variants take pointers into the handle's GPU (from dfd_device_alloc
+ *     or any hipMalloc'd / torch CUDA tensor on that device), enqueue on the
+ *     handle's HIP stream and return without synchronising;
+ *   - a handle is not re-entrant: one caller thread per handle.
+ */
+#ifndef DFD_HIP_H
+#define DFD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dfd_handle dfd_handle;
+
+typedef enum dfd_status {
+    DFD_OK = 0,
+    DFD_ERR_ARG = -1,      /* bad argument (null, size, shape)            */
+    DFD_ERR_BLOB = -2,     /* weights blob malformed or a tensor missing  */
+    DFD_ERR_HIP = -3,      /* a HIP runtime call failed                   */
+    DFD_ERR_NO_DEVICE = -4,/* no usable gfx950 device                     */
+    DFD_ERR_STATE = -5,    /* call order (e.g. detector weights not set)  */
+    DFD_ERR_CAPACITY = -6  /* batch larger than the handle was created for*/
+} dfd_status;
+
+#define DFD_ABI_VERSION 1
+#define DFD_CROP 224          /* classifier input edge, reference deepfake_detection.py:383 */
+#define DFD_FEATURES 1280     /* backbone feature width, reference model.py:46              */
+
+int dfd_abi_version(void);
+
+/* ---- lifetime ------------------------------------------------------------------
+ * Replaces the import-time model construction + weight load of reference
+ * deepfake_detection.py:30-90 (DeepfakeEfficientNet + load_state_dict + .to(DEVICE).eval()).
+ * `blob` is the packed classifier produced by weights.pack_b0 (BatchNorm folded,
+ * NHWC layouts).  `max_batch` sizes the activation workspace (9.6 MB of HBM per crop). */
+int dfd_create(int device, const void* blob, size_t blob_len, int max_batch, dfd_handle** out);
+void dfd_destroy(dfd_handle* h);
+const char* dfd_last_error(const dfd_handle* h);
+int dfd_max_batch(const dfd_handle* h);
+
+/* ---- device memory and stream plumbing (no reference counterpart) -------------- */
+int dfd_device_alloc(dfd_handle* h, size_t bytes, void** dptr);
+int dfd_device_free(dfd_handle* h, void* dptr);
+int dfd_memcpy_h2d(dfd_handle* h, void* dst_dev, const void* src_host, size_t bytes);
+int dfd_memcpy_d2h(dfd_handle* h, void* dst_host, const void* src_dev, size_t bytes);
+int dfd_sync(dfd_handle* h);
+/* HIP events on the handle's own stream (what bench.py times kernels with). */
+int dfd_timer_begin(dfd_handle* h);
+int dfd_timer_end(dfd_handle* h, float* elapsed_ms);
+
+/* ---- classifier ------------------------------------------------------------------
+ * DeepfakeEfficientNet.forward, reference model.py:63-72 (eval mode): normalised RGB
+ * float32 NCHW (n,3,224,224) -> logits (n,1).  sigmoid is applied by the caller as at
+ * reference deepfake_detection.py:397-398. */
+int dfd_classify_nchw(dfd_handle* h, const float* nchw_host, int n, float* logits_host);
+int dfd_classify_nchw_device(dfd_handle* h, const float* nchw_dev, int n, float* logits_dev);
+/* DeepfakeEfficientNet.extract_features, reference model.py:74-89: -> (n,1280). */
+int dfd_extract_features(dfd_handle* h, const float* nchw_host, int n, float* feat_host);
+
+/* Runs the forward on `nchw_dev` and copies one named intermediate to the host
+ * (NHWC float32): "stem", "b<i>.exp", "b<i>.dw", "b<i>.gate", "b<i>.out", "head",
+ * "feat", "logit".  For stage-by-stage parity tests; `count` receives the number of
+ * floats written (<= capacity). */
+int dfd_b0_tap(dfd_handle* h, const float* nchw_dev, int n, const char* name,
+               float* out_host, size_t capacity, size_t* count);
+
+/* Per-launch timing with HIP events on the handle's stream.  Between begin and end every
+ * dfd_classify_nchw_device call records an event after each kernel launch; end synchronises
+ * and returns, per launch position, the elapsed milliseconds summed over the `steps`
+ * forwards seen ("stem", "b<i>.exp", "b<i>.dw", "b<i>.se", "b<i>.proj", "head", "avgpool",
+ * "mlp").  `names` receives pointers to static strings. */
+int dfd_b0_profile_begin(dfd_handle* h);
+int dfd_b0_profile_end(dfd_handle* h, float* ms_sum, const char** names, int max_layers,
+                       int* count, int* steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFD_HIP_H */

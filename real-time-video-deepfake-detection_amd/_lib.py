@@ -1,0 +1,193 @@
+"""ctypes binding of libdfd_hip.so (include/dfd_hip.h).
+
+There is deliberately no fallback: if the shared library is missing, or no gfx950
+device is visible, every compute entry point raises `DfdError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfd_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class DfdError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libdfd_hip: {message} (status {code})")
+        self.code = code
+
+
+# name -> (restype, argtypes); the single source of truth the symbol-export test walks
+SIGNATURES = {
+    "dfd_abi_version": (C.c_int, []),
+    "dfd_create": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "dfd_destroy": (None, [C.c_void_p]),
+    "dfd_last_error": (C.c_char_p, [C.c_void_p]),
+    "dfd_max_batch": (C.c_int, [C.c_void_p]),
+    "dfd_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "dfd_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dfd_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dfd_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dfd_sync": (C.c_int, [C.c_void_p]),
+    "dfd_timer_begin": (C.c_int, [C.c_void_p]),
+    "dfd_timer_end": (C.c_int, [C.c_void_p, c_float_p]),
+    "dfd_classify_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dfd_classify_nchw_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dfd_extract_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dfd_b0_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_size_t,
+                              C.POINTER(C.c_size_t)]),
+    "dfd_b0_profile_begin": (C.c_int, [C.c_void_p]),
+    "dfd_b0_profile_end": (C.c_int, [C.c_void_p, c_float_p, C.POINTER(C.c_char_p), C.c_int,
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+}
+
+_lib: Optional[C.CDLL] = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Load the shared library and declare every prototype.  Raises if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise DfdError(-100, f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                 "or `make -C real-time-video-deepfake-detection_amd/csrc`")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError here = header/library drift
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned by a Handle."""
+
+    def __init__(self, handle: "Handle", nbytes: int):
+        self._h = handle
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        handle._check(handle._lib.dfd_device_alloc(handle._p, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, a: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        if a.nbytes > self.nbytes:
+            raise ValueError("upload larger than buffer")
+        self._h._check(self._h._lib.dfd_memcpy_h2d(self._h._p, self.ptr, _ptr(a), a.nbytes))
+        return self
+
+    def download(self, shape, dtype=np.float32) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes > self.nbytes:
+            raise ValueError("download larger than buffer")
+        self._h._check(self._h._lib.dfd_memcpy_d2h(self._h._p, _ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self._h._lib.dfd_device_free(self._h._p, self.ptr)
+            self.ptr = None
+
+
+class Handle:
+    """One (device, stream) context of the library: weights + workspaces for `max_batch` crops."""
+
+    def __init__(self, blob: bytes, device: int = 0, max_batch: int = 8):
+        self._lib = load()
+        self._blob = blob                      # keep alive during create
+        p = C.c_void_p()
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        rc = self._lib.dfd_create(int(device), buf, len(blob), int(max_batch), C.byref(p))
+        if rc != 0:
+            msg = self._lib.dfd_last_error(None)
+            raise DfdError(rc, (msg or b"dfd_create failed").decode())
+        self._p = p
+        self.device = int(device)
+        self.max_batch = int(max_batch)
+
+    # -- plumbing
+    def _check(self, rc: int):
+        if rc != 0:
+            raise DfdError(rc, (self._lib.dfd_last_error(self._p) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self._lib.dfd_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def sync(self):
+        self._check(self._lib.dfd_sync(self._p))
+
+    def timer_begin(self):
+        self._check(self._lib.dfd_timer_begin(self._p))
+
+    def timer_end(self) -> float:
+        ms = C.c_float()
+        self._check(self._lib.dfd_timer_end(self._p, C.byref(ms)))
+        return float(ms.value)
+
+    # -- classifier
+    @staticmethod
+    def _as_nchw(x) -> np.ndarray:
+        a = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+        if a.ndim != 4 or a.shape[1:] != (3, 224, 224):
+            raise ValueError(f"expected (B,3,224,224) float input, got {a.shape}")
+        return a
+
+    def classify(self, x) -> np.ndarray:
+        a = self._as_nchw(x)
+        out = np.empty((a.shape[0], 1), dtype=np.float32)
+        self._check(self._lib.dfd_classify_nchw(self._p, _ptr(a), a.shape[0], _ptr(out)))
+        return out
+
+    def classify_device(self, x_dev: int, n: int, logits_dev: int):
+        self._check(self._lib.dfd_classify_nchw_device(self._p, x_dev, int(n), logits_dev))
+
+    def extract_features(self, x) -> np.ndarray:
+        a = self._as_nchw(x)
+        out = np.empty((a.shape[0], 1280), dtype=np.float32)
+        self._check(self._lib.dfd_extract_features(self._p, _ptr(a), a.shape[0], _ptr(out)))
+        return out
+
+    def tap(self, x_dev: int, n: int, name: str, capacity: int) -> np.ndarray:
+        out = np.empty(int(capacity), dtype=np.float32)
+        cnt = C.c_size_t()
+        self._check(self._lib.dfd_b0_tap(self._p, x_dev, int(n), name.encode(), _ptr(out), out.size, C.byref(cnt)))
+        return out[: cnt.value]
+
+    def profile_begin(self):
+        self._check(self._lib.dfd_b0_profile_begin(self._p))
+
+    def profile_end(self, max_layers: int = 128):
+        """-> (steps, [(launch name, summed ms over those steps), ...])"""
+        ms = (C.c_float * max_layers)()
+        names = (C.c_char_p * max_layers)()
+        cnt, steps = C.c_int(), C.c_int()
+        self._check(self._lib.dfd_b0_profile_end(self._p, ms, names, max_layers, C.byref(cnt), C.byref(steps)))
+        return steps.value, [(names[i].decode(), float(ms[i])) for i in range(cnt.value)]

@@ -1,0 +1,35 @@
+// Launchers for the EfficientNet-B0 kernels (gfx950).  All activations are NHWC fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dfd {
+
+enum Act { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
+
+// stem: 3x3 stride-2 conv, NCHW (n,3,224,224) -> NHWC (n,112,112,32), folded BN + swish.
+void launch_stem(const float* x_nchw, const float* w /*[3][3][3][32]*/, const float* b,
+                 float* y, int n, hipStream_t s);
+
+// pointwise conv as GEMM: Y[m][o] = act( sum_k X[m][k]*gate[m/HW][k] * W[o][k] + b[o] ) + R[m][o]
+// gate / R may be null.  X rows have stride K, Y/R rows stride N.
+void launch_pointwise(const float* X, const float* W, const float* bias, const float* gate,
+                      const float* R, float* Y, int M, int K, int N, int HW, int act,
+                      hipStream_t s);
+
+// depthwise kxk conv (k in {3,5}, stride in {1,2}, TF-SAME pad) + folded BN + swish, and
+// per-tile channel sums for the squeeze-excite pool: P[n][tile][c].  Returns the tile count
+// through *tiles.  Only the 16 shape classes of EfficientNet-B0 at 224x224 are instantiated.
+bool launch_depthwise(const float* X, const float* W /*[k][k][C]*/, const float* bias, float* Y,
+                      float* P, int n, int H, int C, int k, int stride, int pad_lo,
+                      int* tiles, hipStream_t s);
+int depthwise_tiles(int H, int C, int k, int stride);
+
+// squeeze-excite gate: mean over tiles*pixels -> FC(c_se)+swish -> FC(C)+sigmoid.
+void launch_se(const float* P, int tiles, float inv_hw, const float* w1, const float* b1,
+               const float* w2t, const float* b2, float* gate, int n, int C, int c_se,
+               hipStream_t s);
+
+// global average pool over hw pixels: [n][hw][C] -> [n][C]
+void launch_avgpool(const float* X, float* Y, int n, int hw, int C, hipStream_t s);
+
+}  // namespace dfd

@@ -1,0 +1,461 @@
+// EfficientNet-B0 kernels for gfx950 (CDNA4, wave64).  NHWC fp32 activations.
+//
+//  stem_kernel      3x3 s2 conv from the NCHW network input, folded BN + swish
+//  pw_kernel<NT>    1x1 conv = GEMM on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain),
+//                   W tile double-buffered in LDS, X fragments straight to VGPRs,
+//                   epilogue: bias (+swish|relu) (+residual); optional SE gate folded
+//                   into the X operand load
+//  dw_kernel<...>   depthwise kxk conv: halo tile staged in LDS with 16-byte coalesced
+//                   channel vectors, folded BN + swish, per-tile channel sums for the
+//                   squeeze-excite pool reduced with wave shuffles
+//  se_kernel        pool finish + two tiny FCs -> per-(image,channel) gate
+//  avgpool_kernel   global average pool of the head conv output
+//
+// Semantics follow reference model.py:63-72 (forward = EfficientNet-B0 + MLP head); the
+// arithmetic of each layer is checked against oracle/b0_ref.py by tests/test_b0_gpu.py.
+#include "b0_kernels.h"
+
+namespace dfd {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float swish1(float x) { return __fdividef(x, 1.0f + __expf(-x)); }
+__device__ __forceinline__ v4f swish4(v4f v) {
+    v4f r;
+    r.x = swish1(v.x); r.y = swish1(v.y); r.z = swish1(v.z); r.w = swish1(v.w);
+    return r;
+}
+__device__ __forceinline__ v4f ldg4(const float* p) { return *reinterpret_cast<const v4f*>(p); }
+__device__ __forceinline__ void stg4(float* p, v4f v) { *reinterpret_cast<v4f*>(p) = v; }
+
+// ------------------------------------------------------------------------------ stem
+// One thread = one output pixel x 4 output channels; 8 consecutive lanes share a pixel, so
+// the 27 input taps are wave-broadcast loads and the 128-byte NHWC output row is one
+// coalesced store per 8 lanes.  TF-SAME for 224 -> 112 at k3 s2 pads one row/col at the
+// high side only (reference dependency efficientnet_pytorch Conv2dStaticSamePadding).
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x,
+                                                   const float* __restrict__ w,
+                                                   const float* __restrict__ b,
+                                                   float* __restrict__ y, int n_img) {
+    __shared__ float ws[27 * 32];
+    for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gid & 7);
+    const long long pix = gid >> 3;
+    if (pix >= (long long)n_img * 112 * 112) return;
+    const int ox = (int)(pix % 112);
+    const int oy = (int)((pix / 112) % 112);
+    const int n = (int)(pix / (112 * 112));
+    v4f acc = ldg4(b + 4 * cg);
+    const float* xb = x + (size_t)n * 3 * 224 * 224;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy + ky;
+        if (iy >= 224) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox + kx;
+            if (ix >= 224) continue;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float v = xb[(size_t)ci * 224 * 224 + iy * 224 + ix];
+                const v4f wv = *reinterpret_cast<const v4f*>(&ws[((ky * 3 + kx) * 3 + ci) * 32 + 4 * cg]);
+                acc += v * wv;
+            }
+        }
+    }
+    stg4(y + (size_t)pix * 32 + 4 * cg, swish4(acc));
+}
+
+void launch_stem(const float* x, const float* w, const float* b, float* y, int n, hipStream_t s) {
+    const long long threads = (long long)n * 112 * 112 * 8;
+    const int grid = (int)((threads + 255) / 256);
+    hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(256), 0, s, x, w, b, y, n);
+}
+
+// ------------------------------------------------------------------------ pointwise GEMM
+// D = A*B with v_mfma_f32_16x16x4_f32: A[i][k] on lane (i = l&15, k = l>>4), B[k][j] on lane
+// (j = l&15, k = l>>4), D[i][j] on lane l register r with j = l&15, i = 4*(l>>4)+r.
+// Here i = output channel, j = pixel: a lane ends with 4 consecutive channels of one pixel,
+// i.e. one 16-byte NHWC store.  Each lane fetches 4 consecutive k (one b128) per 16-wide K
+// chunk and feeds element s to MFMA s, so MFMA s sums k = {s, 4+s, 8+s, 12+s}: the same
+// permutation on both operands, which is all the contraction needs.
+constexpr int PW_MT = 2;           // 16-pixel tiles per wave
+constexpr int PW_BK = 32;          // K per LDS stage
+constexpr int PW_BKP = PW_BK + 8;  // +8 floats: conflict-free ds_read_b128 of 16 rows x 4 k-quads
+
+template <int NT>
+__global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ X,
+                                                 const float* __restrict__ W,
+                                                 const float* __restrict__ bias,
+                                                 const float* __restrict__ gate,
+                                                 const float* __restrict__ R,
+                                                 float* __restrict__ Y, int M, int K, int N,
+                                                 int HW, int act, int mblocks, int nblocks) {
+    constexpr int MT = PW_MT, BK = PW_BK, BKP = PW_BKP;
+    constexpr int BN = NT * 16, BM = 4 * MT * 16;
+    constexpr int WLOADS = (BN * (BK / 4) + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float ws[2][BN * BKP];
+
+    // XCD-aware order: blocks b and b+8 share an XCD (and its L2); give each XCD a run of
+    // m-blocks and walk the n-blocks of one m-block back to back so X is re-read from L2.
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int mblk = (idx / nblocks) * 8 + xcd, nblk = idx % nblocks;
+    if (mblk >= mblocks) return;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int n0 = nblk * BN;
+
+    int m[MT];
+    size_t gbase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        m[mt] = mblk * BM + wave * (MT * 16) + mt * 16 + j;
+        gbase[mt] = gate ? (size_t)(m[mt] < M ? m[mt] / HW : 0) * K : 0;
+    }
+
+    v4f acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    v4f wreg[WLOADS];
+    v4f xcur[MT][2], xnext[MT][2];
+
+    auto load_w = [&](int kc) {
+#pragma unroll
+        for (int t = 0; t < WLOADS; ++t) {
+            const int e = tid + t * 256;
+            const int row = e >> 3, c4 = e & 7;
+            const int n = n0 + row, k = kc + 4 * c4;
+            v4f v = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (e < BN * (BK / 4) && n < N && k < K) v = ldg4(W + (size_t)n * K + k);
+            wreg[t] = v;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < WLOADS; ++t) {
+            const int e = tid + t * 256;
+            const int row = e >> 3, c4 = e & 7;
+            if (e < BN * (BK / 4)) *reinterpret_cast<v4f*>(&ws[buf][row * BKP + 4 * c4]) = wreg[t];
+        }
+    };
+    auto load_x = [&](int kc, v4f (&xf)[MT][2]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int k = kc + cc * 16 + 4 * q;
+                v4f v = (v4f){0.f, 0.f, 0.f, 0.f};
+                if (m[mt] < M && k < K) {
+                    v = ldg4(X + (size_t)m[mt] * K + k);
+                    if (gate) v *= ldg4(gate + gbase[mt] + k);
+                }
+                xf[mt][cc] = v;
+            }
+    };
+
+    const int nk = (K + BK - 1) / BK;
+    load_w(0);
+    load_x(0, xcur);
+    store_w(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+            load_w((kt + 1) * BK);
+            load_x((kt + 1) * BK, xnext);
+        }
+        const float* wb = ws[kt & 1];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const v4f wf = *reinterpret_cast<const v4f*>(&wb[(nt * 16 + j) * BKP + cc * 16 + 4 * q]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, xcur[mt][cc].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, xcur[mt][cc].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, xcur[mt][cc].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, xcur[mt][cc].w, acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            store_w((kt + 1) & 1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                xcur[mt][0] = xnext[mt][0];
+                xcur[mt][1] = xnext[mt][1];
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds Y[m][n .. n+3]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + nt * 16 + 4 * q;
+        if (n >= N) continue;
+        const bool vec = n + 3 < N;
+        v4f bv = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (vec) bv = ldg4(bias + n);
+        else
+            for (int r = 0; r < 4; ++r)
+                if (n + r < N) bv[r] = bias[n + r];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (m[mt] >= M) continue;
+            v4f v = acc[mt][nt] + bv;
+            if (act == ACT_SWISH) v = swish4(v);
+            else if (act == ACT_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            float* yp = Y + (size_t)m[mt] * N + n;
+            if (vec) {
+                if (R) v += ldg4(R + (size_t)m[mt] * N + n);
+                stg4(yp, v);
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < N) yp[r] = v[r] + (R ? R[(size_t)m[mt] * N + n + r] : 0.f);
+            }
+        }
+    }
+}
+
+static int pick_nt(int N) {
+    // fewest n-blocks first (X is re-read once per n-block), then least padding
+    const int tiles = (N + 15) / 16;
+    int best = 1, best_blocks = 1 << 30, best_waste = 1 << 30;
+    for (int nt = 1; nt <= 10; ++nt) {
+        const int blocks = (tiles + nt - 1) / nt, waste = blocks * nt - tiles;
+        if (blocks < best_blocks || (blocks == best_blocks && waste < best_waste)) {
+            best = nt; best_blocks = blocks; best_waste = waste;
+        }
+    }
+    return best;
+}
+
+void launch_pointwise(const float* X, const float* W, const float* bias, const float* gate,
+                      const float* R, float* Y, int M, int K, int N, int HW, int act,
+                      hipStream_t s) {
+    const int nt = pick_nt(N);
+    const int BM = 4 * PW_MT * 16, BN = nt * 16;
+    const int mblocks = (M + BM - 1) / BM, nblocks = (N + BN - 1) / BN;
+    const int grid = ((mblocks + 7) / 8) * 8 * nblocks;
+#define DFD_PW_CASE(NTV)                                                                        \
+    case NTV:                                                                                   \
+        hipLaunchKernelGGL(pw_kernel<NTV>, dim3(grid), dim3(256), 0, s, X, W, bias, gate, R, Y, \
+                           M, K, N, HW, act, mblocks, nblocks);                                 \
+        break;
+    switch (nt) {
+        DFD_PW_CASE(1) DFD_PW_CASE(2) DFD_PW_CASE(3) DFD_PW_CASE(4) DFD_PW_CASE(5)
+        DFD_PW_CASE(6) DFD_PW_CASE(7) DFD_PW_CASE(8) DFD_PW_CASE(9) DFD_PW_CASE(10)
+    }
+#undef DFD_PW_CASE
+}
+
+// --------------------------------------------------------------------------- depthwise
+// Block = one image x one CB-channel chunk x one TH x TW output tile.  The (TH-1)S+K by
+// (TW-1)S+K input halo tile is staged in LDS as float4 channel vectors (zero-filled outside
+// the image: TF-SAME padding), weights too.  Thread = (channel quad, strip of RP outputs
+// along W); per kernel row it pulls the (RP-1)S+K input vectors of the strip into
+// registers once and reuses them across the K taps.
+template <int K, int S, int CB, int TH, int TW, int RP>
+__global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X,
+                                                 const float* __restrict__ Wt,
+                                                 const float* __restrict__ bias,
+                                                 float* __restrict__ Y, float* __restrict__ P,
+                                                 int H, int Ho, int C, int pad_lo, int tiles_x,
+                                                 int tiles_sp) {
+    constexpr int CG = CB / 4;
+    constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+    constexpr int SX = TW / RP, NSTRIP = TH * SX, NSLOT = 256 / CG;
+    constexpr int NIN = (RP - 1) * S + K;
+    static_assert(TW % RP == 0 && (CG & (CG - 1)) == 0 && CG <= 64, "tile shape");
+    __shared__ v4f tile[IH * IW * CG];
+    __shared__ v4f wl[K * K * CG];
+    __shared__ v4f red[4 * CG];
+
+    const int tid = threadIdx.x;
+    const int n = blockIdx.y;
+    const int t = blockIdx.x % tiles_sp, chunk = blockIdx.x / tiles_sp;
+    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW, c0 = chunk * CB;
+
+    for (int i = tid; i < K * K * CG; i += 256)
+        wl[i] = ldg4(Wt + (size_t)(i / CG) * C + c0 + 4 * (i % CG));
+
+    const float* xb = X + (size_t)n * H * H * C + c0;
+    const int iy0 = ty0 * S - pad_lo, ix0 = tx0 * S - pad_lo;
+#pragma unroll 4
+    for (int i = tid; i < IH * IW * CG; i += 256) {
+        const int cg = i % CG, pix = i / CG;
+        const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
+        v4f v = (v4f){0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H)
+            v = ldg4(xb + ((size_t)iy * H + ix) * C + 4 * cg);
+        tile[i] = v;
+    }
+    __syncthreads();
+
+    const int cg = tid % CG, slot = tid / CG;
+    const v4f bv = ldg4(bias + c0 + 4 * cg);
+    v4f psum = (v4f){0.f, 0.f, 0.f, 0.f};
+    float* yb = Y + (size_t)n * Ho * Ho * C + c0 + 4 * cg;
+    for (int strip = slot; strip < NSTRIP; strip += NSLOT) {
+        const int oy = strip / SX, ox0 = (strip % SX) * RP;
+        v4f acc[RP];
+#pragma unroll
+        for (int p = 0; p < RP; ++p) acc[p] = bv;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const v4f* row = &tile[((oy * S + ky) * IW + ox0 * S) * CG + cg];
+            v4f in[NIN];
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) in[i] = row[i * CG];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const v4f w = wl[(ky * K + kx) * CG + cg];
+#pragma unroll
+                for (int p = 0; p < RP; ++p) acc[p] += in[p * S + kx] * w;
+            }
+        }
+        const int gy = ty0 + oy;
+#pragma unroll
+        for (int p = 0; p < RP; ++p) {
+            const int gx = tx0 + ox0 + p;
+            if (gy < Ho && gx < Ho) {
+                const v4f v = swish4(acc[p]);
+                stg4(yb + ((size_t)gy * Ho + gx) * C, v);
+                psum += v;
+            }
+        }
+    }
+    // squeeze-excite pool: lanes whose ids differ by a multiple of CG hold the same channels
+#pragma unroll
+    for (int off = CG; off < 64; off <<= 1) {
+        psum.x += __shfl_xor(psum.x, off);
+        psum.y += __shfl_xor(psum.y, off);
+        psum.z += __shfl_xor(psum.z, off);
+        psum.w += __shfl_xor(psum.w, off);
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < CG) red[wave * CG + lane] = psum;
+    __syncthreads();
+    if (tid < CG) {
+        const v4f v = (red[tid] + red[CG + tid]) + (red[2 * CG + tid] + red[3 * CG + tid]);
+        stg4(P + ((size_t)n * tiles_sp + t) * C + c0 + 4 * tid, v);
+    }
+}
+
+struct DwCfg { int k, s, H, cb, th, tw; };
+
+template <int K, int S, int CB, int TH, int TW, int RP>
+static void dw_launch(const float* X, const float* W, const float* b, float* Y, float* P, int n,
+                      int H, int C, int pad_lo, int* tiles, hipStream_t s) {
+    const int Ho = (H + S - 1) / S;
+    const int tx = (Ho + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
+    const int tiles_sp = tx * ty;
+    *tiles = tiles_sp;
+    hipLaunchKernelGGL((dw_kernel<K, S, CB, TH, TW, RP>), dim3(tiles_sp * (C / CB), n), dim3(256), 0,
+                       s, X, W, b, Y, P, H, Ho, C, pad_lo, tx, tiles_sp);
+}
+
+// tile shapes per B0 depthwise layer class: (k, stride, H_in, C) -> <K,S,CB,TH,TW,RP>
+#define DFD_DW_TABLE(OP)                                  \
+    OP(3, 1, 112, 32, 32, 8, 16, 4)   /* block 0      */  \
+    OP(3, 2, 112, 96, 32, 8, 8, 2)    /* block 1      */  \
+    OP(3, 1, 56, 144, 16, 8, 14, 2)   /* block 2      */  \
+    OP(5, 2, 56, 144, 16, 7, 14, 2)   /* block 3      */  \
+    OP(5, 1, 28, 240, 16, 14, 14, 2)  /* block 4      */  \
+    OP(3, 2, 28, 240, 16, 7, 14, 2)   /* block 5      */  \
+    OP(3, 1, 14, 480, 32, 14, 14, 7)  /* blocks 6,7   */  \
+    OP(5, 1, 14, 480, 32, 14, 14, 7)  /* block 8      */  \
+    OP(5, 1, 14, 672, 32, 14, 14, 7)  /* blocks 9,10  */  \
+    OP(5, 2, 14, 672, 32, 7, 7, 1)    /* block 11     */  \
+    OP(5, 1, 7, 1152, 32, 7, 7, 1)    /* blocks 12-14 */  \
+    OP(3, 1, 7, 1152, 32, 7, 7, 1)    /* block 15     */
+
+bool launch_depthwise(const float* X, const float* W, const float* bias, float* Y, float* P, int n,
+                      int H, int C, int k, int stride, int pad_lo, int* tiles, hipStream_t s) {
+#define DFD_DW_DISPATCH(KK, SS, HH, CC, CB, TH, TW, RP)                                \
+    if (k == KK && stride == SS && H == HH && C == CC) {                               \
+        dw_launch<KK, SS, CB, TH, TW, RP>(X, W, bias, Y, P, n, H, C, pad_lo, tiles, s); \
+        return true;                                                                   \
+    }
+    DFD_DW_TABLE(DFD_DW_DISPATCH)
+#undef DFD_DW_DISPATCH
+    return false;
+}
+
+int depthwise_tiles(int H, int C, int k, int stride) {
+    const int Ho = (H + stride - 1) / stride;
+#define DFD_DW_TILES(KK, SS, HH, CC, CB, TH, TW, RP) \
+    if (k == KK && stride == SS && H == HH && C == CC) return ((Ho + TW - 1) / TW) * ((Ho + TH - 1) / TH);
+    DFD_DW_TABLE(DFD_DW_TILES)
+#undef DFD_DW_TILES
+    return -1;
+}
+
+// ---------------------------------------------------------------------- squeeze-excite
+// One block per image.  mean[c] = sum over tiles of P / (H*W); z = swish(W1 mean + b1);
+// gate = sigmoid(W2 z + b2)   (efficientnet_pytorch MBConvBlock SE branch).
+__global__ __launch_bounds__(256) void se_kernel(const float* __restrict__ P, int tiles, float inv_hw,
+                                                 const float* __restrict__ w1,
+                                                 const float* __restrict__ b1,
+                                                 const float* __restrict__ w2t,
+                                                 const float* __restrict__ b2,
+                                                 float* __restrict__ gate, int C, int c_se) {
+    __shared__ float mean[1152];
+    __shared__ float z[64];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* p = P + (size_t)n * tiles * C;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int t = 0; t < tiles; ++t) s += p[(size_t)t * C + c];
+        mean[c] = s * inv_hw;
+    }
+    __syncthreads();
+    for (int o = wave; o < c_se; o += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += mean[c] * w1[(size_t)o * C + c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) z[o] = swish1(s + b1[o]);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = b2[c];
+        for (int o = 0; o < c_se; ++o) s += z[o] * w2t[(size_t)o * C + c];
+        gate[(size_t)n * C + c] = 1.0f / (1.0f + __expf(-s));
+    }
+}
+
+void launch_se(const float* P, int tiles, float inv_hw, const float* w1, const float* b1,
+               const float* w2t, const float* b2, float* gate, int n, int C, int c_se, hipStream_t s) {
+    hipLaunchKernelGGL(se_kernel, dim3(n), dim3(256), 0, s, P, tiles, inv_hw, w1, b1, w2t, b2, gate, C, c_se);
+}
+
+// ------------------------------------------------------------------- global average pool
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ X,
+                                                      float* __restrict__ Y, int n_img, int hw, int C) {
+    const int c4 = C / 4;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)n_img * c4) return;
+    const int n = (int)(gid / c4), c = (int)(gid % c4) * 4;
+    const float* p = X + (size_t)n * hw * C + c;
+    v4f s = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < hw; ++i) s += ldg4(p + (size_t)i * C);
+    stg4(Y + (size_t)n * C + c, s * (1.0f / (float)hw));
+}
+
+void launch_avgpool(const float* X, float* Y, int n, int hw, int C, hipStream_t s) {
+    const long long threads = (long long)n * (C / 4);
+    hipLaunchKernelGGL(avgpool_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, X, Y, n, hw, C);
+}
+
+}  // namespace dfd

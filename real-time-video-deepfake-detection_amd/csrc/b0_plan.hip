@@ -1,0 +1,235 @@
+// Host side of the classifier: weights blob -> device tensors -> per-layer launch plan.
+// The block table restates efficientnet_pytorch's B0 arguments (the dependency the
+// reference builds its backbone from, reference model.py:39-43) and must agree with
+// b0_arch.py; dfd_create checks every tensor's shape against it.
+#include "b0_kernels.h"
+#include "dfd_common.h"
+
+namespace dfd {
+
+thread_local std::string g_create_error;
+
+int fail(dfd_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+bool parse_blob(const void* blob, size_t len, std::map<std::string, Tensor>* out, std::string* err) {
+    const uint8_t* p = static_cast<const uint8_t*>(blob);
+    if (!p || len < 12 || memcmp(p, "DFDW", 4) != 0) { *err = "blob: bad magic"; return false; }
+    uint32_t ver, cnt;
+    memcpy(&ver, p + 4, 4);
+    memcpy(&cnt, p + 8, 4);
+    if (ver != 1) { *err = "blob: unsupported version"; return false; }
+    const size_t esz = 48 + 4 + 16 + 8 + 8;
+    if (12 + (size_t)cnt * esz > len) { *err = "blob: truncated table"; return false; }
+    for (uint32_t i = 0; i < cnt; ++i) {
+        const uint8_t* e = p + 12 + (size_t)i * esz;
+        char name[49];
+        memcpy(name, e, 48);
+        name[48] = 0;
+        Tensor t;
+        memcpy(&t.ndim, e + 48, 4);
+        memcpy(t.dims, e + 52, 16);
+        uint64_t off, nb;
+        memcpy(&off, e + 68, 8);
+        memcpy(&nb, e + 76, 8);
+        if (t.ndim > 4 || off % 4 || off + nb > len) { *err = std::string("blob: bad entry ") + name; return false; }
+        t.count = 1;
+        for (uint32_t d = 0; d < t.ndim; ++d) t.count *= t.dims[d];
+        if (t.count * 4 != nb) { *err = std::string("blob: size mismatch for ") + name; return false; }
+        t.host = reinterpret_cast<const float*>(p + off);
+        (*out)[name] = t;
+    }
+    return true;
+}
+
+namespace {
+
+struct Stage { int rep, k, s, e, ci, co; };
+const Stage kStages[] = {{1, 3, 1, 1, 32, 16}, {2, 3, 2, 6, 16, 24}, {2, 5, 2, 6, 24, 40},
+                         {3, 3, 2, 6, 40, 80}, {3, 5, 1, 6, 80, 112}, {4, 5, 2, 6, 112, 192},
+                         {1, 3, 1, 6, 192, 320}};
+
+const float* need(dfd_handle* h, const std::string& name, std::initializer_list<uint32_t> dims, bool* ok) {
+    auto it = h->tensors.find(name);
+    if (it == h->tensors.end()) {
+        if (*ok) fail(h, DFD_ERR_BLOB, "weights blob: tensor '%s' missing", name.c_str());
+        *ok = false;
+        return nullptr;
+    }
+    const Tensor& t = it->second;
+    size_t want = 1;
+    for (uint32_t d : dims) want *= d;
+    if (t.count != want) {
+        if (*ok) fail(h, DFD_ERR_BLOB, "weights blob: tensor '%s' has %zu elements, expected %zu", name.c_str(), t.count, want);
+        *ok = false;
+        return nullptr;
+    }
+    return t.dev;
+}
+
+}  // namespace
+
+int b0_build_plan(dfd_handle* h) {
+    B0Plan& P = h->b0;
+    bool ok = true;
+    P.stem_w = need(h, "stem.w", {3, 3, 3, 32}, &ok);
+    P.stem_b = need(h, "stem.b", {32}, &ok);
+    int hcur = 112, idx = 0;
+    P.io_floats = (size_t)112 * 112 * 32;
+    for (const Stage& st : kStages) {
+        for (int r = 0; r < st.rep; ++r, ++idx) {
+            B0Block b{};
+            b.kernel = st.k;
+            b.stride = r == 0 ? st.s : 1;
+            b.expand = st.e;
+            b.c_in = r == 0 ? st.ci : st.co;
+            b.c_out = st.co;
+            b.c_exp = b.c_in * st.e;
+            b.c_se = b.c_in / 4 > 0 ? b.c_in / 4 : 1;
+            b.h_in = hcur;
+            b.h_out = (hcur + b.stride - 1) / b.stride;
+            const int total = (b.h_out - 1) * b.stride + b.kernel - b.h_in;
+            b.pad_lo = (total > 0 ? total : 0) / 2;
+            b.skip = b.stride == 1 && b.c_in == b.c_out;
+            const std::string q = "b" + std::to_string(idx);
+            const uint32_t ce = b.c_exp, ci = b.c_in, co = b.c_out, cs = b.c_se, k = b.kernel;
+            if (b.expand != 1) {
+                b.exp_w = need(h, q + ".exp.w", {ce, ci}, &ok);
+                b.exp_b = need(h, q + ".exp.b", {ce}, &ok);
+            }
+            b.dw_w = need(h, q + ".dw.w", {k, k, ce}, &ok);
+            b.dw_b = need(h, q + ".dw.b", {ce}, &ok);
+            b.se_w1 = need(h, q + ".se.w1", {cs, ce}, &ok);
+            b.se_b1 = need(h, q + ".se.b1", {cs}, &ok);
+            b.se_w2 = need(h, q + ".se.w2", {cs, ce}, &ok);
+            b.se_b2 = need(h, q + ".se.b2", {ce}, &ok);
+            b.proj_w = need(h, q + ".proj.w", {co, ce}, &ok);
+            b.proj_b = need(h, q + ".proj.b", {co}, &ok);
+            b.dw_tiles = depthwise_tiles(b.h_in, b.c_exp, b.kernel, b.stride);
+            if (b.dw_tiles < 0) return fail(h, DFD_ERR_STATE, "no depthwise kernel for block %d", idx);
+            auto mx = [](size_t& a, size_t v) { if (v > a) a = v; };
+            mx(P.io_floats, (size_t)b.h_out * b.h_out * b.c_out);
+            if (b.expand != 1) mx(P.exp_floats, (size_t)b.h_in * b.h_in * b.c_exp);
+            mx(P.dw_floats, (size_t)b.h_out * b.h_out * b.c_exp);
+            mx(P.pool_floats, (size_t)b.dw_tiles * b.c_exp);
+            mx(P.gate_floats, (size_t)b.c_exp);
+            P.blocks.push_back(b);
+            hcur = b.h_out;
+        }
+    }
+    P.head_w = need(h, "head.w", {1280, 320}, &ok);
+    P.head_b = need(h, "head.b", {1280}, &ok);
+    P.fc1_w = need(h, "fc1.w", {512, 1280}, &ok);
+    P.fc1_b = need(h, "fc1.b", {512}, &ok);
+    P.fc2_w = need(h, "fc2.w", {256, 512}, &ok);
+    P.fc2_b = need(h, "fc2.b", {256}, &ok);
+    P.fc3_w = need(h, "fc3.w", {1, 256}, &ok);
+    P.fc3_b = need(h, "fc3.b", {1}, &ok);
+    return ok ? DFD_OK : DFD_ERR_BLOB;
+}
+
+namespace {
+
+struct Marks {
+    B0Prof* prof;
+    hipStream_t s;
+    void mark(const char* name) {
+        if (!prof || !prof->enabled) return;
+        hipEvent_t e;
+        hipEventCreate(&e);
+        hipEventRecord(e, s);
+        prof->events.push_back(e);
+        prof->names.push_back(name);
+    }
+};
+
+// copy a device buffer out if it is the requested tap
+int tap_out(dfd_handle* h, B0Tap* tap, const std::string& name, const float* dev, size_t count) {
+    if (!tap || !tap->name || tap->found || name != tap->name) return DFD_OK;
+    tap->found = true;
+    if (count > tap->capacity) return fail(h, DFD_ERR_ARG, "tap '%s' needs %zu floats, capacity %zu", tap->name, count, tap->capacity);
+    DFD_HIP_TRY(h, hipMemcpyAsync(tap->out, dev, count * 4, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    tap->count = count;
+    return DFD_OK;
+}
+
+// static names for the profiler (one per launch, in launch order)
+const char* layer_name(int blk, const char* what) {
+    static std::map<std::string, std::string> pool;
+    const std::string key = "b" + std::to_string(blk) + "." + what;
+    return pool.emplace(key, key).first->second.c_str();
+}
+
+}  // namespace
+
+int b0_forward(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* tap, B0Prof* prof) {
+    if (n <= 0) return fail(h, DFD_ERR_ARG, "batch must be positive");
+    if (n > h->max_batch) return fail(h, DFD_ERR_CAPACITY, "batch %d exceeds handle capacity %d", n, h->max_batch);
+    const B0Plan& P = h->b0;
+    hipStream_t s = h->stream;
+    Marks mk{prof, s};
+    int rc;
+    mk.mark("start");
+    launch_stem(x, P.stem_w, P.stem_b, h->io0, n, s);
+    mk.mark("stem");
+    if ((rc = tap_out(h, tap, "stem", h->io0, (size_t)n * 112 * 112 * 32))) return rc;
+    float* cur = h->io0;
+    float* nxt = h->io1;
+    int bi = 0;
+    for (const B0Block& b : P.blocks) {
+        const int m_in = n * b.h_in * b.h_in, m_out = n * b.h_out * b.h_out;
+        const std::string q = "b" + std::to_string(bi);
+        const float* dw_in = cur;
+        if (b.expand != 1) {
+            launch_pointwise(cur, b.exp_w, b.exp_b, nullptr, nullptr, h->expbuf, m_in, b.c_in, b.c_exp,
+                             b.h_in * b.h_in, ACT_SWISH, s);
+            mk.mark(layer_name(bi, "exp"));
+            if ((rc = tap_out(h, tap, q + ".exp", h->expbuf, (size_t)m_in * b.c_exp))) return rc;
+            dw_in = h->expbuf;
+        }
+        int tiles = 0;
+        if (!launch_depthwise(dw_in, b.dw_w, b.dw_b, h->dwbuf, h->pool, n, b.h_in, b.c_exp, b.kernel,
+                              b.stride, b.pad_lo, &tiles, s))
+            return fail(h, DFD_ERR_STATE, "no depthwise kernel for block %d", bi);
+        mk.mark(layer_name(bi, "dw"));
+        if ((rc = tap_out(h, tap, q + ".dw", h->dwbuf, (size_t)m_out * b.c_exp))) return rc;
+        launch_se(h->pool, tiles, 1.0f / (float)(b.h_out * b.h_out), b.se_w1, b.se_b1, b.se_w2, b.se_b2,
+                  h->gate, n, b.c_exp, b.c_se, s);
+        mk.mark(layer_name(bi, "se"));
+        if ((rc = tap_out(h, tap, q + ".gate", h->gate, (size_t)n * b.c_exp))) return rc;
+        launch_pointwise(h->dwbuf, b.proj_w, b.proj_b, h->gate, b.skip ? cur : nullptr, nxt, m_out,
+                         b.c_exp, b.c_out, b.h_out * b.h_out, ACT_NONE, s);
+        mk.mark(layer_name(bi, "proj"));
+        if ((rc = tap_out(h, tap, q + ".out", nxt, (size_t)m_out * b.c_out))) return rc;
+        float* t = cur; cur = nxt; nxt = t;
+        ++bi;
+    }
+    const B0Block& last = P.blocks.back();
+    const int hw = last.h_out * last.h_out;
+    launch_pointwise(cur, P.head_w, P.head_b, nullptr, nullptr, h->headbuf, n * hw, last.c_out, 1280, hw,
+                     ACT_SWISH, s);
+    mk.mark("head");
+    if ((rc = tap_out(h, tap, "head", h->headbuf, (size_t)n * hw * 1280))) return rc;
+    launch_avgpool(h->headbuf, h->feat, n, hw, 1280, s);
+    mk.mark("avgpool");
+    if ((rc = tap_out(h, tap, "feat", h->feat, (size_t)n * 1280))) return rc;
+    if (!logits_dev) return DFD_OK;   // extract_features stops here
+    launch_pointwise(h->feat, P.fc1_w, P.fc1_b, nullptr, nullptr, h->fc1, n, 1280, 512, 1, ACT_RELU, s);
+    launch_pointwise(h->fc1, P.fc2_w, P.fc2_b, nullptr, nullptr, h->fc2, n, 512, 256, 1, ACT_RELU, s);
+    launch_pointwise(h->fc2, P.fc3_w, P.fc3_b, nullptr, nullptr, logits_dev, n, 256, 1, 1, ACT_NONE, s);
+    mk.mark("mlp");
+    if ((rc = tap_out(h, tap, "logit", logits_dev, (size_t)n))) return rc;
+    DFD_HIP_TRY(h, hipGetLastError());
+    return DFD_OK;
+}
+
+}  // namespace dfd

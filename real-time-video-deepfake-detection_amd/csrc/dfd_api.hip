@@ -1,0 +1,244 @@
+// extern "C" surface of libdfd_hip.so (declared in include/dfd_hip.h).
+#include "b0_kernels.h"
+#include "dfd_common.h"
+
+using namespace dfd;
+
+namespace {
+
+int dev_alloc(dfd_handle* h, size_t bytes, float** out) {
+    void* p = nullptr;
+    DFD_HIP_TRY(h, hipMalloc(&p, bytes ? bytes : 4));
+    h->owned.push_back(p);
+    *out = static_cast<float*>(p);
+    return DFD_OK;
+}
+
+int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, int max_batch) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, DFD_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(h, DFD_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    DFD_HIP_TRY(h, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    DFD_HIP_TRY(h, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(h, DFD_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    h->device = device;
+    h->max_batch = max_batch;
+    DFD_HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    DFD_HIP_TRY(h, hipEventCreate(&h->ev0));
+    DFD_HIP_TRY(h, hipEventCreate(&h->ev1));
+
+    std::string perr;
+    if (!parse_blob(blob, blob_len, &h->tensors, &perr)) return fail(h, DFD_ERR_BLOB, "%s", perr.c_str());
+    // one device allocation for all weights, 256-byte aligned slots
+    size_t total = 0;
+    for (auto& kv : h->tensors) total += (kv.second.count * 4 + 255) / 256 * 256;
+    float* wbase = nullptr;
+    int rc = dev_alloc(h, total, &wbase);
+    if (rc) return rc;
+    size_t off = 0;
+    for (auto& kv : h->tensors) {
+        Tensor& t = kv.second;
+        t.dev = reinterpret_cast<float*>(reinterpret_cast<char*>(wbase) + off);
+        DFD_HIP_TRY(h, hipMemcpy(t.dev, t.host, t.count * 4, hipMemcpyHostToDevice));
+        t.host = nullptr;
+        off += (t.count * 4 + 255) / 256 * 256;
+    }
+    if ((rc = b0_build_plan(h))) return rc;
+
+    const B0Plan& P = h->b0;
+    const size_t nb = (size_t)max_batch;
+    if ((rc = dev_alloc(h, nb * 3 * 224 * 224 * 4, &h->in_nchw))) return rc;
+    if ((rc = dev_alloc(h, nb * P.io_floats * 4, &h->io0))) return rc;
+    if ((rc = dev_alloc(h, nb * P.io_floats * 4, &h->io1))) return rc;
+    if ((rc = dev_alloc(h, nb * P.exp_floats * 4, &h->expbuf))) return rc;
+    if ((rc = dev_alloc(h, nb * P.dw_floats * 4, &h->dwbuf))) return rc;
+    if ((rc = dev_alloc(h, nb * P.pool_floats * 4, &h->pool))) return rc;
+    if ((rc = dev_alloc(h, nb * P.gate_floats * 4, &h->gate))) return rc;
+    if ((rc = dev_alloc(h, nb * 49 * 1280 * 4, &h->headbuf))) return rc;
+    if ((rc = dev_alloc(h, nb * 1280 * 4, &h->feat))) return rc;
+    if ((rc = dev_alloc(h, nb * 512 * 4, &h->fc1))) return rc;
+    if ((rc = dev_alloc(h, nb * 256 * 4, &h->fc2))) return rc;
+    if ((rc = dev_alloc(h, nb * 4, &h->logits))) return rc;
+    return DFD_OK;
+}
+
+void destroy_impl(dfd_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void* p : h->owned) hipFree(p);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dfd_abi_version(void) { return DFD_ABI_VERSION; }
+
+int dfd_create(int device, const void* blob, size_t blob_len, int max_batch, dfd_handle** out) {
+    if (!out) return fail(nullptr, DFD_ERR_ARG, "dfd_create: out is null");
+    *out = nullptr;
+    if (!blob || max_batch <= 0 || max_batch > 4096)
+        return fail(nullptr, DFD_ERR_ARG, "dfd_create: blob is null or max_batch outside 1..4096");
+    dfd_handle* h = new (std::nothrow) dfd_handle();
+    if (!h) return fail(nullptr, DFD_ERR_ARG, "dfd_create: out of host memory");
+    const int rc = create_impl(h, device, blob, blob_len, max_batch);
+    if (rc != DFD_OK) {
+        g_create_error = h->err;
+        destroy_impl(h);
+        return rc;
+    }
+    *out = h;
+    return DFD_OK;
+}
+
+void dfd_destroy(dfd_handle* h) { destroy_impl(h); }
+
+const char* dfd_last_error(const dfd_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dfd_max_batch(const dfd_handle* h) { return h ? h->max_batch : DFD_ERR_ARG; }
+
+int dfd_device_alloc(dfd_handle* h, size_t bytes, void** dptr) {
+    if (!h || !dptr) return DFD_ERR_ARG;
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    DFD_HIP_TRY(h, hipMalloc(dptr, bytes ? bytes : 4));
+    return DFD_OK;
+}
+
+int dfd_device_free(dfd_handle* h, void* dptr) {
+    if (!h) return DFD_ERR_ARG;
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, hipFree(dptr));
+    return DFD_OK;
+}
+
+int dfd_memcpy_h2d(dfd_handle* h, void* dst, const void* src, size_t bytes) {
+    if (!h || (!dst && bytes) || (!src && bytes)) return h ? fail(h, DFD_ERR_ARG, "memcpy_h2d: null pointer") : DFD_ERR_ARG;
+    DFD_HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DFD_OK;
+}
+
+int dfd_memcpy_d2h(dfd_handle* h, void* dst, const void* src, size_t bytes) {
+    if (!h || (!dst && bytes) || (!src && bytes)) return h ? fail(h, DFD_ERR_ARG, "memcpy_d2h: null pointer") : DFD_ERR_ARG;
+    DFD_HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DFD_OK;
+}
+
+int dfd_sync(dfd_handle* h) {
+    if (!h) return DFD_ERR_ARG;
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DFD_OK;
+}
+
+int dfd_timer_begin(dfd_handle* h) {
+    if (!h) return DFD_ERR_ARG;
+    DFD_HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    return DFD_OK;
+}
+
+int dfd_timer_end(dfd_handle* h, float* ms) {
+    if (!h || !ms) return DFD_ERR_ARG;
+    DFD_HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    DFD_HIP_TRY(h, hipEventSynchronize(h->ev1));
+    DFD_HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return DFD_OK;
+}
+
+int dfd_classify_nchw_device(dfd_handle* h, const float* nchw_dev, int n, float* logits_dev) {
+    if (!h) return DFD_ERR_ARG;
+    if (!nchw_dev || !logits_dev) return fail(h, DFD_ERR_ARG, "classify: null pointer");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    if (h->prof.enabled) ++h->prof_steps;
+    return b0_forward(h, nchw_dev, n, logits_dev, nullptr, h->prof.enabled ? &h->prof : nullptr);
+}
+
+int dfd_classify_nchw(dfd_handle* h, const float* nchw_host, int n, float* logits_host) {
+    if (!h) return DFD_ERR_ARG;
+    if (!nchw_host || !logits_host) return fail(h, DFD_ERR_ARG, "classify: null pointer");
+    if (n <= 0 || n > h->max_batch) return fail(h, n <= 0 ? DFD_ERR_ARG : DFD_ERR_CAPACITY, "classify: batch %d outside 1..%d", n, h->max_batch);
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    DFD_HIP_TRY(h, hipMemcpyAsync(h->in_nchw, nchw_host, (size_t)n * 3 * 224 * 224 * 4, hipMemcpyHostToDevice, h->stream));
+    const int rc = b0_forward(h, h->in_nchw, n, h->logits, nullptr, nullptr);
+    if (rc) return rc;
+    DFD_HIP_TRY(h, hipMemcpyAsync(logits_host, h->logits, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DFD_OK;
+}
+
+int dfd_extract_features(dfd_handle* h, const float* nchw_host, int n, float* feat_host) {
+    if (!h) return DFD_ERR_ARG;
+    if (!nchw_host || !feat_host) return fail(h, DFD_ERR_ARG, "extract_features: null pointer");
+    if (n <= 0 || n > h->max_batch) return fail(h, n <= 0 ? DFD_ERR_ARG : DFD_ERR_CAPACITY, "extract_features: batch %d outside 1..%d", n, h->max_batch);
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    DFD_HIP_TRY(h, hipMemcpyAsync(h->in_nchw, nchw_host, (size_t)n * 3 * 224 * 224 * 4, hipMemcpyHostToDevice, h->stream));
+    const int rc = b0_forward(h, h->in_nchw, n, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    DFD_HIP_TRY(h, hipMemcpyAsync(feat_host, h->feat, (size_t)n * 1280 * 4, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DFD_OK;
+}
+
+int dfd_b0_tap(dfd_handle* h, const float* nchw_dev, int n, const char* name, float* out_host,
+               size_t capacity, size_t* count) {
+    if (!h) return DFD_ERR_ARG;
+    if (!nchw_dev || !name || !out_host || !count) return fail(h, DFD_ERR_ARG, "tap: null pointer");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    B0Tap tap;
+    tap.name = name;
+    tap.out = out_host;
+    tap.capacity = capacity;
+    const int rc = b0_forward(h, nchw_dev, n, h->logits, &tap, nullptr);
+    if (rc) return rc;
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!tap.found) return fail(h, DFD_ERR_ARG, "tap: unknown stage '%s'", name);
+    *count = tap.count;
+    return DFD_OK;
+}
+
+int dfd_b0_profile_begin(dfd_handle* h) {
+    if (!h) return DFD_ERR_ARG;
+    for (hipEvent_t e : h->prof.events) hipEventDestroy(e);
+    h->prof.events.clear();
+    h->prof.names.clear();
+    h->prof.enabled = true;
+    h->prof_steps = 0;
+    return DFD_OK;
+}
+
+int dfd_b0_profile_end(dfd_handle* h, float* ms_sum, const char** names, int max_layers, int* count,
+                       int* steps) {
+    if (!h) return DFD_ERR_ARG;
+    if (!ms_sum || !names || !count || !steps) return fail(h, DFD_ERR_ARG, "profile_end: null pointer");
+    h->prof.enabled = false;
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int nsteps = h->prof_steps;
+    const size_t per = nsteps > 0 ? h->prof.events.size() / nsteps : 0;   // marks per forward
+    int k = 0;
+    for (size_t i = 1; i < per && k < max_layers; ++i, ++k) {
+        double acc = 0.0;
+        for (int st = 0; st < nsteps; ++st) {
+            float t = 0.f;
+            hipEventElapsedTime(&t, h->prof.events[st * per + i - 1], h->prof.events[st * per + i]);
+            acc += t;
+        }
+        ms_sum[k] = (float)acc;
+        names[k] = h->prof.names[i];
+    }
+    for (hipEvent_t e : h->prof.events) hipEventDestroy(e);
+    h->prof.events.clear();
+    h->prof.names.clear();
+    *count = k;
+    *steps = nsteps;
+    return DFD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// Shared host-side pieces of libdfd_hip.so: status plumbing, the weights-blob reader and
+// the handle.  Nothing here crosses the C ABI; include/dfd_hip.h is the public surface.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dfd_hip.h"
+
+namespace dfd {
+
+struct Tensor {
+    const float* host = nullptr;   // into the caller's blob (valid during dfd_create only)
+    float* dev = nullptr;          // device copy owned by the handle
+    uint32_t ndim = 0;
+    uint32_t dims[4] = {1, 1, 1, 1};
+    size_t count = 0;
+};
+
+// Blob layout written by weights.serialize(): "DFDW" u32 version u32 count, then
+// {char name[48]; u32 ndim; u32 dims[4]; u64 offset; u64 nbytes} entries, then payloads.
+bool parse_blob(const void* blob, size_t len, std::map<std::string, Tensor>* out, std::string* err);
+
+struct B0Block {
+    int kernel, stride, expand, c_in, c_out, c_exp, c_se, h_in, h_out, pad_lo;
+    bool skip;
+    const float *exp_w, *exp_b, *dw_w, *dw_b, *se_w1, *se_b1, *se_w2, *se_b2, *proj_w, *proj_b;
+    int dw_tiles;
+};
+
+struct B0Plan {
+    std::vector<B0Block> blocks;
+    const float *stem_w, *stem_b, *head_w, *head_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *fc3_w, *fc3_b;
+    // workspace (floats per image)
+    size_t io_floats = 0, exp_floats = 0, dw_floats = 0, pool_floats = 0, gate_floats = 0;
+};
+
+struct B0Tap {
+    const char* name = nullptr;   // stage to copy out, or null
+    float* out = nullptr;
+    size_t capacity = 0, count = 0;
+    bool found = false;
+};
+struct B0Prof {
+    std::vector<hipEvent_t> events;
+    std::vector<const char*> names;
+    bool enabled = false;
+};
+
+}  // namespace dfd
+
+struct dfd_handle {
+    int device = 0;
+    int max_batch = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<std::string, dfd::Tensor> tensors;
+    std::vector<void*> owned;            // every hipMalloc the handle must free
+    dfd::B0Plan b0;
+    // classifier workspace
+    float *in_nchw = nullptr, *io0 = nullptr, *io1 = nullptr, *expbuf = nullptr, *dwbuf = nullptr;
+    float *pool = nullptr, *gate = nullptr, *headbuf = nullptr, *feat = nullptr, *fc1 = nullptr,
+          *fc2 = nullptr, *logits = nullptr;
+    dfd::B0Prof prof;                    // layer events between profile_begin/end
+    int prof_steps = 0;
+    std::string err;
+};
+
+namespace dfd {
+
+extern thread_local std::string g_create_error;
+
+int fail(dfd_handle* h, int code, const char* fmt, ...);
+
+#define DFD_HIP_TRY(h, expr)                                                                    \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return dfd::fail((h), DFD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                             __FILE__, __LINE__);                                               \
+    } while (0)
+
+// b0_plan.cpp
+int b0_build_plan(dfd_handle* h);
+// Runs the classifier on h->stream.  `stop_at_features`: leave after the pooled 1280-vector.
+int b0_forward(dfd_handle* h, const float* nchw_dev, int n, float* logits_dev, B0Tap* tap,
+               B0Prof* prof);
+
+}  // namespace dfd

@@ -1,0 +1,186 @@
+"""Weights for the classifier: seeded generator, checkpoint reader, and packer.
+
+The reference loads ``weights/best_model.pth`` (``{'model_state_dict': ...}`` or a
+bare state dict, keys prefixed ``net.``; reference deepfake_detection.py:44-51,
+train.py:1034-1055).  That file is not in the reference tree, so benchmarks and
+tests use `seeded_state_dict` - random-init weights of the same architecture and
+key names.  `pack_b0` turns any such state dict into the kernel-ready blob the
+C ABI (`dfd_create`, include/dfd_hip.h) takes: BatchNorm folded into the
+preceding conv/linear in float64, weights re-laid out for NHWC kernels.
+
+Blob layout (little endian): ``b"DFDW" u32 version u32 count`` then per tensor
+``char name[48]; u32 ndim; u32 dims[4]; u64 offset; u64 nbytes`` and, 64-byte
+aligned, the float32 payloads.
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, Mapping
+
+import numpy as np
+
+from . import b0_arch as A
+
+BLOB_MAGIC = b"DFDW"
+BLOB_VERSION = 1
+_NAME_LEN = 48
+
+
+# --------------------------------------------------------------------------- generator
+def seeded_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
+    """Random-init state dict with the reference's key names (``net.*``).
+
+    conv ~ N(0, g^2/fan_in) with a gain that keeps swish activations O(1),
+    BN gamma~U(.8,1.2), beta~N(0,.1), running_mean~N(0,.1), running_var~U(.8,1.2),
+    Linear ~ U(+-3/sqrt(fan_in)).  Deterministic in `seed`
+    (numpy RandomState, independent of the torch version).
+    """
+    rs = np.random.RandomState(seed)
+    sd: Dict[str, np.ndarray] = {}
+
+    def conv(name, co, ci_g, k, gain=1.6):
+        fan_in = ci_g * k * k
+        sd[name + ".weight"] = (rs.randn(co, ci_g, k, k) * (gain / np.sqrt(fan_in))).astype(np.float32)
+
+    def bn(name, c):
+        sd[name + ".weight"] = rs.uniform(0.8, 1.2, c).astype(np.float32)
+        sd[name + ".bias"] = (rs.randn(c) * 0.1).astype(np.float32)
+        sd[name + ".running_mean"] = (rs.randn(c) * 0.1).astype(np.float32)
+        sd[name + ".running_var"] = rs.uniform(0.8, 1.2, c).astype(np.float32)
+        sd[name + ".num_batches_tracked"] = np.array(0, dtype=np.int64)
+
+    def bias(name, c, fan_in):
+        b = 1.0 / np.sqrt(fan_in)
+        sd[name + ".bias"] = rs.uniform(-b, b, c).astype(np.float32)
+
+    def linear(name, co, ci, gain=3.0):
+        # torch's default U(+-1/sqrt(fan_in)) times a gain that spreads the logits over O(1)
+        b = gain / np.sqrt(ci)
+        sd[name + ".weight"] = rs.uniform(-b, b, (co, ci)).astype(np.float32)
+        bias(name, co, ci)
+
+    conv("net._conv_stem", A.STEM_OUT, 3, 3)
+    bn("net._bn0", A.STEM_OUT)
+    for b in A.BLOCKS:
+        p = f"net._blocks.{b.index}"
+        if b.expand != 1:
+            conv(p + "._expand_conv", b.c_exp, b.c_in, 1)
+            bn(p + "._bn0", b.c_exp)
+        conv(p + "._depthwise_conv", b.c_exp, 1, b.kernel)
+        bn(p + "._bn1", b.c_exp)
+        conv(p + "._se_reduce", b.c_se, b.c_exp, 1, gain=1.0)
+        bias(p + "._se_reduce", b.c_se, b.c_exp)
+        conv(p + "._se_expand", b.c_exp, b.c_se, 1, gain=1.0)
+        # a positive SE bias keeps the gate near 0.75 so the signal is not halved 16 times
+        sd[p + "._se_expand.bias"] = (1.0 + rs.randn(b.c_exp) * 0.2).astype(np.float32)
+        # project conv has no activation after it: unit gain; smaller on skip blocks
+        conv(p + "._project_conv", b.c_out, b.c_exp, 1, gain=0.7 if b.skip else 1.0)
+        bn(p + "._bn2", b.c_out)
+    conv("net._conv_head", A.HEAD_OUT, A.BLOCKS[-1].c_out, 1)
+    bn("net._bn1", A.HEAD_OUT)
+    d = A.MLP_DIMS
+    linear("net._fc.1", d[1], d[0])
+    bn("net._fc.2", d[1])
+    linear("net._fc.5", d[2], d[1])
+    bn("net._fc.6", d[2])
+    linear("net._fc.9", d[3], d[2])
+    return sd
+
+
+# --------------------------------------------------------------------------- checkpoint
+def load_checkpoint(path: str) -> Dict[str, np.ndarray]:
+    """Read a reference-format checkpoint (reference deepfake_detection.py:44-51)."""
+    import torch
+
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    state = ckpt["model_state_dict"] if isinstance(ckpt, dict) and "model_state_dict" in ckpt else ckpt
+    return {k: v.detach().cpu().numpy() for k, v in state.items()}
+
+
+def to_torch(sd: Mapping[str, np.ndarray]):
+    import torch
+
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+# --------------------------------------------------------------------------- packing
+def _fold(w: np.ndarray, b, bnp: Mapping[str, np.ndarray], prefix: str, eps: float):
+    """Fold eval-mode BatchNorm `prefix` into (w, b); w's axis 0 is the output channel."""
+    g = bnp[prefix + ".weight"].astype(np.float64)
+    beta = bnp[prefix + ".bias"].astype(np.float64)
+    mu = bnp[prefix + ".running_mean"].astype(np.float64)
+    var = bnp[prefix + ".running_var"].astype(np.float64)
+    a = g / np.sqrt(var + eps)
+    w64 = w.astype(np.float64) * a.reshape((-1,) + (1,) * (w.ndim - 1))
+    b64 = (0.0 if b is None else b.astype(np.float64)) * a + (beta - mu * a)
+    return w64.astype(np.float32), b64.astype(np.float32)
+
+
+def pack_b0_tensors(sd: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Kernel-ready tensors (see csrc/b0_plan.cpp for how each one is consumed)."""
+    sd = {(k if k.startswith("net.") else "net." + k): np.asarray(v) for k, v in sd.items()}
+    t: Dict[str, np.ndarray] = {}
+    eps = A.BN_EPS_BACKBONE
+    w, b = _fold(sd["net._conv_stem.weight"], None, sd, "net._bn0", eps)
+    # stem: [co][ci][ky][kx] -> [ky][kx][ci][co]
+    t["stem.w"] = np.ascontiguousarray(w.transpose(2, 3, 1, 0))
+    t["stem.b"] = b
+    for blk in A.BLOCKS:
+        p = f"net._blocks.{blk.index}"
+        q = f"b{blk.index}"
+        if blk.expand != 1:
+            w, b = _fold(sd[p + "._expand_conv.weight"], None, sd, p + "._bn0", eps)
+            t[q + ".exp.w"] = np.ascontiguousarray(w.reshape(blk.c_exp, blk.c_in))     # [co][ci]
+            t[q + ".exp.b"] = b
+        w, b = _fold(sd[p + "._depthwise_conv.weight"], None, sd, p + "._bn1", eps)
+        # depthwise: [c][1][ky][kx] -> [ky][kx][c]
+        t[q + ".dw.w"] = np.ascontiguousarray(w.reshape(blk.c_exp, blk.kernel, blk.kernel).transpose(1, 2, 0))
+        t[q + ".dw.b"] = b
+        t[q + ".se.w1"] = np.ascontiguousarray(sd[p + "._se_reduce.weight"].reshape(blk.c_se, blk.c_exp).astype(np.float32))
+        t[q + ".se.b1"] = sd[p + "._se_reduce.bias"].astype(np.float32)
+        # second SE matmul stored [c_se][c_exp] so consecutive lanes read consecutive channels
+        t[q + ".se.w2"] = np.ascontiguousarray(sd[p + "._se_expand.weight"].reshape(blk.c_exp, blk.c_se).T.astype(np.float32))
+        t[q + ".se.b2"] = sd[p + "._se_expand.bias"].astype(np.float32)
+        w, b = _fold(sd[p + "._project_conv.weight"], None, sd, p + "._bn2", eps)
+        t[q + ".proj.w"] = np.ascontiguousarray(w.reshape(blk.c_out, blk.c_exp))
+        t[q + ".proj.b"] = b
+    w, b = _fold(sd["net._conv_head.weight"], None, sd, "net._bn1", eps)
+    t["head.w"] = np.ascontiguousarray(w.reshape(A.HEAD_OUT, A.BLOCKS[-1].c_out))
+    t["head.b"] = b
+    w, b = _fold(sd["net._fc.1.weight"], sd["net._fc.1.bias"], sd, "net._fc.2", A.BN_EPS_HEAD)
+    t["fc1.w"], t["fc1.b"] = w, b
+    w, b = _fold(sd["net._fc.5.weight"], sd["net._fc.5.bias"], sd, "net._fc.6", A.BN_EPS_HEAD)
+    t["fc2.w"], t["fc2.b"] = w, b
+    t["fc3.w"] = sd["net._fc.9.weight"].astype(np.float32)
+    t["fc3.b"] = sd["net._fc.9.bias"].astype(np.float32)
+    return t
+
+
+def serialize(tensors: Mapping[str, np.ndarray]) -> bytes:
+    names = list(tensors)
+    entry = struct.Struct(f"<{_NAME_LEN}sI4IQQ")
+    head = 12 + entry.size * len(names)
+    off = (head + 63) // 64 * 64
+    table = []
+    chunks = []
+    for n in names:
+        a = np.ascontiguousarray(tensors[n], dtype=np.float32)
+        if a.ndim > 4 or len(n.encode()) >= _NAME_LEN:
+            raise ValueError(f"tensor {n}: unsupported rank or name length")
+        dims = list(a.shape) + [1] * (4 - a.ndim)
+        table.append(entry.pack(n.encode(), a.ndim, *dims, off, a.nbytes))
+        chunks.append((off, a.tobytes()))
+        off = (off + a.nbytes + 63) // 64 * 64
+    buf = bytearray(off)
+    buf[0:12] = BLOB_MAGIC + struct.pack("<II", BLOB_VERSION, len(names))
+    pos = 12
+    for e in table:
+        buf[pos:pos + entry.size] = e
+        pos += entry.size
+    for o, c in chunks:
+        buf[o:o + len(c)] = c
+    return bytes(buf)
+
+
+def pack_b0(sd: Mapping[str, np.ndarray]) -> bytes:
+    return serialize(pack_b0_tensors(sd))

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` via gpurun)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import rtdfd_amd
+
+    return rtdfd_amd
+
+
+@pytest.fixture(scope="session")
+def seeded_sd(pkg):
+    return pkg.weights.seeded_state_dict(0)
+
+
+@pytest.fixture(scope="session")
+def b0_handle(pkg, seeded_sd):
+    """One classifier handle shared by the GPU tests (fails loudly if the .so or GPU is missing)."""
+    h = pkg._lib.Handle(pkg.weights.pack_b0(seeded_sd), device=0, max_batch=16)
+    yield h
+    h.close()

@@ -1,0 +1,121 @@
+"""GPU parity: HIP classifier (through the C ABI) vs the CPU oracle, stage by stage.
+
+Tolerances: fp32 logits |d| <= 1e-3 (BASELINE.json north_star); intermediate activations
+are O(1) so the same absolute bound is applied to every tap.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import b0_ref
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3
+
+
+def _inputs(n, seed=42):
+    rs = np.random.RandomState(seed)
+    x = rs.randn(n, 3, 224, 224).astype(np.float32)
+    scale = np.linspace(0.3, 2.0, n, dtype=np.float32).reshape(n, 1, 1, 1)
+    shift = np.linspace(-1.0, 1.0, n, dtype=np.float32).reshape(n, 1, 1, 1)
+    return x * scale + shift
+
+
+@pytest.fixture(scope="module")
+def ref(pkg, seeded_sd):
+    x = _inputs(3)
+    taps = {}
+    y = b0_ref.forward(pkg.weights.to_torch(seeded_sd), torch.from_numpy(x), taps)
+    return x, y.numpy(), taps
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().numpy() if t.dim() == 4 else t.numpy()
+
+
+def test_taps_match_oracle(b0_handle, ref):
+    x, _, taps = ref
+    n = x.shape[0]
+    xd = b0_handle.alloc(x.nbytes).upload(x)
+    names = ["stem"]
+    for i in range(16):
+        names += ([f"b{i}.exp"] if i else []) + [f"b{i}.dw", f"b{i}.gate", f"b{i}.out"]
+    names += ["head"]
+    worst = {}
+    for name in names:
+        want = _nhwc(taps[name])
+        if name.endswith(".gate"):
+            want = want.reshape(n, -1)
+        got = b0_handle.tap(xd.ptr, n, name, want.size).reshape(want.shape)
+        err = float(np.abs(got - want).max())
+        worst[name] = err
+        assert err <= LOGIT_TOL, f"{name}: max|d|={err:.3e} (ref absmax {np.abs(want).max():.2f})"
+    xd.free()
+    print("worst tap errors:", sorted(worst.items(), key=lambda kv: -kv[1])[:5])
+
+
+def test_logits_match_oracle(b0_handle, ref):
+    x, want, _ = ref
+    got = b0_handle.classify(x)
+    assert got.shape == (x.shape[0], 1)
+    assert np.abs(got - want).max() <= LOGIT_TOL, (got.ravel(), want.ravel())
+    # the logits must actually differ between inputs, or this test says nothing
+    assert np.ptp(want) > 0.1
+
+
+def test_features_match_oracle(pkg, b0_handle, seeded_sd, ref):
+    x, _, _ = ref
+    want = b0_ref.extract_features(pkg.weights.to_torch(seeded_sd), torch.from_numpy(x)).numpy()
+    got = b0_handle.extract_features(x)
+    assert got.shape == (x.shape[0], 1280)
+    assert np.abs(got - want).max() <= LOGIT_TOL
+
+
+def test_batch_invariance_and_determinism(b0_handle):
+    """Same crop alone, in a ragged batch (M not a multiple of any tile) and twice in a row gives
+    bit-identical logits (reference tests/test_reliability.py:123-132 asserts out1 == out2)."""
+    x = _inputs(11, seed=7)
+    full = b0_handle.classify(x)
+    again = b0_handle.classify(x)
+    assert np.array_equal(full, again)
+    for i in (0, 5, 10):
+        one = b0_handle.classify(x[i:i + 1])
+        assert np.array_equal(one, full[i:i + 1]), (i, one, full[i])
+    part = b0_handle.classify(x[3:10])
+    assert np.array_equal(part, full[3:10])
+
+
+def test_reference_determinism_input(pkg, b0_handle, seeded_sd):
+    """The reference's own determinism input: torch.manual_seed(42); randn(1,3,224,224)."""
+    torch.manual_seed(42)
+    x = torch.randn(1, 3, 224, 224)
+    want = b0_ref.forward(pkg.weights.to_torch(seeded_sd), x).numpy()
+    got = b0_handle.classify(x.numpy())
+    assert abs(float(got[0, 0]) - float(want[0, 0])) <= LOGIT_TOL
+
+
+def test_model_surface(pkg, seeded_sd, ref):
+    """DeepfakeEfficientNet host mirror: shapes/ranges the reference tests pin
+    (tests/test_functional.py:70-110)."""
+    x, want, _ = ref
+    m = pkg.model.DeepfakeEfficientNet(pretrained=False, max_batch=2, state_dict=seeded_sd).eval()
+    fc = m.net._fc
+    assert len(fc) == 10 and fc[1].in_features == 1280 and fc[1].out_features == 512 and fc[9].out_features == 1
+    out = m(torch.from_numpy(x))
+    assert tuple(out.shape) == (3, 1)
+    assert np.abs(out.numpy() - want).max() <= LOGIT_TOL
+    probs = torch.sigmoid(out)
+    assert probs.min() >= 0.0 and probs.max() <= 1.0
+    logits, proj = m.forward_with_projection(x)
+    assert proj is None and logits.shape == (3, 1)
+    assert m.extract_features(x[:1]).shape == (1, 1280)
+
+
+def test_errors_are_loud(pkg, b0_handle):
+    with pytest.raises(pkg._lib.DfdError):
+        b0_handle.classify(np.zeros((17, 3, 224, 224), np.float32))   # capacity 16
+    with pytest.raises(ValueError):
+        b0_handle.classify(np.zeros((1, 3, 32, 32), np.float32))
+    with pytest.raises(pkg._lib.DfdError):
+        pkg._lib.Handle(b"not a blob", device=0, max_batch=1)
