@@ -38,7 +38,13 @@ def cpu_baseline(sd_np, sample_crops=32, chunk=16):
     import rtdfd_amd
     from oracle import b0_ref
 
-    cores = os.cpu_count() or 1
+    # the cores this process may actually use (the GPU box gives a 1-GPU job a 16-core share;
+    # os.cpu_count() there reports the whole host and oversubscribes torch's pool 16x)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("DFD_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
     sd = rtdfd_amd.weights.to_torch(sd_np)
     torch.manual_seed(1)

@@ -311,8 +311,7 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X,
         v4f acc[RP];
 #pragma unroll
         for (int p = 0; p < RP; ++p) acc[p] = bv;
-#pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
+        auto tap_row = [&](int ky) {
             const v4f* row = &tile[((oy * S + ky) * IW + ox0 * S) * CG + cg];
             v4f in[NIN];
 #pragma unroll
@@ -323,6 +322,14 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X,
 #pragma unroll
                 for (int p = 0; p < RP; ++p) acc[p] += in[p * S + kx] * w;
             }
+        };
+        if constexpr (K == 5) {
+            // rolled: one kernel row (5 weight vectors) live at a time instead of all 25
+#pragma unroll 1
+            for (int ky = 0; ky < K; ++ky) tap_row(ky);
+        } else {
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) tap_row(ky);
         }
         const int gy = ty0 + oy;
 #pragma unroll
@@ -402,42 +409,70 @@ int depthwise_tiles(int H, int C, int k, int stride) {
 }
 
 // ---------------------------------------------------------------------- squeeze-excite
-// One block per image.  mean[c] = sum over tiles of P / (H*W); z = swish(W1 mean + b1);
-// gate = sigmoid(W2 z + b2)   (efficientnet_pytorch MBConvBlock SE branch).
-__global__ __launch_bounds__(256) void se_kernel(const float* __restrict__ P, int tiles, float inv_hw,
-                                                 const float* __restrict__ w1,
-                                                 const float* __restrict__ b1,
-                                                 const float* __restrict__ w2t,
-                                                 const float* __restrict__ b2,
-                                                 float* __restrict__ gate, int C, int c_se) {
-    __shared__ float mean[1152];
-    __shared__ float z[64];
+// One 1024-thread block per image.  mean[c] = sum over tiles of P / (H*W); z = swish(W1 mean
+// + b1); gate = sigmoid(W2 z + b2)  (efficientnet_pytorch MBConvBlock SE branch).  The work is
+// tiny (<= 2*1152*48 MACs) and purely latency-bound, so every loop has a compile-time trip
+// count (C <= 18*64, c_se <= 16*3) and its loads are issued back to back.
+constexpr int SE_MAXC = 1152, SE_MAXSE = 48;
+__global__ __launch_bounds__(1024) void se_kernel(const float* __restrict__ P, int tiles, float inv_hw,
+                                                  const float* __restrict__ w1,
+                                                  const float* __restrict__ b1,
+                                                  const float* __restrict__ w2t,
+                                                  const float* __restrict__ b2,
+                                                  float* __restrict__ gate, int C, int c_se) {
+    __shared__ float mean[SE_MAXC];
+    __shared__ float z[SE_MAXSE];
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* p = P + (size_t)n * tiles * C;
-    for (int c = tid; c < C; c += 256) {
-        float s = 0.f;
-        for (int t = 0; t < tiles; ++t) s += p[(size_t)t * C + c];
-        mean[c] = s * inv_hw;
+    for (int c = tid; c < C; c += 1024) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int t = 0;
+        for (; t + 3 < tiles; t += 4) {
+            s0 += p[(size_t)t * C + c];
+            s1 += p[(size_t)(t + 1) * C + c];
+            s2 += p[(size_t)(t + 2) * C + c];
+            s3 += p[(size_t)(t + 3) * C + c];
+        }
+        for (; t < tiles; ++t) s0 += p[(size_t)t * C + c];
+        mean[c] = ((s0 + s1) + (s2 + s3)) * inv_hw;
     }
     __syncthreads();
-    for (int o = wave; o < c_se; o += 4) {
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s += mean[c] * w1[(size_t)o * C + c];
+    {   // FC1: wave w owns outputs w, w+16, w+32
+        float s[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) z[o] = swish1(s + b1[o]);
+        for (int i = 0; i < SE_MAXC / 64; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) {
+                const float mv = mean[c];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int o = wave + 16 * k;
+                    if (o < c_se) s[k] += mv * w1[(size_t)o * C + c];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v = s[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            const int o = wave + 16 * k;
+            if (lane == 0 && o < c_se) z[o] = swish1(v + b1[o]);
+        }
     }
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += 1024) {
         float s = b2[c];
-        for (int o = 0; o < c_se; ++o) s += z[o] * w2t[(size_t)o * C + c];
+#pragma unroll
+        for (int o = 0; o < SE_MAXSE; ++o)
+            if (o < c_se) s += z[o] * w2t[(size_t)o * C + c];
         gate[(size_t)n * C + c] = 1.0f / (1.0f + __expf(-s));
     }
 }
 
 void launch_se(const float* P, int tiles, float inv_hw, const float* w1, const float* b1,
                const float* w2t, const float* b2, float* gate, int n, int C, int c_se, hipStream_t s) {
-    hipLaunchKernelGGL(se_kernel, dim3(n), dim3(256), 0, s, P, tiles, inv_hw, w1, b1, w2t, b2, gate, C, c_se);
+    hipLaunchKernelGGL(se_kernel, dim3(n), dim3(1024), 0, s, P, tiles, inv_hw, w1, b1, w2t, b2, gate, C, c_se);
 }
 
 // ------------------------------------------------------------------- global average pool
