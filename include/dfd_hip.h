@@ -91,6 +91,32 @@ int dfd_b0_profile_begin(dfd_handle* h);
 int dfd_b0_profile_end(dfd_handle* h, float* ms_sum, const char** names, int max_layers,
                        int* count, int* steps);
 
+/* ---- per-face pre-processing ----------------------------------------------------------
+ * All take an 8-bit BGR image in host memory (rows `stride` bytes apart) as cv2 hands it to
+ * the reference.  Boxes are (x, y, w, h) int32 quadruples inside the frame. */
+
+/* cv2.resize(frame, (dw, dh), interpolation=INTER_LINEAR) for 8-bit BGR: reference
+ * frame_analysis.py:71,112 (256x256) and face_detection.py:77 (300x300).  out: dh*dw*3. */
+int dfd_resize_bgr(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
+                   int dh, int dw, uint8_t* out);
+
+/* DeepfakeDetector.preprocess_face_quality, reference deepfake_detection.py:357-370:
+ * BGR->Lab, CLAHE(clipLimit 2.0, 8x8 tiles) on L, Lab->BGR.  out: height*width*3, packed. */
+int dfd_preprocess_face_quality(dfd_handle* h, const uint8_t* bgr, int height, int width,
+                                int stride, uint8_t* out);
+
+/* crop (reference backend_server.py:160-161 / deepfake_detection.py:612) -> optional CLAHE ->
+ * BGR->RGB, bilinear 224x224 (align_corners=False), /255, ImageNet normalise (reference
+ * deepfake_detection.py:376,382-389; the MTCNN re-crop at :377 is bypassed).
+ * nchw_out: (n,3,224,224) float32. */
+int dfd_preprocess_crops(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
+                         const int32_t* xywh, int n, int apply_clahe, float* nchw_out);
+
+/* The same followed by the classifier: one logit per box (analyze_face without the
+ * calibration/heuristic scalars, reference deepfake_detection.py:517-538). */
+int dfd_classify_crops(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
+                       const int32_t* xywh, int n, int apply_clahe, float* logits_out);
+
 #ifdef __cplusplus
 }
 #endif

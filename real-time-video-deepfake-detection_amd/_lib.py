@@ -45,6 +45,12 @@ SIGNATURES = {
     "dfd_extract_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dfd_b0_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_size_t,
                               C.POINTER(C.c_size_t)]),
+    "dfd_resize_bgr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dfd_preprocess_face_quality": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dfd_preprocess_crops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_void_p]),
+    "dfd_classify_crops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_void_p]),
     "dfd_b0_profile_begin": (C.c_int, [C.c_void_p]),
     "dfd_b0_profile_end": (C.c_int, [C.c_void_p, c_float_p, C.POINTER(C.c_char_p), C.c_int,
                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -191,3 +197,46 @@ class Handle:
         cnt, steps = C.c_int(), C.c_int()
         self._check(self._lib.dfd_b0_profile_end(self._p, ms, names, max_layers, C.byref(cnt), C.byref(steps)))
         return steps.value, [(names[i].decode(), float(ms[i])) for i in range(cnt.value)]
+
+    # -- 8-bit image path
+    @staticmethod
+    def _as_bgr(frame) -> np.ndarray:
+        a = np.asarray(frame)
+        if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError(f"expected (H,W,3) uint8 BGR image, got {a.dtype} {a.shape}")
+        if not a.flags["C_CONTIGUOUS"]:
+            a = np.ascontiguousarray(a)
+        return a
+
+    @staticmethod
+    def _as_boxes(boxes) -> np.ndarray:
+        b = np.ascontiguousarray(np.asarray(boxes, dtype=np.int32).reshape(-1, 4))
+        if b.shape[0] == 0:
+            raise ValueError("no boxes")
+        return b
+
+    def resize_bgr(self, frame, dw: int, dh: int) -> np.ndarray:
+        a = self._as_bgr(frame)
+        out = np.empty((dh, dw, 3), np.uint8)
+        self._check(self._lib.dfd_resize_bgr(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0], dh, dw, _ptr(out)))
+        return out
+
+    def preprocess_face_quality(self, face) -> np.ndarray:
+        a = self._as_bgr(face)
+        out = np.empty_like(a)
+        self._check(self._lib.dfd_preprocess_face_quality(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0], _ptr(out)))
+        return out
+
+    def preprocess_crops(self, frame, boxes, apply_clahe: bool = True) -> np.ndarray:
+        a, b = self._as_bgr(frame), self._as_boxes(boxes)
+        out = np.empty((b.shape[0], 3, 224, 224), np.float32)
+        self._check(self._lib.dfd_preprocess_crops(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0], _ptr(b),
+                                                   b.shape[0], int(apply_clahe), _ptr(out)))
+        return out
+
+    def classify_crops(self, frame, boxes, apply_clahe: bool = True) -> np.ndarray:
+        a, b = self._as_bgr(frame), self._as_boxes(boxes)
+        out = np.empty((b.shape[0], 1), np.float32)
+        self._check(self._lib.dfd_classify_crops(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0], _ptr(b),
+                                                 b.shape[0], int(apply_clahe), _ptr(out)))
+        return out

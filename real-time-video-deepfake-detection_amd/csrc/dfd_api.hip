@@ -47,6 +47,7 @@ int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, in
         off += (t.count * 4 + 255) / 256 * 256;
     }
     if ((rc = b0_build_plan(h))) return rc;
+    if ((rc = color_tables_init(h))) return rc;
 
     const B0Plan& P = h->b0;
     const size_t nb = (size_t)max_batch;
@@ -69,7 +70,8 @@ void destroy_impl(dfd_handle* h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    for (void* p : h->owned) hipFree(p);
+    for (void* p : h->owned)
+        if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);

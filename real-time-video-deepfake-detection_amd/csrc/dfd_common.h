@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/dfd_hip.h"
+#include "imgproc_kernels.h"
 
 namespace dfd {
 
@@ -41,6 +42,12 @@ struct B0Plan {
     size_t io_floats = 0, exp_floats = 0, dw_floats = 0, pool_floats = 0, gate_floats = 0;
 };
 
+// a device buffer that only ever grows (re-allocated outside of steady state)
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
 struct B0Tap {
     const char* name = nullptr;   // stage to copy out, or null
     float* out = nullptr;
@@ -67,6 +74,10 @@ struct dfd_handle {
     float *in_nchw = nullptr, *io0 = nullptr, *io1 = nullptr, *expbuf = nullptr, *dwbuf = nullptr;
     float *pool = nullptr, *gate = nullptr, *headbuf = nullptr, *feat = nullptr, *fc1 = nullptr,
           *fc2 = nullptr, *logits = nullptr;
+    // image pre-processing: colour LUTs + lazily grown scratch (frame upload, Lab/BGR crops)
+    dfd::ColorTables color{};
+    bool has_color = false;
+    dfd::DevBuf frame_buf, lab_buf, crop_buf, lut_buf, desc_buf, u8_out;
     dfd::B0Prof prof;                    // layer events between profile_begin/end
     int prof_steps = 0;
     std::string err;
@@ -85,6 +96,11 @@ int fail(dfd_handle* h, int code, const char* fmt, ...);
             return dfd::fail((h), DFD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
                              __FILE__, __LINE__);                                               \
     } while (0)
+
+// grows `b` to at least `bytes` (frees and re-allocates; contents are not preserved)
+int ensure(dfd_handle* h, DevBuf* b, size_t bytes);
+// builds h->color from the "lut.*" tensors of the blob (imgproc_api.hip)
+int color_tables_init(dfd_handle* h);
 
 // b0_plan.cpp
 int b0_build_plan(dfd_handle* h);

@@ -1,0 +1,189 @@
+// C ABI entry points of the per-face pre-processing path (include/dfd_hip.h).
+#include "b0_kernels.h"
+#include "dfd_common.h"
+
+using namespace dfd;
+
+namespace dfd {
+
+int ensure(dfd_handle* h, DevBuf* b, size_t bytes) {
+    if (bytes <= b->cap) return DFD_OK;
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (b->p) {
+        DFD_HIP_TRY(h, hipFree(b->p));
+        for (auto& o : h->owned)
+            if (o == b->p) o = nullptr;
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    const size_t want = (bytes + (1 << 20) - 1) & ~((size_t)(1 << 20) - 1);
+    DFD_HIP_TRY(h, hipMalloc(&b->p, want));
+    h->owned.push_back(b->p);
+    b->cap = want;
+    return DFD_OK;
+}
+
+// "lut.*" tensors hold integers as exactly-representable float32; convert to int32 tables.
+int color_tables_init(dfd_handle* h) {
+    struct Want { const char* name; size_t count; const int** slot; };
+    ColorTables& T = h->color;
+    const Want wants[] = {{"lut.gamma", 256, &T.gamma},       {"lut.cbrt", 3072, &T.cbrt},
+                          {"lut.L_fy", 256, &T.L_fy},         {"lut.L_y", 256, &T.L_y},
+                          {"lut.a_div", 256, &T.a_div},       {"lut.b_div", 256, &T.b_div},
+                          {"lut.ab_xz", 36864, &T.ab_xz},     {"lut.inv_gamma", 16385, &T.inv_gamma},
+                          {"lut.hsv_sdiv", 256, &T.hsv_sdiv}, {"lut.hsv_hdiv", 256, &T.hsv_hdiv}};
+    if (h->tensors.find("lut.gamma") == h->tensors.end()) return DFD_OK;   // blob without tables
+    std::vector<float> tmp;
+    for (const Want& w : wants) {
+        auto it = h->tensors.find(w.name);
+        if (it == h->tensors.end() || it->second.count != w.count)
+            return fail(h, DFD_ERR_BLOB, "weights blob: table '%s' missing or wrong size", w.name);
+        tmp.resize(w.count);
+        DFD_HIP_TRY(h, hipMemcpy(tmp.data(), it->second.dev, w.count * 4, hipMemcpyDeviceToHost));
+        std::vector<int> iv(w.count);
+        for (size_t i = 0; i < w.count; ++i) iv[i] = (int)tmp[i];
+        void* d = nullptr;
+        DFD_HIP_TRY(h, hipMalloc(&d, w.count * 4));
+        h->owned.push_back(d);
+        DFD_HIP_TRY(h, hipMemcpy(d, iv.data(), w.count * 4, hipMemcpyHostToDevice));
+        *w.slot = static_cast<const int*>(d);
+    }
+    for (const char* name : {"lut.fwd_coef", "lut.inv_coef"}) {
+        auto it = h->tensors.find(name);
+        if (it == h->tensors.end() || it->second.count != 9)
+            return fail(h, DFD_ERR_BLOB, "weights blob: table '%s' missing or wrong size", name);
+        float c[9];
+        DFD_HIP_TRY(h, hipMemcpy(c, it->second.dev, 36, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 9; ++i) {
+            if (name[4] == 'f') T.fwd[i] = (int)c[i];
+            else T.inv[i] = (long long)c[i];
+        }
+    }
+    h->has_color = true;
+    return DFD_OK;
+}
+
+}  // namespace dfd
+
+namespace {
+
+int upload_frame(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride) {
+    if (!bgr || hh <= 0 || ww <= 0 || stride < ww * 3) return fail(h, DFD_ERR_ARG, "frame: bad pointer or geometry");
+    int rc = ensure(h, &h->frame_buf, (size_t)hh * stride);
+    if (rc) return rc;
+    DFD_HIP_TRY(h, hipMemcpyAsync(h->frame_buf.p, bgr, (size_t)hh * stride, hipMemcpyHostToDevice, h->stream));
+    return DFD_OK;
+}
+
+// validates the boxes, lays the packed crops out in the scratch buffers, uploads descriptors
+int stage_crops(dfd_handle* h, int hh, int ww, const int32_t* xywh, int n, size_t* total, int* max_pixels) {
+    if (!xywh || n <= 0) return fail(h, DFD_ERR_ARG, "crops: null boxes or n <= 0");
+    if (n > h->max_batch) return fail(h, DFD_ERR_CAPACITY, "crops: %d boxes exceed handle capacity %d", n, h->max_batch);
+    std::vector<CropDesc> d(n);
+    size_t off = 0;
+    int mp = 0;
+    for (int i = 0; i < n; ++i) {
+        const int x = xywh[4 * i], y = xywh[4 * i + 1], w = xywh[4 * i + 2], hgt = xywh[4 * i + 3];
+        if (w <= 0 || hgt <= 0 || x < 0 || y < 0 || x + w > ww || y + hgt > hh)
+            return fail(h, DFD_ERR_ARG, "crops: box %d (%d,%d,%d,%d) outside the %dx%d frame", i, x, y, w, hgt, ww, hh);
+        d[i] = CropDesc{x, y, w, hgt, off};
+        off += ((size_t)w * hgt * 3 + 255) & ~(size_t)255;
+        if (w * hgt > mp) mp = w * hgt;
+    }
+    int rc;
+    if ((rc = ensure(h, &h->desc_buf, n * sizeof(CropDesc)))) return rc;
+    DFD_HIP_TRY(h, hipMemcpyAsync(h->desc_buf.p, d.data(), n * sizeof(CropDesc), hipMemcpyHostToDevice, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));   // `d` is a stack temporary
+    *total = off;
+    *max_pixels = mp;
+    return DFD_OK;
+}
+
+// frame already on the device -> normalised NCHW crops in h->in_nchw
+int preprocess_on_device(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride,
+                         const int32_t* xywh, int n, int apply_clahe) {
+    size_t total = 0;
+    int mp = 0, rc;
+    if ((rc = stage_crops(h, hh, ww, xywh, n, &total, &mp))) return rc;
+    const CropDesc* dd = static_cast<const CropDesc*>(h->desc_buf.p);
+    if (apply_clahe) {
+        if (!h->has_color) return fail(h, DFD_ERR_STATE, "CLAHE needs the colour tables (blob packed without luts)");
+        if ((rc = ensure(h, &h->lab_buf, total))) return rc;
+        if ((rc = ensure(h, &h->crop_buf, total))) return rc;
+        if ((rc = ensure(h, &h->lut_buf, (size_t)n * 64 * 256))) return rc;
+        launch_clahe(frame_dev, stride, dd, n, (uint8_t*)h->lab_buf.p, (uint8_t*)h->lut_buf.p,
+                     (uint8_t*)h->crop_buf.p, h->color, mp, h->stream);
+    }
+    launch_crop_norm(frame_dev, stride, (const uint8_t*)h->crop_buf.p, dd, n, h->in_nchw, apply_clahe != 0, h->stream);
+    DFD_HIP_TRY(h, hipGetLastError());
+    return DFD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dfd_resize_bgr(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride, int dh, int dw, uint8_t* out) {
+    if (!h) return DFD_ERR_ARG;
+    if (!out || dh <= 0 || dw <= 0) return fail(h, DFD_ERR_ARG, "resize: bad output");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    int rc = upload_frame(h, bgr, hh, ww, stride);
+    if (rc) return rc;
+    if ((rc = ensure(h, &h->u8_out, (size_t)dh * dw * 3))) return rc;
+    launch_resize_bgr((const uint8_t*)h->frame_buf.p, 1, hh, ww, stride, 0, (uint8_t*)h->u8_out.p, dh, dw, h->stream);
+    DFD_HIP_TRY(h, hipMemcpyAsync(out, h->u8_out.p, (size_t)dh * dw * 3, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DFD_OK;
+}
+
+int dfd_preprocess_face_quality(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride, uint8_t* out) {
+    if (!h) return DFD_ERR_ARG;
+    if (!out) return fail(h, DFD_ERR_ARG, "preprocess_face_quality: null output");
+    if (!h->has_color) return fail(h, DFD_ERR_STATE, "CLAHE needs the colour tables (blob packed without luts)");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    int rc = upload_frame(h, bgr, hh, ww, stride);
+    if (rc) return rc;
+    const int32_t box[4] = {0, 0, ww, hh};
+    size_t total = 0;
+    int mp = 0;
+    const int saved = h->max_batch;
+    if ((rc = stage_crops(h, hh, ww, box, 1, &total, &mp))) return rc;
+    (void)saved;
+    if ((rc = ensure(h, &h->lab_buf, total))) return rc;
+    if ((rc = ensure(h, &h->crop_buf, total))) return rc;
+    if ((rc = ensure(h, &h->lut_buf, 64 * 256))) return rc;
+    launch_clahe((const uint8_t*)h->frame_buf.p, stride, (const CropDesc*)h->desc_buf.p, 1, (uint8_t*)h->lab_buf.p,
+                 (uint8_t*)h->lut_buf.p, (uint8_t*)h->crop_buf.p, h->color, mp, h->stream);
+    DFD_HIP_TRY(h, hipMemcpyAsync(out, h->crop_buf.p, (size_t)hh * ww * 3, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DFD_OK;
+}
+
+int dfd_preprocess_crops(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride, const int32_t* xywh,
+                         int n, int apply_clahe, float* nchw_out) {
+    if (!h) return DFD_ERR_ARG;
+    if (!nchw_out) return fail(h, DFD_ERR_ARG, "preprocess_crops: null output");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    int rc = upload_frame(h, bgr, hh, ww, stride);
+    if (rc) return rc;
+    if ((rc = preprocess_on_device(h, (const uint8_t*)h->frame_buf.p, hh, ww, stride, xywh, n, apply_clahe))) return rc;
+    DFD_HIP_TRY(h, hipMemcpyAsync(nchw_out, h->in_nchw, (size_t)n * 3 * 224 * 224 * 4, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DFD_OK;
+}
+
+int dfd_classify_crops(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride, const int32_t* xywh, int n,
+                       int apply_clahe, float* logits_out) {
+    if (!h) return DFD_ERR_ARG;
+    if (!logits_out) return fail(h, DFD_ERR_ARG, "classify_crops: null output");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    int rc = upload_frame(h, bgr, hh, ww, stride);
+    if (rc) return rc;
+    if ((rc = preprocess_on_device(h, (const uint8_t*)h->frame_buf.p, hh, ww, stride, xywh, n, apply_clahe))) return rc;
+    if ((rc = b0_forward(h, h->in_nchw, n, h->logits, nullptr, nullptr))) return rc;
+    DFD_HIP_TRY(h, hipMemcpyAsync(logits_out, h->logits, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DFD_OK;
+}
+
+}  // extern "C"

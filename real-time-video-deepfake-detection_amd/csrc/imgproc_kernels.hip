@@ -1,0 +1,257 @@
+// 8-bit image kernels of the per-face pre-processing path (gfx950).  HBM-bound byte work:
+// no MFMA, coalesced u8 rows, LDS only for the per-tile CLAHE histogram.
+//
+//   resize_linear_u8    cv2.resize(INTER_LINEAR) fixed-point bilinear    frame_analysis.py:71, face_detection.py:77
+//   clahe_hist_kernel   BGR->Lab + per-tile histogram/clip/LUT            deepfake_detection.py:363-366
+//   clahe_apply_kernel  4-LUT bilinear blend + Lab->BGR                   deepfake_detection.py:366-368
+//   crop_norm_kernel    bilinear 224x224 + /255 + ImageNet normalise      deepfake_detection.py:382-389
+//
+// Compiled with -ffp-contract=off: the float expressions below are written in the exact
+// operation order of the algorithms they restate and must not be fused.
+#include "imgproc_kernels.h"
+
+namespace dfd {
+
+__device__ __forceinline__ int descale(long long x, int n) { return (int)((x + (1ll << (n - 1))) >> n); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+// ------------------------------------------------------------------------------ resize
+struct Tap { int i0, i1, a0, a1; };
+
+// x direction: coefficient forced to 0 at the borders; y direction: indices clipped (OpenCV)
+__device__ __forceinline__ Tap linear_tap(int d, int src_n, int dst_n, bool is_x) {
+    const double scale = (double)src_n / (double)dst_n;
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    Tap t;
+    if (is_x) {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= src_n - 1) { f = 0.f; s = src_n - 1; }
+        t.i0 = s;
+        t.i1 = s + 1 < src_n ? s + 1 : src_n - 1;
+    } else {
+        t.i0 = clampi(s, 0, src_n - 1);
+        t.i1 = clampi(s + 1, 0, src_n - 1);
+    }
+    t.a0 = clampi((int)rintf((1.f - f) * 2048.f), -32768, 32767);
+    t.a1 = clampi((int)rintf(f * 2048.f), -32768, 32767);
+    return t;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __restrict__ src, int sh,
+                                                               int sw, size_t sstride, size_t simg,
+                                                               uint8_t* __restrict__ dst, int dh, int dw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= dh * dw) return;
+    const int dy = idx / dw, dx = idx % dw;
+    const uint8_t* s = src + (size_t)blockIdx.y * simg;
+    uint8_t* d = dst + ((size_t)blockIdx.y * dh * dw + idx) * C;
+    if (sh == dh && sw == dw) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) d[c] = s[(size_t)dy * sstride + dx * C + c];
+        return;
+    }
+    const Tap tx = linear_tap(dx, sw, dw, true), ty = linear_tap(dy, sh, dh, false);
+    const uint8_t* r0 = s + (size_t)ty.i0 * sstride;
+    const uint8_t* r1 = s + (size_t)ty.i1 * sstride;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int h0 = r0[tx.i0 * C + c] * tx.a0 + r0[tx.i1 * C + c] * tx.a1;
+        const int h1 = r1[tx.i0 * C + c] * tx.a0 + r1[tx.i1 * C + c] * tx.a1;
+        const int v = (((ty.a0 * (h0 >> 4)) >> 16) + ((ty.a1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        d[c] = (uint8_t)clampi(v, 0, 255);
+    }
+}
+
+void launch_resize_bgr(const uint8_t* src, int n, int sh, int sw, size_t sstride, size_t simg,
+                       uint8_t* dst, int dh, int dw, hipStream_t s) {
+    hipLaunchKernelGGL(resize_linear_u8_kernel<3>, dim3((dh * dw + 255) / 256, n), dim3(256), 0, s, src, sh,
+                       sw, sstride, simg, dst, dh, dw);
+}
+
+// ------------------------------------------------------------------------------ Lab
+__device__ __forceinline__ void bgr2lab(const ColorTables& T, int b, int g, int r, int& L, int& A, int& B) {
+    const long long R_ = T.gamma[r], G_ = T.gamma[g], B_ = T.gamma[b];
+    const int fX = T.cbrt[descale(R_ * T.fwd[0] + G_ * T.fwd[1] + B_ * T.fwd[2], 12)];
+    const int fY = T.cbrt[descale(R_ * T.fwd[3] + G_ * T.fwd[4] + B_ * T.fwd[5], 12)];
+    const int fZ = T.cbrt[descale(R_ * T.fwd[6] + G_ * T.fwd[7] + B_ * T.fwd[8], 12)];
+    const int Lscale = (116 * 255 + 50) / 100;
+    const int Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
+    L = clampi(descale((long long)Lscale * fY + Lshift, 15), 0, 255);
+    A = clampi(descale(500ll * (fX - fY) + 128ll * (1 << 15), 15), 0, 255);
+    B = clampi(descale(200ll * (fY - fZ) + 128ll * (1 << 15), 15), 0, 255);
+}
+
+__device__ __forceinline__ void lab2bgr(const ColorTables& T, int L, int A, int B, int& b, int& g, int& r) {
+    const int AB_MIN = -8145, AB_TAB = 36864, ONE = 1 << 14;
+    const long long fy = T.L_fy[L], y = T.L_y[L];
+    const long long x = T.ab_xz[clampi((int)(fy + T.a_div[A]) - AB_MIN, 0, AB_TAB - 1)];
+    const long long z = T.ab_xz[clampi((int)(fy - T.b_div[B]) - AB_MIN, 0, AB_TAB - 1)];
+    r = T.inv_gamma[clampi(descale(T.inv[0] * x + T.inv[1] * y + T.inv[2] * z, 12), 0, ONE)];
+    g = T.inv_gamma[clampi(descale(T.inv[3] * x + T.inv[4] * y + T.inv[5] * z, 12), 0, ONE)];
+    b = T.inv_gamma[clampi(descale(T.inv[6] * x + T.inv[7] * y + T.inv[8] * z, 12), 0, ONE)];
+}
+
+// ------------------------------------------------------------------------------ CLAHE
+// One block per (tile, crop).  The tile grid is 8x8 over the crop extended by reflect-101 to
+// a multiple of 8 (OpenCV pads BOTH dimensions by a full 8-rem when either is ragged).
+__device__ __forceinline__ void clahe_geometry(const CropDesc& cd, int& ew, int& eh) {
+    if (cd.w % 8 == 0 && cd.h % 8 == 0) { ew = cd.w; eh = cd.h; }
+    else { ew = cd.w + (8 - cd.w % 8); eh = cd.h + (8 - cd.h % 8); }
+}
+
+__global__ __launch_bounds__(256) void clahe_hist_kernel(const uint8_t* __restrict__ frame, size_t fstride,
+                                                         const CropDesc* __restrict__ crops,
+                                                         uint8_t* __restrict__ lab_out,
+                                                         uint8_t* __restrict__ luts, ColorTables T,
+                                                         float clip_limit) {
+    __shared__ int hist[256];
+    __shared__ int scan[256];
+    __shared__ int clipped_total;
+    const int tid = threadIdx.x;
+    const CropDesc cd = crops[blockIdx.y];
+    int ew, eh;
+    clahe_geometry(cd, ew, eh);
+    const int tw = ew / 8, th = eh / 8;
+    const int tx = blockIdx.x % 8, ty = blockIdx.x / 8;
+    hist[tid] = 0;
+    if (tid == 0) clipped_total = 0;
+    __syncthreads();
+    uint8_t* lab = lab_out + cd.offset;
+    for (int i = tid; i < tw * th; i += 256) {
+        const int ex = tx * tw + i % tw, ey = ty * th + i / tw;
+        const int sx = reflect101(ex, cd.w), sy = reflect101(ey, cd.h);
+        const uint8_t* p = frame + (size_t)(cd.y + sy) * fstride + (size_t)(cd.x + sx) * 3;
+        int L, A, B;
+        bgr2lab(T, p[0], p[1], p[2], L, A, B);
+        atomicAdd(&hist[L], 1);
+        if (ex < cd.w && ey < cd.h) {
+            uint8_t* o = lab + ((size_t)ey * cd.w + ex) * 3;
+            o[0] = (uint8_t)L; o[1] = (uint8_t)A; o[2] = (uint8_t)B;
+        }
+    }
+    __syncthreads();
+    const int area = tw * th;
+    int clip = (int)((double)clip_limit * area / 256);
+    if (clip < 1) clip = 1;
+    int hv = hist[tid];
+    if (hv > clip) { atomicAdd(&clipped_total, hv - clip); hv = clip; }
+    __syncthreads();
+    const int clipped = clipped_total;
+    const int batch = clipped / 256;
+    int residual = clipped - batch * 256;
+    hv += batch;
+    if (residual != 0) {
+        int step = 256 / residual;
+        if (step < 1) step = 1;
+        if (tid % step == 0 && tid / step < residual) hv += 1;
+    }
+    // inclusive scan of the 256 bins
+    scan[tid] = hv;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    const float lut_scale = 255.0f / (float)area;
+    const float v = rintf((float)scan[tid] * lut_scale);
+    luts[((size_t)blockIdx.y * 64 + blockIdx.x) * 256 + tid] = (uint8_t)clampi((int)v, 0, 255);
+}
+
+__global__ __launch_bounds__(256) void clahe_apply_kernel(const CropDesc* __restrict__ crops,
+                                                          const uint8_t* __restrict__ lab_in,
+                                                          const uint8_t* __restrict__ luts,
+                                                          uint8_t* __restrict__ bgr_out, ColorTables T) {
+    const CropDesc cd = crops[blockIdx.y];
+    int ew, eh;
+    clahe_geometry(cd, ew, eh);
+    const float inv_tw = 1.0f / (float)(ew / 8), inv_th = 1.0f / (float)(eh / 8);
+    const uint8_t* lut = luts + (size_t)blockIdx.y * 64 * 256;
+    const uint8_t* lab = lab_in + cd.offset;
+    uint8_t* out = bgr_out + cd.offset;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cd.w * cd.h; i += gridDim.x * 256) {
+        const int x = i % cd.w, y = i / cd.w;
+        const float txf = (float)x * inv_tw - 0.5f, tyf = (float)y * inv_th - 0.5f;
+        int tx1 = (int)floorf(txf), ty1 = (int)floorf(tyf);
+        const float xa = txf - (float)tx1, ya = tyf - (float)ty1;
+        const float xa1 = 1.0f - xa, ya1 = 1.0f - ya;
+        int tx2 = tx1 + 1 < 7 ? tx1 + 1 : 7, ty2 = ty1 + 1 < 7 ? ty1 + 1 : 7;
+        tx1 = tx1 > 0 ? tx1 : 0;
+        ty1 = ty1 > 0 ? ty1 : 0;
+        const uint8_t* p = lab + (size_t)i * 3;
+        const int L = p[0];
+        const float l11 = lut[(ty1 * 8 + tx1) * 256 + L], l12 = lut[(ty1 * 8 + tx2) * 256 + L];
+        const float l21 = lut[(ty2 * 8 + tx1) * 256 + L], l22 = lut[(ty2 * 8 + tx2) * 256 + L];
+        const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+        const int Ln = clampi((int)rintf(res), 0, 255);
+        int b, g, r;
+        lab2bgr(T, Ln, p[1], p[2], b, g, r);
+        uint8_t* o = out + (size_t)i * 3;
+        o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r;
+    }
+}
+
+// ------------------------------------------------------------------ crop -> network input
+// torch F.interpolate(bilinear, align_corners=False) on the RGB float crop, /255, normalise.
+// from_scratch: read the CLAHE'd packed crop; else read the box straight from the frame.
+__global__ __launch_bounds__(256) void crop_norm_kernel(const uint8_t* __restrict__ frame, size_t fstride,
+                                                        const uint8_t* __restrict__ scratch,
+                                                        const CropDesc* __restrict__ crops,
+                                                        float* __restrict__ out_nchw, int from_scratch) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 224 * 224) return;
+    const CropDesc cd = crops[blockIdx.y];
+    const int oy = idx / 224, ox = idx % 224;
+    const float sy = (float)cd.h / 224.0f, sx = (float)cd.w / 224.0f;
+    float fy = sy * ((float)oy + 0.5f) - 0.5f, fx = sx * ((float)ox + 0.5f) - 0.5f;
+    if (fy < 0.f) fy = 0.f;
+    if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < cd.h - 1 ? 1 : 0), x1 = x0 + (x0 < cd.w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const uint8_t *p00, *p01, *p10, *p11;
+    if (from_scratch) {
+        const uint8_t* b = scratch + cd.offset;
+        p00 = b + ((size_t)y0 * cd.w + x0) * 3; p01 = b + ((size_t)y0 * cd.w + x1) * 3;
+        p10 = b + ((size_t)y1 * cd.w + x0) * 3; p11 = b + ((size_t)y1 * cd.w + x1) * 3;
+    } else {
+        const uint8_t* b = frame + (size_t)cd.y * fstride + (size_t)cd.x * 3;
+        p00 = b + (size_t)y0 * fstride + x0 * 3; p01 = b + (size_t)y0 * fstride + x1 * 3;
+        p10 = b + (size_t)y1 * fstride + x0 * 3; p11 = b + (size_t)y1 * fstride + x1 * 3;
+    }
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    float* o = out_nchw + (size_t)blockIdx.y * 3 * 224 * 224 + idx;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                 // output channel c = R,G,B = source byte 2-c
+        const int sc = 2 - c;
+        const float v = hy * (hx * (float)p00[sc] + lx * (float)p01[sc]) + ly * (hx * (float)p10[sc] + lx * (float)p11[sc]);
+        o[(size_t)c * 224 * 224] = (v / 255.0f - mean[c]) / stdv[c];
+    }
+}
+
+void launch_clahe(const uint8_t* frame, size_t fstride, const CropDesc* crops_dev, int n, uint8_t* lab,
+                  uint8_t* luts, uint8_t* bgr_out, const ColorTables& T, int max_pixels, hipStream_t s) {
+    hipLaunchKernelGGL(clahe_hist_kernel, dim3(64, n), dim3(256), 0, s, frame, fstride, crops_dev, lab, luts, T, 2.0f);
+    int gx = (max_pixels + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(clahe_apply_kernel, dim3(gx, n), dim3(256), 0, s, crops_dev, lab, luts, bgr_out, T);
+}
+
+void launch_crop_norm(const uint8_t* frame, size_t fstride, const uint8_t* scratch, const CropDesc* crops_dev,
+                      int n, float* out_nchw, bool from_scratch, hipStream_t s) {
+    hipLaunchKernelGGL(crop_norm_kernel, dim3((224 * 224 + 255) / 256, n), dim3(256), 0, s, frame, fstride,
+                       scratch, crops_dev, out_nchw, from_scratch ? 1 : 0);
+}
+
+}  // namespace dfd

@@ -182,5 +182,11 @@ def serialize(tensors: Mapping[str, np.ndarray]) -> bytes:
     return bytes(buf)
 
 
-def pack_b0(sd: Mapping[str, np.ndarray]) -> bytes:
-    return serialize(pack_b0_tensors(sd))
+def pack_b0(sd: Mapping[str, np.ndarray], with_tables: bool = True) -> bytes:
+    """Classifier blob; by default also carries the colour LUTs the pre-processing kernels use."""
+    t = pack_b0_tensors(sd)
+    if with_tables:
+        from . import luts
+
+        t.update(luts.as_float_tensors())
+    return serialize(t)
