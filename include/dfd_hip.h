@@ -117,6 +117,27 @@ int dfd_preprocess_crops(dfd_handle* h, const uint8_t* bgr, int height, int widt
 int dfd_classify_crops(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
                        const int32_t* xywh, int n, int apply_clahe, float* logits_out);
 
+/* ---- frame forensics ------------------------------------------------------------------
+ * FrameForensicAnalyzer.analyze (full != 0) / analyze_fast (full == 0), reference
+ * frame_analysis.py:58-126: cv2.resize to 256x256, then the six signals (:128-389), weighted
+ * sum (:49-56,88 / :118-119), clip to [0,1].  Temporal state (previous gray frame, last 30
+ * mean differences, frame counter; :35-37) is kept per `stream_id` inside the handle.
+ *   scores_out[6] = frequency, noise, ela, edge, color, temporal   (NaN where the fast variant
+ *                   does not compute a signal)
+ *   prob_out      = fake_probability
+ *   stats_out     = NULL or DFD_FORENSIC_NSTATS doubles: the quantities the thresholds act on
+ *                   (low/mid/high band means, high ratio, mid ratio, mid cv, noise mean, noise cv,
+ *                    ela mean, ela cv, edge density, laplacian variance, S std, V std, unique hues,
+ *                    mean abs frame difference (-1 on a stream's first frame), temporal cv,
+ *                    frame counter) */
+#define DFD_FORENSIC_NSTATS 18
+int dfd_forensics(dfd_handle* h, int stream_id, const uint8_t* bgr, int height, int width, int stride,
+                  int full, double* scores_out, double* prob_out, double* stats_out);
+/* FrameForensicAnalyzer.reset, reference frame_analysis.py:391-395. */
+int dfd_forensics_reset(dfd_handle* h, int stream_id);
+/* Mirrors the analyzer's attributes frame_count, len(temporal_diffs), prev_frame_gray is not None. */
+int dfd_forensics_state(dfd_handle* h, int stream_id, int* frame_count, int* n_diffs, int* has_prev);
+
 #ifdef __cplusplus
 }
 #endif

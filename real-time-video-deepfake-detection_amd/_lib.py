@@ -51,6 +51,11 @@ SIGNATURES = {
                                        C.c_int, C.c_void_p]),
     "dfd_classify_crops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                      C.c_int, C.c_void_p]),
+    "dfd_forensics": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dfd_forensics_reset": (C.c_int, [C.c_void_p, C.c_int]),
+    "dfd_forensics_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]),
     "dfd_b0_profile_begin": (C.c_int, [C.c_void_p]),
     "dfd_b0_profile_end": (C.c_int, [C.c_void_p, c_float_p, C.POINTER(C.c_char_p), C.c_int,
                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -240,3 +245,28 @@ class Handle:
         self._check(self._lib.dfd_classify_crops(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0], _ptr(b),
                                                  b.shape[0], int(apply_clahe), _ptr(out)))
         return out
+
+    # -- frame forensics
+    FORENSIC_KEYS = ("frequency", "noise", "ela", "edge", "color", "temporal")
+    FORENSIC_STAT_KEYS = ("freq_low", "freq_mid", "freq_high", "freq_high_ratio", "freq_mid_ratio", "freq_mid_cv",
+                          "noise_mean", "noise_cv", "ela_mean", "ela_cv", "edge_density", "lap_var", "sat_std",
+                          "val_std", "unique_hues", "mean_diff", "temporal_cv", "frame_count")
+
+    def forensics(self, frame, full: bool = True, stream_id: int = 0):
+        """-> (scores dict, fake_probability, stats dict)"""
+        a = self._as_bgr(frame)
+        sc = np.empty(6, np.float64)
+        st = np.empty(len(self.FORENSIC_STAT_KEYS), np.float64)
+        prob = C.c_double()
+        self._check(self._lib.dfd_forensics(self._p, int(stream_id), _ptr(a), a.shape[0], a.shape[1], a.strides[0],
+                                            int(bool(full)), _ptr(sc), C.byref(prob), _ptr(st)))
+        scores = {k: float(v) for k, v in zip(self.FORENSIC_KEYS, sc) if not np.isnan(v)}
+        return scores, float(prob.value), dict(zip(self.FORENSIC_STAT_KEYS, (float(v) for v in st)))
+
+    def forensics_reset(self, stream_id: int = 0):
+        self._check(self._lib.dfd_forensics_reset(self._p, int(stream_id)))
+
+    def forensics_state(self, stream_id: int = 0):
+        fc, nd, hp = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.dfd_forensics_state(self._p, int(stream_id), C.byref(fc), C.byref(nd), C.byref(hp)))
+        return fc.value, nd.value, bool(hp.value)

@@ -16,6 +16,9 @@
 
 namespace dfd {
 
+struct ForensicState;   // forensic_api.hip
+void forensic_destroy(dfd_handle* h);
+
 struct Tensor {
     const float* host = nullptr;   // into the caller's blob (valid during dfd_create only)
     float* dev = nullptr;          // device copy owned by the handle
@@ -78,6 +81,7 @@ struct dfd_handle {
     dfd::ColorTables color{};
     bool has_color = false;
     dfd::DevBuf frame_buf, lab_buf, crop_buf, lut_buf, desc_buf, u8_out;
+    dfd::ForensicState* forensic = nullptr;   // per-stream temporal state + work buffers
     dfd::B0Prof prof;                    // layer events between profile_begin/end
     int prof_steps = 0;
     std::string err;

@@ -1,0 +1,223 @@
+// C ABI of the forensic analyzer: device statistics -> the reference's threshold scoring
+// (reference frame_analysis.py:58-389), with the per-stream temporal state kept here.
+#include <cmath>
+#include <deque>
+
+#include "dfd_common.h"
+#include "forensic_kernels.h"
+
+using namespace dfd;
+
+namespace dfd {
+
+struct ForensicStream {
+    void* prev_gray = nullptr;     // 65536 bytes on the device
+    bool has_prev = false;
+    std::deque<double> diffs;      // last 30 mean absolute differences
+    int frame_count = 0;
+};
+
+struct ForensicState {
+    std::map<int, ForensicStream> streams;
+    DevBuf work;                   // carved by forensic_carve for `cap` frames
+    int cap = 0;
+    ForensicBuffers buf{};
+    float2* twiddle = nullptr;
+    double* diff_part = nullptr;   // 256 partial sums
+};
+
+void forensic_destroy(dfd_handle* h) {
+    delete h->forensic;
+    h->forensic = nullptr;
+}
+
+}  // namespace dfd
+
+namespace {
+
+int state_init(dfd_handle* h, int frames) {
+    if (!h->forensic) {
+        h->forensic = new ForensicState();
+        float2 tw[128];
+        for (int k = 0; k < 128; ++k) {
+            const double a = -2.0 * M_PI * k / 256.0;
+            tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        void* d = nullptr;
+        DFD_HIP_TRY(h, hipMalloc(&d, sizeof tw));
+        h->owned.push_back(d);
+        DFD_HIP_TRY(h, hipMemcpy(d, tw, sizeof tw, hipMemcpyHostToDevice));
+        h->forensic->twiddle = static_cast<float2*>(d);
+        DFD_HIP_TRY(h, hipMalloc(&d, 256 * 8));
+        h->owned.push_back(d);
+        h->forensic->diff_part = static_cast<double*>(d);
+    }
+    ForensicState& F = *h->forensic;
+    if (frames > F.cap) {
+        const int rc = ensure(h, &F.work, forensic_bytes_per_frame() * frames + 65536);
+        if (rc) return rc;
+        forensic_carve(F.work.p, frames, &F.buf);
+        F.cap = frames;
+    }
+    return DFD_OK;
+}
+
+double pop_std(const double* v, int n, double* mean_out) {
+    double m = 0;
+    for (int i = 0; i < n; ++i) m += v[i];
+    m /= n;
+    double q = 0;
+    for (int i = 0; i < n; ++i) q += (v[i] - m) * (v[i] - m);
+    *mean_out = m;
+    return std::sqrt(q / n);
+}
+
+double clip01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
+
+}  // namespace
+
+extern "C" {
+
+int dfd_forensics(dfd_handle* h, int stream_id, const uint8_t* bgr, int hh, int ww, int stride, int full,
+                  double* scores_out, double* prob_out, double* stats_out) {
+    if (!h) return DFD_ERR_ARG;
+    if (!bgr || !scores_out || !prob_out || hh <= 0 || ww <= 0 || stride < ww * 3)
+        return fail(h, DFD_ERR_ARG, "forensics: bad pointer or geometry");
+    if (!h->has_color) return fail(h, DFD_ERR_STATE, "forensics needs the colour tables (blob packed without luts)");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    int rc = state_init(h, 1);
+    if (rc) return rc;
+    ForensicState& F = *h->forensic;
+    ForensicStream& S = F.streams[stream_id];
+    if (!S.prev_gray) {
+        DFD_HIP_TRY(h, hipMalloc(&S.prev_gray, 65536));
+        h->owned.push_back(S.prev_gray);
+    }
+    S.frame_count += 1;                                              // frame_analysis.py:68,110
+
+    if ((rc = ensure(h, &h->frame_buf, (size_t)hh * stride))) return rc;
+    DFD_HIP_TRY(h, hipMemcpyAsync(h->frame_buf.p, bgr, (size_t)hh * stride, hipMemcpyHostToDevice, h->stream));
+    launch_resize_bgr((const uint8_t*)h->frame_buf.p, 1, hh, ww, stride, 0, F.buf.rs, 256, 256, h->stream);
+    launch_forensics(F.buf, 1, full != 0, h->color, F.twiddle, h->stream);
+    double mean_diff = -1.0;
+    if (S.has_prev) launch_absdiff(F.buf.gray, (const uint8_t*)S.prev_gray, F.diff_part, h->stream);
+    double st[FORENSIC_STATS], noise[64], ela[64], dpart[256];
+    DFD_HIP_TRY(h, hipMemcpyAsync(st, F.buf.stats, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    if (full) {
+        DFD_HIP_TRY(h, hipMemcpyAsync(noise, F.buf.stats_noise, sizeof noise, hipMemcpyDeviceToHost, h->stream));
+        DFD_HIP_TRY(h, hipMemcpyAsync(ela, F.buf.stats_ela, sizeof ela, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (S.has_prev) DFD_HIP_TRY(h, hipMemcpyAsync(dpart, F.diff_part, sizeof dpart, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipMemcpyAsync(S.prev_gray, F.buf.gray, 65536, hipMemcpyDeviceToDevice, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, hipGetLastError());
+
+    const double nan = std::nan("");
+    double sc[6] = {0, nan, nan, 0, nan, 0};      // frequency, noise, ela, edge, color, temporal
+    // ---- frequency (frame_analysis.py:150-180)
+    const double lo = st[ST_FREQ_LOW], mi = st[ST_FREQ_MID], hi = st[ST_FREQ_HIGH];
+    const double total = lo + mi + hi + 1e-10, hr = hi / total, mr = mi / total;
+    const double mid_cv = st[ST_FREQ_MID_STD] / (mi + 1e-10);
+    double s = 0.0;
+    if (hr < 0.18) s += 0.4; else if (hr < 0.22) s += 0.2;
+    if (mid_cv > 0.6) s += 0.25; else if (mid_cv > 0.45) s += 0.1;
+    if (mr > 0.45 && hr < 0.2) s += 0.15;
+    sc[0] = clip01(s);
+    // ---- edges (:296-309)
+    const double density = st[ST_EDGE_COUNT] / 65536.0, lap_var = st[ST_LAP_VAR];
+    s = 0.0;
+    if (density < 0.02) s += 0.35; else if (density < 0.04) s += 0.15;
+    if (lap_var < 50) s += 0.3; else if (lap_var < 100) s += 0.1;
+    sc[3] = clip01(s);
+    double noise_mean = nan, noise_cv = nan, ela_mean = nan, ela_cv = nan;
+    if (full) {
+        // ---- noise (:207-225)
+        noise_cv = pop_std(noise, 64, &noise_mean) / (noise_mean + 1e-10);
+        s = 0.0;
+        if (noise_cv > 0.7) s += 0.5; else if (noise_cv > 0.5) s += 0.25;
+        if (noise_mean < 1.0) s += 0.3; else if (noise_mean < 2.0) s += 0.1;
+        sc[1] = clip01(s);
+        // ---- ELA (:258-276)
+        ela_cv = pop_std(ela, 64, &ela_mean) / (ela_mean + 1e-10);
+        s = 0.0;
+        if (ela_cv > 0.9) s += 0.5; else if (ela_cv > 0.6) s += 0.2;
+        if (ela_mean > 15) s += 0.2; else if (ela_mean > 10) s += 0.1;
+        sc[2] = clip01(s);
+        // ---- colour (:326-347)
+        s = 0.0;
+        if (st[ST_SAT_STD] < 15) s += 0.3; else if (st[ST_SAT_STD] < 25) s += 0.1;
+        if (st[ST_VAL_STD] < 15) s += 0.25; else if (st[ST_VAL_STD] < 25) s += 0.1;
+        if (st[ST_HUES] < 30) s += 0.25; else if (st[ST_HUES] < 50) s += 0.1;
+        sc[4] = clip01(s);
+    }
+    // ---- temporal (:358-389)
+    double temporal_cv = nan;
+    if (!S.has_prev) {
+        S.has_prev = true;
+    } else {
+        double sum = 0;
+        for (int i = 0; i < 256; ++i) sum += dpart[i];
+        mean_diff = sum / 65536.0;
+        S.diffs.push_back(mean_diff);
+        if (S.diffs.size() > 30) S.diffs.pop_front();
+        if (S.diffs.size() >= 5) {
+            std::vector<double> d(S.diffs.begin(), S.diffs.end());
+            double dm;
+            temporal_cv = pop_std(d.data(), (int)d.size(), &dm) / (dm + 1e-10);
+            s = 0.0;
+            if (temporal_cv > 1.5) s += 0.4; else if (temporal_cv > 1.0) s += 0.2;
+            if (mean_diff < 0.3 && S.frame_count > 10) s += 0.3;
+            else if (mean_diff < 0.8 && S.frame_count > 10) s += 0.1;
+            sc[5] = clip01(s);
+        }
+    }
+    // ---- weighted sum in the reference's dict order (:49-56,88 / :118-119)
+    double comb = 0.0;
+    if (full) {
+        const double w[6] = {0.25, 0.20, 0.20, 0.15, 0.10, 0.10};
+        for (int i = 0; i < 6; ++i) comb += sc[i] * w[i];
+    } else {
+        comb += sc[0] * 0.45;
+        comb += sc[5] * 0.25;
+        comb += sc[3] * 0.30;
+    }
+    for (int i = 0; i < 6; ++i) scores_out[i] = sc[i];
+    *prob_out = clip01(comb);
+    if (stats_out) {
+        const double out[DFD_FORENSIC_NSTATS] = {lo, mi, hi, hr, mr, mid_cv, noise_mean, noise_cv, ela_mean, ela_cv,
+                                                 density, lap_var, full ? st[ST_SAT_STD] : nan, full ? st[ST_VAL_STD] : nan,
+                                                 full ? st[ST_HUES] : nan, mean_diff, temporal_cv, (double)S.frame_count};
+        for (int i = 0; i < DFD_FORENSIC_NSTATS; ++i) stats_out[i] = out[i];
+    }
+    return DFD_OK;
+}
+
+int dfd_forensics_reset(dfd_handle* h, int stream_id) {
+    if (!h) return DFD_ERR_ARG;
+    if (!h->forensic) return DFD_OK;
+    auto it = h->forensic->streams.find(stream_id);
+    if (it == h->forensic->streams.end()) return DFD_OK;
+    it->second.has_prev = false;                 // frame_analysis.py:391-395
+    it->second.diffs.clear();
+    it->second.frame_count = 0;
+    return DFD_OK;
+}
+
+int dfd_forensics_state(dfd_handle* h, int stream_id, int* frame_count, int* n_diffs, int* has_prev) {
+    if (!h) return DFD_ERR_ARG;
+    int fc = 0, nd = 0, hp = 0;
+    if (h->forensic) {
+        auto it = h->forensic->streams.find(stream_id);
+        if (it != h->forensic->streams.end()) {
+            fc = it->second.frame_count;
+            nd = (int)it->second.diffs.size();
+            hp = it->second.has_prev ? 1 : 0;
+        }
+    }
+    if (frame_count) *frame_count = fc;
+    if (n_diffs) *n_diffs = nd;
+    if (has_prev) *has_prev = hp;
+    return DFD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+"""Process-wide default library handle (the counterpart of the reference's import-time
+``model = DeepfakeEfficientNet(...); model.to(DEVICE).eval()`` singleton,
+reference deepfake_detection.py:30-90), created lazily on first use.
+
+Weights: ``$DFD_WEIGHTS`` or ``weights/best_model.pth`` next to the package if present
+(reference checkpoint layout), else the seeded random-init state dict - the reference tree ships
+no weights.  Device: ``$DFD_DEVICE`` or ``$LOCAL_RANK`` or 0.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import threading
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import weights as W
+from ._lib import Handle
+
+log = logging.getLogger(__name__)
+_lock = threading.Lock()
+_default: Optional[Handle] = None
+_state: Optional[Dict[str, np.ndarray]] = None
+model_loaded = False          # True when a trained checkpoint was found
+
+
+def device_index() -> int:
+    return int(os.environ.get("DFD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def default_state_dict() -> Dict[str, np.ndarray]:
+    global _state, model_loaded
+    if _state is None:
+        here = os.path.dirname(os.path.abspath(__file__))
+        path = os.environ.get("DFD_WEIGHTS", os.path.join(here, "weights", "best_model.pth"))
+        if os.path.exists(path):
+            _state = W.load_checkpoint(path)
+            model_loaded = True
+            log.info("loaded checkpoint %s", path)
+        else:
+            _state = W.seeded_state_dict(int(os.environ.get("DFD_SEED", "0")))
+            log.warning("no trained checkpoint (%s); using seeded random-init weights", path)
+    return _state
+
+
+def default_handle() -> Handle:
+    global _default
+    with _lock:
+        if _default is None:
+            _default = Handle(W.pack_b0(default_state_dict()), device=device_index(),
+                              max_batch=int(os.environ.get("DFD_MAX_BATCH", "16")))
+        return _default
+
+
+def set_default_handle(h: Optional[Handle]) -> None:
+    global _default
+    with _lock:
+        _default = h
