@@ -117,6 +117,22 @@ int dfd_preprocess_crops(dfd_handle* h, const uint8_t* bgr, int height, int widt
 int dfd_classify_crops(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
                        const int32_t* xywh, int n, int apply_clahe, float* logits_out);
 
+/* ---- face detector ----------------------------------------------------------------------
+ * _detect_dnn, reference face_detection.py:71-105, for a blob packed with detector weights
+ * (weights.pack_all): cv2.resize to 300x300, mean (104,177,123) subtraction, SSD forward,
+ * DetectionOutput (NMS 0.45, top_k 400, keep_top_k 200), then the reference's integer
+ * post-processing: conf > conf_thr (strict), scale by [w,h,w,h], truncate, clamp, keep
+ * w > 20 and h > 20.  Writes up to max_out (x, y, w, h) quadruples in network (descending
+ * confidence) order; frames smaller than 30 pixels in either direction give n_out = 0
+ * (reference :55-56).  conf_out may be NULL. */
+int dfd_detect_faces(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
+                     float conf_thr, int32_t* xywh_out, float* conf_out, int max_out, int* n_out);
+int dfd_has_detector(const dfd_handle* h);
+/* One named detector intermediate for parity tests: a layer name of ssd_arch.LAYERS,
+ * "<source>.head", "prob", "boxes" (per prior) or "rows" (DetectionOutput: score,x1,y1,x2,y2). */
+int dfd_ssd_tap(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
+                const char* name, float* out, size_t capacity, size_t* count);
+
 /* ---- frame forensics ------------------------------------------------------------------
  * FrameForensicAnalyzer.analyze (full != 0) / analyze_fast (full == 0), reference
  * frame_analysis.py:58-126: cv2.resize to 256x256, then the six signals (:128-389), weighted

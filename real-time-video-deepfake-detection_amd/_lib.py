@@ -51,6 +51,11 @@ SIGNATURES = {
                                        C.c_int, C.c_void_p]),
     "dfd_classify_crops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                      C.c_int, C.c_void_p]),
+    "dfd_detect_faces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                   C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "dfd_has_detector": (C.c_int, [C.c_void_p]),
+    "dfd_ssd_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p,
+                              C.c_size_t, C.POINTER(C.c_size_t)]),
     "dfd_forensics": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "dfd_forensics_reset": (C.c_int, [C.c_void_p, C.c_int]),
@@ -270,3 +275,27 @@ class Handle:
         fc, nd, hp = C.c_int(), C.c_int(), C.c_int()
         self._check(self._lib.dfd_forensics_state(self._p, int(stream_id), C.byref(fc), C.byref(nd), C.byref(hp)))
         return fc.value, nd.value, bool(hp.value)
+
+    # -- face detector
+    @property
+    def has_detector(self) -> bool:
+        return bool(self._lib.dfd_has_detector(self._p))
+
+    def detect_faces(self, frame, confidence_threshold: float = 0.5, max_out: int = 200, with_conf: bool = False):
+        """-> [(x, y, w, h), ...] in descending-confidence order (reference face_detection.py:71-105)."""
+        a = self._as_bgr(frame)
+        boxes = np.zeros((max_out, 4), np.int32)
+        conf = np.zeros(max_out, np.float32)
+        n = C.c_int()
+        self._check(self._lib.dfd_detect_faces(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0],
+                                               float(confidence_threshold), _ptr(boxes), _ptr(conf), max_out, C.byref(n)))
+        out = [tuple(int(v) for v in boxes[i]) for i in range(n.value)]
+        return (out, conf[: n.value].copy()) if with_conf else out
+
+    def ssd_tap(self, frame, name: str, capacity: int) -> np.ndarray:
+        a = self._as_bgr(frame)
+        out = np.empty(int(capacity), np.float32)
+        cnt = C.c_size_t()
+        self._check(self._lib.dfd_ssd_tap(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0], name.encode(),
+                                          _ptr(out), out.size, C.byref(cnt)))
+        return out[: cnt.value]

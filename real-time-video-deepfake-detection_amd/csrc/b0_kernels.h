@@ -16,6 +16,17 @@ void launch_pointwise(const float* X, const float* W, const float* bias, const f
                       const float* R, float* Y, int M, int K, int N, int HW, int act,
                       hipStream_t s);
 
+// geometry of an implicit-GEMM convolution on NHWC fp32 (square kernel, same stride/pad/dilation
+// in both directions)
+struct ConvGeom {
+    int H = 0, W = 0, Ho = 0, Wo = 0, Cin = 0, ksize = 1, stride = 1, pad = 0, dil = 1;
+};
+
+// k x k convolution as implicit GEMM on the same MFMA kernel (C_in % 32 == 0; returns false
+// otherwise): Y[n][oy][ox][o] = act( conv(X, W[o][ky][kx][ci]) + b[o] (+ R before act if res_first) )
+bool launch_conv_gemm(const float* X, const float* W, const float* bias, const float* R, float* Y,
+                      int n_img, const ConvGeom& g, int Cout, int act, bool res_first, hipStream_t s);
+
 // depthwise kxk conv (k in {3,5}, stride in {1,2}, TF-SAME pad) + folded BN + swish, and
 // per-tile channel sums for the squeeze-excite pool: P[n][tile][c].  Returns the tile count
 // through *tiles.  Only the 16 shape classes of EfficientNet-B0 at 224x224 are instantiated.

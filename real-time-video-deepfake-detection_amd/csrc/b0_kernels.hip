@@ -85,14 +85,20 @@ constexpr int PW_MT = 2;           // 16-pixel tiles per wave
 constexpr int PW_BK = 32;          // K per LDS stage
 constexpr int PW_BKP = PW_BK + 8;  // +8 floats: conflict-free ds_read_b128 of 16 rows x 4 k-quads
 
-template <int NT>
+// CONV = true turns the same kernel into an implicit-GEMM k x k convolution (SSD detector):
+// row m is output pixel (n, oy, ox), K = taps * C_in with the taps outermost, so a 32-wide K
+// stage (C_in % 32 == 0) lies inside one tap and the X fragment is still one 16-byte load per
+// lane from the NHWC input, zero outside the image.  res_first: add R before the activation
+// (ResNet basic block) instead of after it (MBConv skip).
+template <int NT, bool CONV>
 __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ X,
                                                  const float* __restrict__ W,
                                                  const float* __restrict__ bias,
                                                  const float* __restrict__ gate,
                                                  const float* __restrict__ R,
                                                  float* __restrict__ Y, int M, int K, int N,
-                                                 int HW, int act, int mblocks, int nblocks) {
+                                                 int HW, int act, int mblocks, int nblocks,
+                                                 ConvGeom cg, int res_first) {
     constexpr int MT = PW_MT, BK = PW_BK, BKP = PW_BKP;
     constexpr int BN = NT * 16, BM = 4 * MT * 16;
     constexpr int WLOADS = (BN * (BK / 4) + 255) / 256;
@@ -110,10 +116,21 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ X,
 
     int m[MT];
     size_t gbase[MT];
+    int iy0[MT], ix0[MT];       // CONV: top-left input coordinate of the pixel's receptive field
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         m[mt] = mblk * BM + wave * (MT * 16) + mt * 16 + j;
-        gbase[mt] = gate ? (size_t)(m[mt] < M ? m[mt] / HW : 0) * K : 0;
+        if constexpr (CONV) {
+            const int mm = m[mt] < M ? m[mt] : 0;
+            const int img = mm / (cg.Ho * cg.Wo), r = mm - img * (cg.Ho * cg.Wo);
+            const int oy = r / cg.Wo, ox = r - oy * cg.Wo;
+            gbase[mt] = (size_t)img * cg.H * cg.W * cg.Cin;
+            iy0[mt] = oy * cg.stride - cg.pad;
+            ix0[mt] = ox * cg.stride - cg.pad;
+        } else {
+            gbase[mt] = gate ? (size_t)(m[mt] < M ? m[mt] / HW : 0) * K : 0;
+            iy0[mt] = ix0[mt] = 0;
+        }
     }
 
     v4f acc[MT][NT];
@@ -145,18 +162,32 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ X,
         }
     };
     auto load_x = [&](int kc, v4f (&xf)[MT][2]) {
+        if constexpr (CONV) {
+            const int tap = kc / cg.Cin, ci0 = kc - tap * cg.Cin;      // wave-uniform
+            const int ky = tap / cg.ksize, kx = tap - ky * cg.ksize;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
+                const int iy = iy0[mt] + ky * cg.dil, ix = ix0[mt] + kx * cg.dil;
+                const bool ok = m[mt] < M && (unsigned)iy < (unsigned)cg.H && (unsigned)ix < (unsigned)cg.W;
+                const float* p = X + gbase[mt] + ((size_t)iy * cg.W + ix) * cg.Cin + ci0 + 4 * q;
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                const int k = kc + cc * 16 + 4 * q;
-                v4f v = (v4f){0.f, 0.f, 0.f, 0.f};
-                if (m[mt] < M && k < K) {
-                    v = ldg4(X + (size_t)m[mt] * K + k);
-                    if (gate) v *= ldg4(gate + gbase[mt] + k);
-                }
-                xf[mt][cc] = v;
+                for (int cc = 0; cc < 2; ++cc)
+                    xf[mt][cc] = ok ? ldg4(p + cc * 16) : (v4f){0.f, 0.f, 0.f, 0.f};
             }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const int k = kc + cc * 16 + 4 * q;
+                    v4f v = (v4f){0.f, 0.f, 0.f, 0.f};
+                    if (m[mt] < M && k < K) {
+                        v = ldg4(X + (size_t)m[mt] * K + k);
+                        if (gate) v *= ldg4(gate + gbase[mt] + k);
+                    }
+                    xf[mt][cc] = v;
+                }
+        }
     };
 
     const int nk = (K + BK - 1) / BK;
@@ -211,18 +242,24 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ X,
         for (int mt = 0; mt < MT; ++mt) {
             if (m[mt] >= M) continue;
             v4f v = acc[mt][nt] + bv;
+            v4f rv = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (R) {
+                if (vec) rv = ldg4(R + (size_t)m[mt] * N + n);
+                else
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < N) rv[r] = R[(size_t)m[mt] * N + n + r];
+            }
+            if (res_first) v += rv;
             if (act == ACT_SWISH) v = swish4(v);
             else if (act == ACT_RELU) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
+            if (!res_first) v += rv;
             float* yp = Y + (size_t)m[mt] * N + n;
-            if (vec) {
-                if (R) v += ldg4(R + (size_t)m[mt] * N + n);
-                stg4(yp, v);
-            } else {
+            if (vec) stg4(yp, v);
+            else
                 for (int r = 0; r < 4; ++r)
-                    if (n + r < N) yp[r] = v[r] + (R ? R[(size_t)m[mt] * N + n + r] : 0.f);
-            }
+                    if (n + r < N) yp[r] = v[r];
         }
     }
 }
@@ -247,16 +284,38 @@ void launch_pointwise(const float* X, const float* W, const float* bias, const f
     const int BM = 4 * PW_MT * 16, BN = nt * 16;
     const int mblocks = (M + BM - 1) / BM, nblocks = (N + BN - 1) / BN;
     const int grid = ((mblocks + 7) / 8) * 8 * nblocks;
-#define DFD_PW_CASE(NTV)                                                                        \
-    case NTV:                                                                                   \
-        hipLaunchKernelGGL(pw_kernel<NTV>, dim3(grid), dim3(256), 0, s, X, W, bias, gate, R, Y, \
-                           M, K, N, HW, act, mblocks, nblocks);                                 \
+    const ConvGeom none{};
+#define DFD_PW_CASE(NTV)                                                                               \
+    case NTV:                                                                                          \
+        hipLaunchKernelGGL((pw_kernel<NTV, false>), dim3(grid), dim3(256), 0, s, X, W, bias, gate, R, Y, \
+                           M, K, N, HW, act, mblocks, nblocks, none, 0);                               \
         break;
     switch (nt) {
         DFD_PW_CASE(1) DFD_PW_CASE(2) DFD_PW_CASE(3) DFD_PW_CASE(4) DFD_PW_CASE(5)
         DFD_PW_CASE(6) DFD_PW_CASE(7) DFD_PW_CASE(8) DFD_PW_CASE(9) DFD_PW_CASE(10)
     }
 #undef DFD_PW_CASE
+}
+
+bool launch_conv_gemm(const float* X, const float* W, const float* bias, const float* R, float* Y, int n_img,
+                      const ConvGeom& g, int Cout, int act, bool res_first, hipStream_t s) {
+    if (g.Cin % PW_BK != 0) return false;                  // a K stage must not straddle two taps
+    const int M = n_img * g.Ho * g.Wo, K = g.ksize * g.ksize * g.Cin, N = Cout;
+    const int nt = pick_nt(N);
+    const int BM = 4 * PW_MT * 16, BN = nt * 16;
+    const int mblocks = (M + BM - 1) / BM, nblocks = (N + BN - 1) / BN;
+    const int grid = ((mblocks + 7) / 8) * 8 * nblocks;
+#define DFD_CV_CASE(NTV)                                                                                  \
+    case NTV:                                                                                             \
+        hipLaunchKernelGGL((pw_kernel<NTV, true>), dim3(grid), dim3(256), 0, s, X, W, bias, nullptr, R, Y, \
+                           M, K, N, 1, act, mblocks, nblocks, g, res_first ? 1 : 0);                      \
+        break;
+    switch (nt) {
+        DFD_CV_CASE(1) DFD_CV_CASE(2) DFD_CV_CASE(3) DFD_CV_CASE(4) DFD_CV_CASE(5)
+        DFD_CV_CASE(6) DFD_CV_CASE(7) DFD_CV_CASE(8) DFD_CV_CASE(9) DFD_CV_CASE(10)
+    }
+#undef DFD_CV_CASE
+    return true;
 }
 
 // --------------------------------------------------------------------------- depthwise

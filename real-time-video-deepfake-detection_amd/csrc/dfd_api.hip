@@ -48,6 +48,7 @@ int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, in
     }
     if ((rc = b0_build_plan(h))) return rc;
     if ((rc = color_tables_init(h))) return rc;
+    if ((rc = ssd_init(h))) return rc;
 
     const B0Plan& P = h->b0;
     const size_t nb = (size_t)max_batch;
@@ -71,6 +72,7 @@ void destroy_impl(dfd_handle* h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     forensic_destroy(h);
+    ssd_destroy(h);
     for (void* p : h->owned)
         if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);

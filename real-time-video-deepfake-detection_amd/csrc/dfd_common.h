@@ -18,6 +18,9 @@ namespace dfd {
 
 struct ForensicState;   // forensic_api.hip
 void forensic_destroy(dfd_handle* h);
+struct SsdState;        // ssd_api.hip
+int ssd_init(dfd_handle* h);
+void ssd_destroy(dfd_handle* h);
 
 struct Tensor {
     const float* host = nullptr;   // into the caller's blob (valid during dfd_create only)
@@ -82,6 +85,7 @@ struct dfd_handle {
     bool has_color = false;
     dfd::DevBuf frame_buf, lab_buf, crop_buf, lut_buf, desc_buf, u8_out;
     dfd::ForensicState* forensic = nullptr;   // per-stream temporal state + work buffers
+    dfd::SsdState* ssd = nullptr;             // detector plan + workspace (null: blob has no detector)
     dfd::B0Prof prof;                    // layer events between profile_begin/end
     int prof_steps = 0;
     std::string err;

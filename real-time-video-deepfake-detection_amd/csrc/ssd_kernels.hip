@@ -1,0 +1,226 @@
+// SSD-style face detector: the kernels that are not plain convolutions (gfx950).
+//
+//   ssd_conv1_kernel   7x7 s2 conv straight from the resized u8 BGR image with the
+//                      blobFromImage mean subtracted on the fly            face_detection.py:76-79
+//   maxpool3s2_kernel  Caffe max pooling 3x3 s2, ceil mode
+//   l2norm_kernel      SSD Normalize across channels (wave reduction)
+//   ssd_decode_kernel  analytic PriorBox + CENTER_SIZE decode + 2-way softmax
+//   ssd_nms_kernel     DetectionOutput: per-image bitonic sort in LDS (score desc, index asc =
+//                      stable), top_k, greedy NMS, keep_top_k
+// The 3x3 / 1x1 trunk and head convolutions run on pw_kernel<NT, true> (b0_kernels.hip).
+#include "ssd_kernels.h"
+
+namespace dfd {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------- conv1
+// thread = (output pixel, 4 of the 32 output channels); weights [7][7][3][32] staged in LDS
+__global__ __launch_bounds__(256) void ssd_conv1_kernel(const uint8_t* __restrict__ img, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y, int n_img,
+                                                        float mb, float mg, float mr) {
+    __shared__ float ws[147 * 32];
+    for (int i = threadIdx.x; i < 147 * 32; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(gid & 7);
+    const long long pix = gid >> 3;
+    if (pix >= (long long)n_img * 150 * 150) return;
+    const int ox = (int)(pix % 150), oy = (int)((pix / 150) % 150), n = (int)(pix / 22500);
+    const uint8_t* src = img + (size_t)n * 300 * 300 * 3;
+    const float mean[3] = {mb, mg, mr};
+    v4f acc = *reinterpret_cast<const v4f*>(b + 4 * cg);
+    for (int ky = 0; ky < 7; ++ky) {
+        const int iy = 2 * oy - 3 + ky;
+        if ((unsigned)iy >= 300u) continue;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+            const int ix = 2 * ox - 3 + kx;
+            if ((unsigned)ix >= 300u) continue;
+            const uint8_t* p = src + ((size_t)iy * 300 + ix) * 3;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float v = (float)p[ci] - mean[ci];
+                acc += v * *reinterpret_cast<const v4f*>(&ws[((ky * 7 + kx) * 3 + ci) * 32 + 4 * cg]);
+            }
+        }
+    }
+    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    *reinterpret_cast<v4f*>(y + (size_t)pix * 32 + 4 * cg) = acc;
+}
+
+void launch_ssd_conv1(const uint8_t* img, const float* w, const float* b, float* y, int n, const float mean_bgr[3],
+                      hipStream_t s) {
+    const long long threads = (long long)n * 150 * 150 * 8;
+    hipLaunchKernelGGL(ssd_conv1_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, img, w, b, y, n,
+                       mean_bgr[0], mean_bgr[1], mean_bgr[2]);
+}
+
+// -------------------------------------------------------------------------------- maxpool
+__global__ __launch_bounds__(256) void maxpool3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int n_img,
+                                                         int H, int Ho, int C) {
+    const int c4 = C / 4;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)n_img * Ho * Ho * c4) return;
+    const int cg = (int)(gid % c4);
+    const long long pix = gid / c4;
+    const int ox = (int)(pix % Ho), oy = (int)((pix / Ho) % Ho), n = (int)(pix / ((long long)Ho * Ho));
+    v4f m = (v4f){-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy + ky;
+        if (iy >= H) continue;                       // ceil mode: the last window hangs over the edge
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox + kx;
+            if (ix >= H) continue;
+            const v4f v = *reinterpret_cast<const v4f*>(x + (((size_t)n * H + iy) * H + ix) * C + 4 * cg);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    *reinterpret_cast<v4f*>(y + (size_t)pix * C + 4 * cg) = m;
+}
+
+void launch_maxpool3s2(const float* x, float* y, int n, int H, int Ho, int C, hipStream_t s) {
+    const long long threads = (long long)n * Ho * Ho * (C / 4);
+    hipLaunchKernelGGL(maxpool3s2_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, x, y, n, H, Ho, C);
+}
+
+// --------------------------------------------------------------------------------- l2norm
+// one 32-lane half-wave per pixel (C = 128 = 32 lanes x float4)
+__global__ __launch_bounds__(256) void l2norm128_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                        float* __restrict__ y, long long npix) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long pix = gid >> 5;
+    const int l = (int)(gid & 31);
+    if (pix >= npix) return;                          // whole half-waves leave together (256 % 32 == 0)
+    const v4f v = *reinterpret_cast<const v4f*>(x + pix * 128 + 4 * l);
+    float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float inv = 1.0f / sqrtf(ss + 1e-10f);
+    const v4f sc = *reinterpret_cast<const v4f*>(scale + 4 * l);
+    *reinterpret_cast<v4f*>(y + pix * 128 + 4 * l) = v * inv * sc;
+}
+
+void launch_l2norm128(const float* x, const float* scale, float* y, long long npix, hipStream_t s) {
+    const long long threads = npix * 32;
+    hipLaunchKernelGGL(l2norm128_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, x, scale, y, npix);
+}
+
+// --------------------------------------------------------------------------------- decode
+// thread per prior: PriorBox (offset .5, clip false) generated analytically, CENTER_SIZE decode
+// with variances, softmax over (background, face).
+__global__ __launch_bounds__(256) void ssd_decode_kernel(SsdHeads H, float* __restrict__ boxes, float* __restrict__ prob,
+                                                         int n_priors, float image_size, float v0, float v1, float v2,
+                                                         float v3) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_priors) return;
+    const int img = blockIdx.y;
+    int s = 0;
+    while (s < 5 && i >= H.first[s + 1]) ++s;
+    const int local = i - H.first[s], p = H.priors[s], m = H.map[s];
+    const int cell = local / p, k = local - cell * p;
+    // the prior itself comes from the host-built table (PriorBox evaluated in double, rounded once)
+    const float x1 = H.prior_tab[i * 4], y1 = H.prior_tab[i * 4 + 1], x2 = H.prior_tab[i * 4 + 2], y2 = H.prior_tab[i * 4 + 3];
+    // head output [img][cell][p*6]: p*4 loc values then p*2 conf values
+    const float* o = H.out[s] + ((size_t)img * m * m + cell) * (p * 6);
+    const float l0 = o[k * 4], l1 = o[k * 4 + 1], l2 = o[k * 4 + 2], l3 = o[k * 4 + 3];
+    const float c0 = o[p * 4 + k * 2], c1 = o[p * 4 + k * 2 + 1];
+    const float pw = x2 - x1, ph = y2 - y1, pcx = (x1 + x2) * 0.5f, pcy = (y1 + y2) * 0.5f;
+    const float dcx = v0 * l0 * pw + pcx, dcy = v1 * l1 * ph + pcy;
+    const float dw = expf(v2 * l2) * pw, dh = expf(v3 * l3) * ph;
+    float* b = boxes + ((size_t)img * n_priors + i) * 4;
+    b[0] = dcx - dw * 0.5f; b[1] = dcy - dh * 0.5f; b[2] = dcx + dw * 0.5f; b[3] = dcy + dh * 0.5f;
+    const float mxl = fmaxf(c0, c1);
+    const float e0 = expf(c0 - mxl), e1 = expf(c1 - mxl);
+    prob[(size_t)img * n_priors + i] = e1 / (e0 + e1);
+}
+
+void launch_ssd_decode(const SsdHeads& H, float* boxes, float* prob, int n, int n_priors, float image_size,
+                       const float var[4], hipStream_t s) {
+    hipLaunchKernelGGL(ssd_decode_kernel, dim3((n_priors + 255) / 256, n), dim3(256), 0, s, H, boxes, prob, n_priors,
+                       image_size, var[0], var[1], var[2], var[3]);
+}
+
+// ------------------------------------------------------------------------------------ NMS
+constexpr int NMS_SORT = 16384;      // next power of two >= 8732
+constexpr int NMS_TOPK = 400;
+
+__device__ __forceinline__ float box_area(const float* b) {
+    return (b[2] < b[0] || b[3] < b[1]) ? 0.f : (b[2] - b[0]) * (b[3] - b[1]);
+}
+__device__ __forceinline__ float jaccard(const float* a, const float* b) {
+    if (b[0] > a[2] || b[2] < a[0] || b[1] > a[3] || b[3] < a[1]) return 0.f;
+    const float ix = fminf(a[2], b[2]) - fmaxf(a[0], b[0]), iy = fminf(a[3], b[3]) - fmaxf(a[1], b[1]);
+    const float inter = ix * iy;
+    return inter / (box_area(a) + box_area(b) - inter);
+}
+
+// one 1024-thread block per image; key = score bits (positive floats order like uints) in the high
+// word, ~index in the low word, sorted descending => score desc, index asc (stable order)
+__global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ prob,
+                                                       int n_priors, float conf_thr, double nms_thr, int keep_top_k,
+                                                       float* __restrict__ rows, int* __restrict__ count) {
+    __shared__ unsigned long long key[NMS_SORT];
+    __shared__ float cand[NMS_TOPK][4];
+    __shared__ unsigned char dead[NMS_TOPK];
+    __shared__ int kept[NMS_TOPK];
+    __shared__ int n_kept;
+    const int tid = threadIdx.x, img = blockIdx.x;
+    const float* pr = prob + (size_t)img * n_priors;
+    for (int i = tid; i < NMS_SORT; i += 1024) {
+        unsigned long long k = 0ull;
+        if (i < n_priors) {
+            const float p = pr[i];
+            if (p > conf_thr) k = ((unsigned long long)__float_as_uint(p) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (int size = 2; size <= NMS_SORT; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < NMS_SORT / 2; t += 1024) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const unsigned long long a = key[lo], b = key[hi];
+                if ((a < b) == desc) { key[lo] = b; key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    // candidates: first min(top_k, #valid) keys
+    int ncand = 0;
+    for (int i = tid; i < NMS_TOPK; i += 1024) {
+        dead[i] = 0;
+        if (key[i] != 0ull) {
+            const unsigned idx = 0xFFFFFFFFu - (unsigned)(key[i] & 0xFFFFFFFFull);
+            const float* b = boxes + ((size_t)img * n_priors + idx) * 4;
+            cand[i][0] = b[0]; cand[i][1] = b[1]; cand[i][2] = b[2]; cand[i][3] = b[3];
+        }
+    }
+    if (tid == 0) n_kept = 0;
+    __syncthreads();
+    for (int i = 0; i < NMS_TOPK; ++i) ncand += key[i] != 0ull;     // every thread computes the same count
+    for (int i = 0; i < ncand; ++i) {
+        if (!dead[i]) {                                             // uniform: all threads read the same flag
+            if (tid == 0) kept[n_kept++] = i;
+            for (int j = i + 1 + tid; j < ncand; j += 1024)
+                if (!dead[j] && (double)jaccard(cand[i], cand[j]) > nms_thr) dead[j] = 1;
+        }
+        __syncthreads();
+    }
+    const int nk = n_kept < keep_top_k ? n_kept : keep_top_k;
+    for (int r = tid; r < nk; r += 1024) {
+        const int i = kept[r];
+        float* o = rows + ((size_t)img * keep_top_k + r) * 5;
+        o[0] = __uint_as_float((unsigned)(key[i] >> 32));
+        o[1] = cand[i][0]; o[2] = cand[i][1]; o[3] = cand[i][2]; o[4] = cand[i][3];
+    }
+    if (tid == 0) count[img] = nk;
+}
+
+void launch_ssd_nms(const float* boxes, const float* prob, int n, int n_priors, float conf_thr, double nms_thr,
+                    int keep_top_k, float* rows, int* count, hipStream_t s) {
+    hipLaunchKernelGGL(ssd_nms_kernel, dim3(n), dim3(1024), 0, s, boxes, prob, n_priors, conf_thr, nms_thr, keep_top_k,
+                       rows, count);
+}
+
+}  // namespace dfd

@@ -182,6 +182,75 @@ def serialize(tensors: Mapping[str, np.ndarray]) -> bytes:
     return bytes(buf)
 
 
+# --------------------------------------------------------------------------- SSD detector
+def seeded_ssd_state_dict(seed: int = 0, background_bias: float = 4.0) -> Dict[str, np.ndarray]:
+    """Random-init detector weights in Caffe layout (``<layer>.weight`` [co][ci][k][k], ``.bias``).
+
+    He-normal convolutions; the background-class bias of every confidence head is raised so that
+    a random network marks only a fraction of a percent of the 8732 priors as faces, as a
+    trained detector would (otherwise every prior fires and NMS is all that is exercised).
+    """
+    from . import ssd_arch as S
+
+    rs = np.random.RandomState(seed + 1000)
+    sd: Dict[str, np.ndarray] = {}
+    for name, kind, a in S.LAYERS:
+        if kind == "conv":
+            _, ci, co, k = a[:4]
+            gain = np.sqrt(2.0) if a[7] else 1.0
+            if a[8] is not None or name.endswith("p"):
+                gain *= 0.7                                    # two branches are summed
+            if name == "conv1":
+                gain /= 50.0                                   # mean-subtracted pixels are O(50): bring activations to O(1)
+            sd[name + ".weight"] = (rs.randn(co, ci, k, k) * gain / np.sqrt(ci * k * k)).astype(np.float32)
+            sd[name + ".bias"] = (rs.randn(co) * 0.05).astype(np.float32)
+        elif kind == "l2norm":
+            sd[name + ".scale"] = np.full(a[1], S.NORM_SCALE_INIT, np.float32)
+    for t, c, m, _, _, ars, _ in S.SOURCES:
+        p = S.priors_per_cell(ars)
+        sd[t + "_loc.weight"] = (rs.randn(p * 4, c, 3, 3) * 0.5 / np.sqrt(c * 9)).astype(np.float32)
+        sd[t + "_loc.bias"] = (rs.randn(p * 4) * 0.2).astype(np.float32)
+        sd[t + "_conf.weight"] = (rs.randn(p * 2, c, 3, 3) * 0.6 / np.sqrt(c * 9)).astype(np.float32)
+        b = rs.randn(p * 2).astype(np.float32) * 0.1
+        b[0::2] += background_bias                            # channel order per prior: (background, face)
+        sd[t + "_conf.bias"] = b
+    return sd
+
+
+def pack_ssd_tensors(sd: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Detector tensors for the GPU: GEMM convs as [co][ky][kx][ci], conv1 as [ky][kx][ci][co],
+    per-source loc+conf heads fused into one [p*6][ky][kx][ci] matrix (loc rows first)."""
+    from . import ssd_arch as S
+
+    t: Dict[str, np.ndarray] = {}
+    for name, kind, a in S.LAYERS:
+        if kind == "conv":
+            w = np.asarray(sd[name + ".weight"], np.float32)
+            if name == "conv1":
+                t["ssd.conv1.w"] = np.ascontiguousarray(w.transpose(2, 3, 1, 0))
+            else:
+                t[f"ssd.{name}.w"] = np.ascontiguousarray(w.transpose(0, 2, 3, 1)).reshape(w.shape[0], -1)
+            t[f"ssd.{name}.b"] = np.asarray(sd[name + ".bias"], np.float32)
+        elif kind == "l2norm":
+            t[f"ssd.{name}.scale"] = np.asarray(sd[name + ".scale"], np.float32)
+    for src, c, m, _, _, ars, _ in S.SOURCES:
+        w = np.concatenate([sd[src + "_loc.weight"], sd[src + "_conf.weight"]], 0).astype(np.float32)
+        t[f"ssd.{src}.head.w"] = np.ascontiguousarray(w.transpose(0, 2, 3, 1)).reshape(w.shape[0], -1)
+        t[f"ssd.{src}.head.b"] = np.concatenate([sd[src + "_loc.bias"], sd[src + "_conf.bias"]]).astype(np.float32)
+    return t
+
+
+def pack_all(b0_sd: Mapping[str, np.ndarray], ssd_sd: Mapping[str, np.ndarray] = None) -> bytes:
+    """One blob for `dfd_create`: classifier + colour tables (+ detector when given)."""
+    from . import luts
+
+    t = pack_b0_tensors(b0_sd)
+    t.update(luts.as_float_tensors())
+    if ssd_sd is not None:
+        t.update(pack_ssd_tensors(ssd_sd))
+    return serialize(t)
+
+
 def pack_b0(sd: Mapping[str, np.ndarray], with_tables: bool = True) -> bytes:
     """Classifier blob; by default also carries the colour LUTs the pre-processing kernels use."""
     t = pack_b0_tensors(sd)

@@ -25,8 +25,14 @@ def seeded_sd(pkg):
 
 
 @pytest.fixture(scope="session")
+def ssd_sd(pkg):
+    return pkg.weights.seeded_ssd_state_dict(0)
+
+
+@pytest.fixture(scope="session")
 def b0_handle(pkg, seeded_sd):
     """One classifier handle shared by the GPU tests (fails loudly if the .so or GPU is missing)."""
-    h = pkg._lib.Handle(pkg.weights.pack_b0(seeded_sd), device=0, max_batch=16)
+    blob = pkg.weights.pack_all(seeded_sd, pkg.weights.seeded_ssd_state_dict(0))
+    h = pkg._lib.Handle(blob, device=0, max_batch=16)
     yield h
     h.close()
