@@ -154,6 +154,19 @@ int dfd_forensics_reset(dfd_handle* h, int stream_id);
 /* Mirrors the analyzer's attributes frame_count, len(temporal_diffs), prev_frame_gray is not None. */
 int dfd_forensics_state(dfd_handle* h, int stream_id, int* frame_count, int* n_diffs, int* has_prev);
 
+/* ---- one frame, end to end ---------------------------------------------------------------
+ * The per-frame work of DeepfakeDetector.predict (reference deepfake_detection.py:597-626)
+ * and of the /analyze handler (reference backend_server.py:147-164) with ONE upload of the
+ * frame: forensics (full or fast) on `stream_id`, face detection, then crop -> CLAHE -> 224x224
+ * -> classifier for the first min(n_detected, max_faces) boxes (predict uses all faces, the
+ * server faces[0]).  scores_out[6]/forensic_prob_out as dfd_forensics; xywh_out receives
+ * n_faces_out boxes and logits_out one logit per box.  Calibration, the +0.10 small-face
+ * heuristic and the vote are host logic (scalars). */
+int dfd_analyze_frame(dfd_handle* h, int stream_id, const uint8_t* bgr, int height, int width,
+                      int stride, int full_forensics, float conf_thr, int max_faces, int apply_clahe,
+                      double* scores_out, double* forensic_prob_out, int32_t* xywh_out,
+                      int* n_faces_out, float* logits_out);
+
 #ifdef __cplusplus
 }
 #endif

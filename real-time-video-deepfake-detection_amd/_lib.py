@@ -56,6 +56,8 @@ SIGNATURES = {
     "dfd_has_detector": (C.c_int, [C.c_void_p]),
     "dfd_ssd_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p,
                               C.c_size_t, C.POINTER(C.c_size_t)]),
+    "dfd_analyze_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "dfd_forensics": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "dfd_forensics_reset": (C.c_int, [C.c_void_p, C.c_int]),
@@ -291,6 +293,24 @@ class Handle:
                                                float(confidence_threshold), _ptr(boxes), _ptr(conf), max_out, C.byref(n)))
         out = [tuple(int(v) for v in boxes[i]) for i in range(n.value)]
         return (out, conf[: n.value].copy()) if with_conf else out
+
+    def analyze_frame(self, frame, full_forensics: bool, stream_id: int = 0, confidence_threshold: float = 0.5,
+                      max_faces: int = 16, apply_clahe: bool = True):
+        """One upload: forensics + detect + crop/CLAHE + classify.
+        -> (scores dict, forensic probability, [(x,y,w,h)...], logits (n,))"""
+        a = self._as_bgr(frame)
+        max_faces = max(1, min(int(max_faces), self.max_batch))
+        sc = np.empty(6, np.float64)
+        prob = C.c_double()
+        boxes = np.zeros((max_faces, 4), np.int32)
+        logits = np.zeros(max_faces, np.float32)
+        n = C.c_int()
+        self._check(self._lib.dfd_analyze_frame(self._p, int(stream_id), _ptr(a), a.shape[0], a.shape[1], a.strides[0],
+                                                int(bool(full_forensics)), float(confidence_threshold), max_faces,
+                                                int(bool(apply_clahe)), _ptr(sc), C.byref(prob), _ptr(boxes), C.byref(n),
+                                                _ptr(logits)))
+        scores = {k: float(v) for k, v in zip(self.FORENSIC_KEYS, sc) if not np.isnan(v)}
+        return scores, float(prob.value), [tuple(int(v) for v in boxes[i]) for i in range(n.value)], logits[: n.value].copy()
 
     def ssd_tap(self, frame, name: str, capacity: int) -> np.ndarray:
         a = self._as_bgr(frame)

@@ -110,6 +110,14 @@ int ensure(dfd_handle* h, DevBuf* b, size_t bytes);
 // builds h->color from the "lut.*" tensors of the blob (imgproc_api.hip)
 int color_tables_init(dfd_handle* h);
 
+// stages that work on a frame already resident in HBM (forensic_api / ssd_api / imgproc_api)
+int forensics_run(dfd_handle* h, int stream_id, const uint8_t* frame_dev, int hh, int ww, int stride, int full,
+                  double* scores_out, double* prob_out, double* stats_out);
+int detect_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, float conf_thr, int32_t* xywh_out,
+               float* conf_out, int max_out, int* n_out);
+int preprocess_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, const int32_t* xywh, int n,
+                   int apply_clahe);
+
 // b0_plan.cpp
 int b0_build_plan(dfd_handle* h);
 // Runs the classifier on h->stream.  `stop_at_features`: leave after the pooled 1280-vector.

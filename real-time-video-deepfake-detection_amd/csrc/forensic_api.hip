@@ -76,15 +76,12 @@ double clip01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
 
 }  // namespace
 
-extern "C" {
+namespace dfd {
 
-int dfd_forensics(dfd_handle* h, int stream_id, const uint8_t* bgr, int hh, int ww, int stride, int full,
+// the analyzer on a frame that is already in HBM (shared by dfd_forensics and dfd_analyze_frame)
+int forensics_run(dfd_handle* h, int stream_id, const uint8_t* frame_dev, int hh, int ww, int stride, int full,
                   double* scores_out, double* prob_out, double* stats_out) {
-    if (!h) return DFD_ERR_ARG;
-    if (!bgr || !scores_out || !prob_out || hh <= 0 || ww <= 0 || stride < ww * 3)
-        return fail(h, DFD_ERR_ARG, "forensics: bad pointer or geometry");
     if (!h->has_color) return fail(h, DFD_ERR_STATE, "forensics needs the colour tables (blob packed without luts)");
-    DFD_HIP_TRY(h, hipSetDevice(h->device));
     int rc = state_init(h, 1);
     if (rc) return rc;
     ForensicState& F = *h->forensic;
@@ -95,9 +92,7 @@ int dfd_forensics(dfd_handle* h, int stream_id, const uint8_t* bgr, int hh, int 
     }
     S.frame_count += 1;                                              // frame_analysis.py:68,110
 
-    if ((rc = ensure(h, &h->frame_buf, (size_t)hh * stride))) return rc;
-    DFD_HIP_TRY(h, hipMemcpyAsync(h->frame_buf.p, bgr, (size_t)hh * stride, hipMemcpyHostToDevice, h->stream));
-    launch_resize_bgr((const uint8_t*)h->frame_buf.p, 1, hh, ww, stride, 0, F.buf.rs, 256, 256, h->stream);
+    launch_resize_bgr(frame_dev, 1, hh, ww, stride, 0, F.buf.rs, 256, 256, h->stream);
     launch_forensics(F.buf, 1, full != 0, h->color, F.twiddle, h->stream);
     double mean_diff = -1.0;
     if (S.has_prev) launch_absdiff(F.buf.gray, (const uint8_t*)S.prev_gray, F.diff_part, h->stream);
@@ -190,6 +185,22 @@ int dfd_forensics(dfd_handle* h, int stream_id, const uint8_t* bgr, int hh, int 
         for (int i = 0; i < DFD_FORENSIC_NSTATS; ++i) stats_out[i] = out[i];
     }
     return DFD_OK;
+}
+
+}  // namespace dfd
+
+extern "C" {
+
+int dfd_forensics(dfd_handle* h, int stream_id, const uint8_t* bgr, int hh, int ww, int stride, int full,
+                  double* scores_out, double* prob_out, double* stats_out) {
+    if (!h) return DFD_ERR_ARG;
+    if (!bgr || !scores_out || !prob_out || hh <= 0 || ww <= 0 || stride < ww * 3)
+        return fail(h, DFD_ERR_ARG, "forensics: bad pointer or geometry");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    const int rc = ensure(h, &h->frame_buf, (size_t)hh * stride);
+    if (rc) return rc;
+    DFD_HIP_TRY(h, hipMemcpyAsync(h->frame_buf.p, bgr, (size_t)hh * stride, hipMemcpyHostToDevice, h->stream));
+    return forensics_run(h, stream_id, (const uint8_t*)h->frame_buf.p, hh, ww, stride, full, scores_out, prob_out, stats_out);
 }
 
 int dfd_forensics_reset(dfd_handle* h, int stream_id) {

@@ -121,7 +121,42 @@ int preprocess_on_device(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww
 
 }  // namespace
 
+namespace dfd {
+int preprocess_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, const int32_t* xywh, int n,
+                   int apply_clahe) {
+    return preprocess_on_device(h, frame_dev, hh, ww, stride, xywh, n, apply_clahe);
+}
+}  // namespace dfd
+
 extern "C" {
+
+// DeepfakeDetector's per-frame work with ONE upload of the frame: forensics -> detect -> crop/CLAHE ->
+// classify (reference backend_server.py:147-164 / deepfake_detection.py:597-615).
+int dfd_analyze_frame(dfd_handle* h, int stream_id, const uint8_t* bgr, int hh, int ww, int stride, int full_forensics,
+                      float conf_thr, int max_faces, int apply_clahe, double* scores_out, double* forensic_prob_out,
+                      int32_t* xywh_out, int* n_faces_out, float* logits_out) {
+    if (!h) return DFD_ERR_ARG;
+    if (!bgr || !scores_out || !forensic_prob_out || !xywh_out || !n_faces_out || !logits_out || max_faces <= 0 ||
+        hh <= 0 || ww <= 0 || stride < ww * 3)
+        return fail(h, DFD_ERR_ARG, "analyze_frame: bad pointer or geometry");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure(h, &h->frame_buf, (size_t)hh * stride);
+    if (rc) return rc;
+    DFD_HIP_TRY(h, hipMemcpyAsync(h->frame_buf.p, bgr, (size_t)hh * stride, hipMemcpyHostToDevice, h->stream));
+    const uint8_t* fd = (const uint8_t*)h->frame_buf.p;
+    if ((rc = forensics_run(h, stream_id, fd, hh, ww, stride, full_forensics, scores_out, forensic_prob_out, nullptr))) return rc;
+    *n_faces_out = 0;
+    if (max_faces > h->max_batch) max_faces = h->max_batch;
+    int n = 0;
+    if ((rc = detect_run(h, fd, hh, ww, stride, conf_thr, xywh_out, nullptr, max_faces, &n))) return rc;
+    *n_faces_out = n;
+    if (n == 0) return DFD_OK;
+    if ((rc = preprocess_on_device(h, fd, hh, ww, stride, xywh_out, n, apply_clahe))) return rc;
+    if ((rc = b0_forward(h, h->in_nchw, n, h->logits, nullptr, nullptr))) return rc;
+    DFD_HIP_TRY(h, hipMemcpyAsync(logits_out, h->logits, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DFD_OK;
+}
 
 int dfd_resize_bgr(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride, int dh, int dw, uint8_t* out) {
     if (!h) return DFD_ERR_ARG;

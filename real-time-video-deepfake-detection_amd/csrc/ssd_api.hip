@@ -285,6 +285,25 @@ int ssd_postprocess(const float* rows, int nrows, int hh, int ww, float conf_thr
     return k;
 }
 
+// detector on a frame already in HBM (shared by dfd_detect_faces and dfd_analyze_frame)
+int detect_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, float conf_thr, int32_t* xywh_out,
+               float* conf_out, int max_out, int* n_out) {
+    *n_out = 0;
+    if (hh < 30 || ww < 30) return DFD_OK;                                    // face_detection.py:55-56
+    if (!h->ssd || !h->ssd->ready) return fail(h, DFD_ERR_STATE, "detector weights were not packed into the blob (weights.pack_all)");
+    int rc;
+    if ((rc = ensure(h, &h->ssd->in_u8, (size_t)SSD_IN * SSD_IN * 3))) return rc;
+    launch_resize_bgr(frame_dev, 1, hh, ww, stride, 0, (uint8_t*)h->ssd->in_u8.p, SSD_IN, SSD_IN, h->stream);
+    if ((rc = ssd_forward(h, (const uint8_t*)h->ssd->in_u8.p, 1, nullptr, nullptr, 0, nullptr))) return rc;
+    float rows[SSD_KEEP * 5];
+    int cnt = 0;
+    DFD_HIP_TRY(h, hipMemcpyAsync(&cnt, h->ssd->count.p, 4, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipMemcpyAsync(rows, h->ssd->rows.p, sizeof rows, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *n_out = ssd_postprocess(rows, cnt, hh, ww, conf_thr, xywh_out, conf_out, max_out);
+    return DFD_OK;
+}
+
 }  // namespace dfd
 
 extern "C" {
@@ -300,19 +319,10 @@ int dfd_detect_faces(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stri
     if (hh < 30 || ww < 30) return DFD_OK;                                    // face_detection.py:55-56
     if (!h->ssd || !h->ssd->ready) return fail(h, DFD_ERR_STATE, "detector weights were not packed into the blob (weights.pack_all)");
     DFD_HIP_TRY(h, hipSetDevice(h->device));
-    int rc;
-    if ((rc = ensure(h, &h->frame_buf, (size_t)hh * stride))) return rc;
-    if ((rc = ensure(h, &h->ssd->in_u8, (size_t)SSD_IN * SSD_IN * 3))) return rc;
+    const int rc = ensure(h, &h->frame_buf, (size_t)hh * stride);
+    if (rc) return rc;
     DFD_HIP_TRY(h, hipMemcpyAsync(h->frame_buf.p, bgr, (size_t)hh * stride, hipMemcpyHostToDevice, h->stream));
-    launch_resize_bgr((const uint8_t*)h->frame_buf.p, 1, hh, ww, stride, 0, (uint8_t*)h->ssd->in_u8.p, SSD_IN, SSD_IN, h->stream);
-    if ((rc = ssd_forward(h, (const uint8_t*)h->ssd->in_u8.p, 1, nullptr, nullptr, 0, nullptr))) return rc;
-    float rows[SSD_KEEP * 5];
-    int cnt = 0;
-    DFD_HIP_TRY(h, hipMemcpyAsync(&cnt, h->ssd->count.p, 4, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipMemcpyAsync(rows, h->ssd->rows.p, sizeof rows, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
-    *n_out = ssd_postprocess(rows, cnt, hh, ww, conf_thr, xywh_out, conf_out, max_out);
-    return DFD_OK;
+    return detect_run(h, (const uint8_t*)h->frame_buf.p, hh, ww, stride, conf_thr, xywh_out, conf_out, max_out, n_out);
 }
 
 int dfd_ssd_tap(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride, const char* name, float* out,

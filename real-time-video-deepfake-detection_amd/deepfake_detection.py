@@ -1,0 +1,280 @@
+"""Host mirror of the reference's ``deepfake_detection.py`` over the HIP path.
+
+`DeepfakeDetector` keeps the constructor, attributes, methods and result dictionaries of
+reference deepfake_detection.py:292-726 and the module keeps its globals (`DEVICE`, `model`,
+`mtcnn`, `detector`, `predict`, `predict_with_forensics`; :21-32,729-747).  Per frame the GPU
+does forensics, face detection, crop -> CLAHE -> 224x224 -> EfficientNet-B0 in ONE call
+(`dfd_analyze_frame`); calibration, the small-face heuristic and the vote stay on the host as in
+the reference.  Deliberate differences: no MTCNN re-crop (`mtcnn` is None),
+TTA and GradCAM are not implemented (both are disabled in the reference's shipped configurations,
+:730-736 and backend_server.py:57), frames are returned un-annotated, nothing is printed per frame.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import pickle
+import threading
+from typing import List, Optional
+
+import numpy as np
+
+from . import runtime
+from ._lib import DfdError, Handle
+from .face_detection import detect_bounding_box
+from .frame_analysis import FrameForensicAnalyzer
+from .tracker import TemporalTracker
+
+log = logging.getLogger(__name__)
+
+DEVICE = f"cuda:{runtime.device_index()}"
+mtcnn = None                     # reference :24-28; the MTCNN stage is bypassed
+
+
+def _sigmoid32(logit) -> float:
+    """torch.sigmoid on a float32 scalar, then .item() (reference :397-398)."""
+    x = np.float32(logit)
+    return float(np.float32(1.0) / (np.float32(1.0) + np.exp(-x, dtype=np.float32)))
+
+
+class _LazyModel:
+    """`model` global of the reference (:32): the classifier bound to the default handle."""
+
+    def __call__(self, rgb_input, freq_input=None):
+        x = rgb_input.detach().cpu().numpy() if hasattr(rgb_input, "detach") else np.asarray(rgb_input)
+        out = runtime.default_handle().classify(np.ascontiguousarray(x, dtype=np.float32))
+        if hasattr(rgb_input, "detach"):
+            import torch
+
+            return torch.from_numpy(out)
+        return out
+
+    def eval(self):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+
+model = _LazyModel()
+
+
+class DeepfakeDetector:
+    def __init__(self, enable_gradcam=False, use_tta=True, num_tta_augmentations=3, detection_threshold=0.5,
+                 face_weight=0.70, forensic_weight=0.30, *, handle: Optional[Handle] = None):
+        self.enable_gradcam = enable_gradcam
+        self.use_tta = use_tta
+        self.num_tta_augmentations = num_tta_augmentations
+        self.detection_threshold = detection_threshold
+        self.face_weight = face_weight                  # stored, never used - as in the reference
+        self.forensic_weight = forensic_weight
+        if use_tta and num_tta_augmentations > 1:
+            log.info("TTA is not implemented on the HIP path; using a single prediction per face")
+        self.temporal_tracker = TemporalTracker(window_size=60, high_confidence_threshold=0.6, voting_window=10,
+                                                detection_threshold=detection_threshold)
+        self.frame_count = 0
+        self._handle = handle
+        self.frame_analyzer = FrameForensicAnalyzer(analysis_size=(256, 256), handle=handle)
+        self.full_forensic_interval = 3
+        self.last_frame_forensic_result = None
+        self.calibrator = None
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "weights", "calibrator.pkl")
+        if os.path.exists(path):
+            try:
+                with open(path, "rb") as f:
+                    self.calibrator = pickle.load(f)
+            except Exception:                             # reference :341-342
+                log.warning("could not load calibrator")
+        self._lock = threading.Lock()                     # a handle is single-caller; Flask is threaded
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def handle(self) -> Handle:
+        if self._handle is None:
+            self._handle = runtime.default_handle()
+            self.frame_analyzer._handle = self._handle
+        return self._handle
+
+    def reset(self):
+        """reference :344-355"""
+        self.temporal_tracker.reset()
+        self.frame_count = 0
+        self.frame_analyzer.reset()
+        self.last_frame_forensic_result = None
+
+    # ------------------------------------------------------------------ scalars after the network
+    def apply_calibration(self, raw_prob):
+        """reference :445-455"""
+        if self.calibrator is None:
+            return raw_prob
+        try:
+            return self.calibrator.predict_proba([[raw_prob]])[0][1]
+        except Exception:
+            return raw_prob
+
+    def apply_heuristics(self, fake_prob, face_region):
+        """reference :489-502: +0.10 for crops under 80 px, clipped to [0,1]."""
+        h, w = face_region.shape[:2]
+        return self._heuristics_hw(fake_prob, h, w)
+
+    @staticmethod
+    def _heuristics_hw(fake_prob, h, w):
+        adjustment = 0.10 if (h < 80 or w < 80) else 0.0
+        return np.clip(fake_prob + adjustment, 0, 1)
+
+    def _finish_face(self, logit, h, w):
+        p = self.apply_calibration(_sigmoid32(logit))
+        return self._heuristics_hw(p, h, w)
+
+    # ------------------------------------------------------------------ reference methods
+    def preprocess_face_quality(self, face_region):
+        """BGR -> Lab, CLAHE(2.0, 8x8) on L, Lab -> BGR on the GPU (reference :357-370)."""
+        with self._lock:
+            return self.handle.preprocess_face_quality(np.ascontiguousarray(face_region))
+
+    def _forensic_is_full(self) -> bool:
+        return self.frame_count % self.full_forensic_interval == 0          # reference :509
+
+    def analyze_frame_forensics(self, frame):
+        """reference :504-515"""
+        with self._lock:
+            if self._forensic_is_full():
+                result = self.frame_analyzer.analyze(frame)
+            else:
+                result = self.frame_analyzer.analyze_fast(frame)
+        self.last_frame_forensic_result = result
+        return result
+
+    def analyze_face(self, face_region):
+        """(fake_prob, fake_prob, None) or (None, None, None) (reference :517-550)."""
+        try:
+            face = np.ascontiguousarray(face_region)
+            if face.ndim != 3 or face.shape[2] != 3 or face.shape[0] < 1 or face.shape[1] < 1:
+                return None, None, None
+            h, w = face.shape[:2]
+            with self._lock:
+                logit = self.handle.classify_crops(face, [(0, 0, w, h)], apply_clahe=True)[0, 0]
+            p = self._finish_face(logit, h, w)
+            return p, p, None
+        except (DfdError, ValueError) as e:
+            log.warning("face analysis error: %s", e)
+            return None, None, None
+
+    def _frame_on_gpu(self, frame, max_faces):
+        """forensics + detection + per-face logits in one library call."""
+        full = self._forensic_is_full()
+        with self._lock:
+            scores, prob, boxes, logits = self.handle.analyze_frame(
+                frame, full, stream_id=self.frame_analyzer.stream_id, confidence_threshold=0.5, max_faces=max_faces)
+            number = self.frame_analyzer.frame_count
+        forensic = {'scores': scores, 'fake_probability': prob,
+                    'analysis_type': 'frame_forensic' if full else 'frame_forensic_fast', 'frame_number': number}
+        self.last_frame_forensic_result = forensic
+        return forensic, boxes, logits
+
+    def predict(self, frame):
+        """(frame, trigger_forensic, forensic_frame, result_data) (reference :588-686)."""
+        self.frame_count += 1
+        frame = np.ascontiguousarray(frame)
+        small = frame.shape[0] < 30 or frame.shape[1] < 30
+        frame_forensic, faces, logits = self._frame_on_gpu(frame, max_faces=self.handle.max_batch)
+        if small:
+            faces, logits = [], []
+        trigger_forensic, forensic_frame = False, None
+        face_results: List[dict] = []
+        confidence_level = self.temporal_tracker.get_confidence_level()
+        if len(faces) > 0:
+            for (x, y, w, h), logit in zip(faces, logits):
+                fake_prob = self._finish_face(logit, h, w)
+                self.temporal_tracker.update(fake_prob)
+                confidence_level = self.temporal_tracker.get_confidence_level()
+                if self.temporal_tracker.should_trigger_forensic_analysis():
+                    trigger_forensic, forensic_frame = True, frame.copy()
+                face_results.append({'face_prob': float(fake_prob), 'combined_prob': float(fake_prob),
+                                     'bbox': {'x': int(x), 'y': int(y), 'w': int(w), 'h': int(h)}})
+        else:
+            self.temporal_tracker.update(frame_forensic['fake_probability'])
+            confidence_level = self.temporal_tracker.get_confidence_level()
+            if self.temporal_tracker.should_trigger_forensic_analysis():
+                trigger_forensic, forensic_frame = True, frame.copy()
+        result_data = {
+            'frame_count': self.frame_count,
+            'faces_detected': len(faces),
+            'face_results': face_results,
+            'frame_forensic': frame_forensic,
+            'confidence_level': confidence_level if faces or self.frame_count > 1 else 'UNCERTAIN',
+            'temporal_average': float(self.temporal_tracker.get_temporal_average()),
+            'stability_score': float(self.temporal_tracker.get_stability_score()),
+            'analysis_mode': 'face+frame' if len(faces) > 0 else 'frame_only',
+        }
+        return frame, trigger_forensic, forensic_frame, result_data
+
+    def analyze(self, frame):
+        """`result_data` of `predict` - the name BASELINE.json's north_star uses."""
+        return self.predict(frame)[3]
+
+    def analyze_request(self, frame):
+        """The /analyze flow of the reference server (backend_server.py:147-233): forensics BEFORE the
+        frame counter moves, only faces[0] is classified, one vote per request.  Returns the response
+        dict without timing."""
+        frame = np.ascontiguousarray(frame)
+        small = frame.shape[0] < 30 or frame.shape[1] < 30
+        frame_forensic, faces, logits = self._frame_on_gpu(frame, max_faces=1)
+        n_detected = 0 if small else self._last_face_count(frame, faces)
+        self.frame_count += 1
+        tr = self.temporal_tracker
+        fprob = frame_forensic['fake_probability']
+        if len(faces) > 0 and not small:
+            x, y, w, h = faces[0]
+            fake_prob = self._finish_face(logits[0], h, w)
+            tr.update(fake_prob)
+            return {'success': True, 'analysis_mode': 'face+frame', 'faces_detected': n_detected,
+                    'fake_probability': float(fake_prob), 'face_probability': float(fake_prob),
+                    'frame_forensic_probability': float(fprob), 'real_probability': float(1 - fake_prob),
+                    'confidence_level': tr.get_confidence_level(), 'temporal_average': float(tr.get_temporal_average()),
+                    'stability_score': float(tr.get_stability_score()), 'frame_count': self.frame_count,
+                    'face_bbox': {'x': int(x), 'y': int(y), 'width': int(w), 'height': int(h)}}
+        tr.update(fprob)
+        return {'success': True, 'analysis_mode': 'frame_only', 'faces_detected': n_detected,
+                'fake_probability': float(fprob), 'frame_forensic_probability': float(fprob),
+                'real_probability': float(1 - fprob), 'confidence_level': tr.get_confidence_level(),
+                'temporal_average': float(tr.get_temporal_average()), 'stability_score': float(tr.get_stability_score()),
+                'frame_count': self.frame_count}
+
+    def _last_face_count(self, frame, faces):
+        """`faces_detected` of the server response counts ALL detections (backend_server.py:181); the fused
+        call classified only the first, so ask the detector for the full list when there was one."""
+        if not faces:
+            return 0
+        with self._lock:
+            return len(self.handle.detect_faces(frame, 0.5))
+
+
+_detector: Optional[DeepfakeDetector] = None
+_detector_lock = threading.Lock()
+
+
+def _global_detector() -> DeepfakeDetector:
+    """reference :730-736: module-level instance, built on first use instead of at import."""
+    global _detector
+    with _detector_lock:
+        if _detector is None:
+            _detector = DeepfakeDetector(use_tta=False, num_tta_augmentations=1, detection_threshold=0.5,
+                                         face_weight=0.70, forensic_weight=0.30)
+        return _detector
+
+
+def __getattr__(name):
+    if name == "detector":
+        return _global_detector()
+    raise AttributeError(name)
+
+
+def predict(frame):
+    """reference :739-742"""
+    return _global_detector().predict(frame)[0]
+
+
+def predict_with_forensics(frame):
+    """reference :745-747"""
+    return _global_detector().predict(frame)

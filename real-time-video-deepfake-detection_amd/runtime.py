@@ -48,7 +48,10 @@ def default_handle() -> Handle:
     global _default
     with _lock:
         if _default is None:
-            _default = Handle(W.pack_b0(default_state_dict()), device=device_index(),
+            # detector: the reference's Caffe files are not in its tree either (face_detection.py:19-20);
+            # seeded random-init weights of the same topology stand in
+            ssd = W.seeded_ssd_state_dict(int(os.environ.get("DFD_SEED", "0")))
+            _default = Handle(W.pack_all(default_state_dict(), ssd), device=device_index(),
                               max_batch=int(os.environ.get("DFD_MAX_BATCH", "16")))
         return _default
 

@@ -1,0 +1,98 @@
+"""GPU parity for the per-frame orchestrations (DeepfakeDetector.predict and the /analyze flow)
+against oracle/pipeline_ref.py on multi-frame streams: boxes, vote counts and verdicts must be
+identical (BASELINE.json: "bit-exact for bbox indices and vote counts"), probabilities within the
+logit tolerance."""
+import numpy as np
+import pytest
+
+import frames as F
+from oracle.pipeline_ref import PredictRef
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-3
+
+
+def _stream(n, seed):
+    """natural-looking frames (a few detections each) with blank frames (no detection) mixed in"""
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        if i % 4 == 3:
+            out.append(F.blank_frame(640, 480))
+        else:
+            out.append(F.natural_like(480, 640, seed=100 + seed * 10 + int(rs.randint(0, 3))))
+    return out
+
+
+@pytest.fixture()
+def refs(pkg, seeded_sd, ssd_sd):
+    return pkg.weights.to_torch(seeded_sd), pkg.weights.to_torch(ssd_sd), pkg.ssd_arch
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.75])
+def test_predict_stream_matches_oracle(pkg, b0_handle, refs, thr):
+    det = pkg.deepfake_detection.DeepfakeDetector(use_tta=False, num_tta_augmentations=1, detection_threshold=thr,
+                                                  handle=b0_handle)
+    ref = PredictRef(*refs, detection_threshold=thr)
+    levels = []
+    for frame in _stream(8, seed=int(thr * 100)):
+        want = ref.predict(frame)
+        out_frame, trigger, forensic_frame, got = det.predict(frame)
+        assert out_frame.shape == frame.shape and isinstance(trigger, bool)
+        assert set(got) == {'frame_count', 'faces_detected', 'face_results', 'frame_forensic', 'confidence_level',
+                            'temporal_average', 'stability_score', 'analysis_mode'}          # reference :675-684
+        assert got['frame_count'] == want['frame_count'] and got['faces_detected'] == want['faces_detected']
+        assert got['analysis_mode'] == want['analysis_mode']
+        assert [r['bbox'] for r in got['face_results']] == [r['bbox'] for r in want['face_results']]
+        for g, w in zip(got['face_results'], want['face_results']):
+            assert abs(g['face_prob'] - w['face_prob']) <= PROB_TOL
+            assert abs(g['face_prob'] - thr) > 2 * PROB_TOL, "fixture sits on the vote threshold"
+        assert got['frame_forensic']['analysis_type'] == want['frame_forensic']['analysis_type']
+        assert got['frame_forensic']['scores'] == want['frame_forensic']['scores']
+        assert got['confidence_level'] == want['confidence_level']
+        assert det.temporal_tracker.get_voting_stats() == want['votes']
+        assert abs(got['temporal_average'] - want['temporal_average']) <= PROB_TOL
+        levels.append(got['confidence_level'])
+    assert levels[0] == 'UNCERTAIN' and levels[-1] in ('FAKE', 'REAL')        # several votes per frame fill the window
+    det.reset()
+    assert det.frame_count == 0 and det.temporal_tracker.current_verdict is None and det.frame_analyzer.frame_count == 0
+
+
+def test_server_flow_matches_oracle(pkg, b0_handle, refs):
+    det = pkg.deepfake_detection.DeepfakeDetector(enable_gradcam=False, use_tta=False, num_tta_augmentations=1,
+                                                  detection_threshold=0.55, handle=b0_handle)      # backend_server.py:57
+    ref = PredictRef(*refs, detection_threshold=0.55)
+    for frame in _stream(12, seed=7):
+        want = ref.request(frame)
+        got = det.analyze_request(frame)
+        for k in ('analysis_mode', 'faces_detected', 'confidence_level', 'frame_count'):
+            assert got[k] == want[k], k
+        assert got.get('face_bbox') == want.get('face_bbox')
+        assert abs(got['fake_probability'] - want['fake_probability']) <= PROB_TOL
+        assert abs(got['frame_forensic_probability'] - want['frame_forensic_probability']) == 0.0
+        assert det.temporal_tracker.get_voting_stats() == want['votes']
+    assert det.temporal_tracker.get_voting_stats()['total_frames'] == 10          # one vote per request, window full
+
+
+def test_analyze_face_and_neutral_values(pkg, b0_handle, refs):
+    det = pkg.deepfake_detection.DeepfakeDetector(use_tta=False, handle=b0_handle)
+    ref = PredictRef(*refs)
+    face = F.face_frame(200, 160, 4)
+    p, p2, cam = det.analyze_face(face)
+    want, _ = ref.analyze_face(face)
+    assert p == p2 and cam is None and abs(float(p) - want) <= PROB_TOL
+    small = F.face_frame(64, 72, 5)                                               # < 80 px: +0.10 (reference :494-496)
+    ps, _, _ = det.analyze_face(small)
+    ws, _ = ref.analyze_face(small)
+    assert abs(float(ps) - ws) <= PROB_TOL and 0.0 <= float(ps) <= 1.0
+    assert det.analyze_face(np.zeros((0, 0, 3), np.uint8)) == (None, None, None)
+    assert det.analyze(F.blank_frame())['analysis_mode'] == 'frame_only'           # alias named by north_star
+    assert pkg.face_detection.detect_bounding_box(None) == []
+    assert pkg.face_detection.detect_bounding_box(np.zeros(100, np.uint8)) == []
+    assert pkg.face_detection.detect_bounding_box(np.zeros((10, 10, 3), np.uint8), handle=b0_handle) == []
+    boxes = pkg.face_detection.detect_bounding_box(F.face_frame(), handle=b0_handle)
+    region = pkg.face_detection.extract_face_region(F.face_frame(), (200, 100, 160, 220))
+    assert region.shape == (220, 160, 3) and isinstance(boxes, list)
+    drawn = pkg.face_detection.draw_bounding_boxes(F.face_frame(), boxes[:2])
+    assert drawn.shape == F.face_frame().shape
