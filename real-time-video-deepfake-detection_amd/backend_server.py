@@ -1,0 +1,152 @@
+"""Flask surface of the reference's ``backend_server.py``, unchanged for clients.
+
+Routes, methods, status codes and JSON keys follow reference backend_server.py:82-255 (the wire
+contract the Chrome extension reads): ``POST /analyze`` (multipart field
+``frame``), ``GET /health``, ``POST /reset``, ``GET /stats``; 400 for a missing/undecodable
+frame, 429 from the 100 ms rate limiter, 500 with ``{'error': ...}`` for anything else.  The
+per-request work is `DeepfakeDetector.analyze_request` (one GPU call).  Differences: images are
+decoded with Pillow (cv2 is not a dependency here), CORS headers are added by hand (no
+flask_cors), and the rate limiter and detector are guarded by locks (the reference shares them
+unsynchronised across Flask's worker threads, :57,62-80,275).
+"""
+from __future__ import annotations
+
+import io
+import logging
+import threading
+import time
+import traceback
+from functools import wraps
+
+import numpy as np
+from flask import Flask, jsonify, request
+
+from . import runtime
+from .deepfake_detection import DEVICE, DeepfakeDetector, model, mtcnn  # noqa: F401  (reference :39)
+from .face_detection import detect_bounding_box  # noqa: F401                      (reference :40)
+
+logging.basicConfig(level=logging.INFO, format='%(asctime)s [%(levelname)s] %(message)s', datefmt='%H:%M:%S')
+logger = logging.getLogger(__name__)
+
+app = Flask(__name__)
+
+
+@app.after_request
+def _cors(resp):                                  # reference :46-53 (CORS(app, origins="*", GET/POST/OPTIONS))
+    resp.headers["Access-Control-Allow-Origin"] = "*"
+    resp.headers["Access-Control-Allow-Methods"] = "GET, POST, OPTIONS"
+    resp.headers["Access-Control-Allow-Headers"] = "Content-Type"
+    return resp
+
+
+detector = DeepfakeDetector(enable_gradcam=False, use_tta=False, num_tta_augmentations=1,
+                            detection_threshold=0.55)                       # reference :57
+
+_last_request_time = 0.0
+_min_request_interval = 0.1                                                 # reference :63
+_rate_lock = threading.Lock()
+_detector_lock = threading.Lock()
+
+
+def rate_limit(f):
+    """reference :66-80"""
+    @wraps(f)
+    def decorated(*args, **kwargs):
+        global _last_request_time
+        with _rate_lock:
+            now = time.time()
+            elapsed = now - _last_request_time
+            if elapsed < _min_request_interval:
+                return jsonify({'error': 'Rate limited',
+                                'retry_after_ms': int((_min_request_interval - elapsed) * 1000)}), 429
+            _last_request_time = now
+        return f(*args, **kwargs)
+    return decorated
+
+
+def decode_image(image_bytes: bytes):
+    """cv2.imdecode(..., IMREAD_COLOR) stand-in: BGR uint8 (H,W,3) or None (reference :139-145)."""
+    from PIL import Image
+
+    try:
+        with Image.open(io.BytesIO(image_bytes)) as im:
+            rgb = np.asarray(im.convert("RGB"))
+    except Exception:
+        return None
+    if rgb.ndim != 3 or rgb.shape[0] < 1 or rgb.shape[1] < 1:
+        return None
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def _gpu_name():
+    try:
+        import torch
+
+        return torch.cuda.get_device_name(runtime.device_index()) if torch.cuda.is_available() else None
+    except Exception:
+        return None
+
+
+@app.route('/health', methods=['GET'])
+def health_check():
+    """reference :82-99"""
+    name = _gpu_name()
+    return jsonify({'status': 'healthy', 'model_loaded': model is not None, 'device': DEVICE, 'gpu_name': name,
+                    'frame_count': detector.frame_count,
+                    'capabilities': {'face_detection': True, 'frame_forensics': True, 'temporal_tracking': True}}), 200
+
+
+@app.route('/reset', methods=['POST'])
+def reset_detector():
+    """reference :101-115"""
+    try:
+        with _detector_lock:
+            detector.reset()
+        return jsonify({'success': True, 'message': 'Detector reset successfully'}), 200
+    except Exception as e:
+        logger.error("Reset failed: %s", e)
+        return jsonify({'success': False, 'error': str(e)}), 500
+
+
+@app.route('/analyze', methods=['POST'])
+@rate_limit
+def analyze_frame():
+    """reference :117-238"""
+    start_time = time.time()
+    try:
+        if 'frame' not in request.files:
+            return jsonify({'error': 'No frame provided'}), 400
+        frame = decode_image(request.files['frame'].read())
+        if frame is None:
+            return jsonify({'error': 'Invalid image format'}), 400
+        with _detector_lock:
+            response = detector.analyze_request(frame)
+        ms = (time.time() - start_time) * 1000
+        # key order as the reference builds it (:178-195 / :213-225)
+        bbox = response.pop('face_bbox', None)
+        response['processing_time_ms'] = round(ms, 1)
+        if bbox is not None:
+            response['face_bbox'] = bbox
+        logger.info("Frame %d%s | %.0f%% | Verdict: %s | %.0fms", response['frame_count'],
+                    "" if bbox else " [NO FACE]", response['fake_probability'] * 100, response['confidence_level'], ms)
+        return jsonify(response), 200
+    except Exception as e:
+        logger.error("Error analyzing frame: %s", e)
+        logger.error(traceback.format_exc())
+        return jsonify({'error': str(e)}), 500
+
+
+@app.route('/stats', methods=['GET'])
+def get_stats():
+    """reference :240-255"""
+    try:
+        t = detector.temporal_tracker
+        return jsonify({'frame_count': detector.frame_count, 'temporal_average': float(t.get_temporal_average()),
+                        'stability_score': float(t.get_stability_score()), 'confidence_level': t.get_confidence_level(),
+                        'history_length': len(t.score_history), 'voting': t.get_voting_stats(), 'device': DEVICE}), 200
+    except Exception as e:
+        return jsonify({'error': str(e)}), 500
+
+
+if __name__ == '__main__':
+    app.run(host='0.0.0.0', port=5000, debug=False, threaded=True)         # reference :275

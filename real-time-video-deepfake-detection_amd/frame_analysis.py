@@ -39,19 +39,32 @@ class FrameForensicAnalyzer:
             self._handle = runtime.default_handle()
         return self._handle
 
+    def _existing_handle(self) -> Optional[Handle]:
+        """The handle if one exists already - state queries and reset must not need a GPU when
+        nothing has run yet (there is then no state)."""
+        if self._handle is None:
+            from . import runtime
+
+            return runtime.peek_default_handle()
+        return self._handle
+
+    def _state(self):
+        h = self._existing_handle()
+        return h.forensics_state(self.stream_id) if h is not None else (0, 0, False)
+
     # ---- reference attributes, read back from the library
     @property
     def frame_count(self) -> int:
-        return self.handle.forensics_state(self.stream_id)[0]
+        return self._state()[0]
 
     @property
     def temporal_diffs(self):
         """len() is what callers use (reference :376); values stay on the library side."""
-        return range(self.handle.forensics_state(self.stream_id)[1])
+        return range(self._state()[1])
 
     @property
     def prev_frame_gray(self):
-        return True if self.handle.forensics_state(self.stream_id)[2] else None
+        return True if self._state()[2] else None
 
     # ---- reference methods
     def _run(self, frame, full: bool, kind: str):
@@ -73,5 +86,7 @@ class FrameForensicAnalyzer:
 
     def reset(self):
         """reference :391-395"""
-        self.handle.forensics_reset(self.stream_id)
+        h = self._existing_handle()
+        if h is not None:
+            h.forensics_reset(self.stream_id)
         self.last_stats = {}

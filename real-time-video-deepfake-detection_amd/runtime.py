@@ -56,6 +56,11 @@ def default_handle() -> Handle:
         return _default
 
 
+def peek_default_handle() -> Optional[Handle]:
+    """The default handle if it has been created, without creating it."""
+    return _default
+
+
 def set_default_handle(h: Optional[Handle]) -> None:
     global _default
     with _lock:

@@ -1,0 +1,100 @@
+"""Flask surface (reference backend_server.py:82-255; contracts from reference
+tests/test_functional.py:356-423 and tests/test_reliability.py:51-73,172-290).
+CPU part: everything that must not need a GPU.  GPU part: real /analyze round trips."""
+import io
+import time
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import frames as F
+
+
+@pytest.fixture()
+def client(pkg):
+    srv = pkg.backend_server
+    srv.app.config["TESTING"] = True
+    srv._last_request_time = 0.0
+    with srv.app.test_client() as c:
+        yield c
+
+
+def _encode(frame_bgr, fmt, **kw):
+    buf = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(frame_bgr[..., ::-1])).save(buf, format=fmt, **kw)
+    return buf.getvalue()
+
+
+def _post(client, payload, name="frame.jpg"):
+    return client.post("/analyze", data={"frame": (io.BytesIO(payload), name)}, content_type="multipart/form-data")
+
+
+# ------------------------------------------------------------------ no GPU needed
+def test_health_stats_reset_contracts(client):
+    r = client.get("/health")
+    assert r.status_code == 200
+    d = r.get_json()
+    assert d["status"] == "healthy" and {"model_loaded", "device", "gpu_name", "frame_count", "capabilities"} <= set(d)
+    assert d["capabilities"] == {"face_detection": True, "frame_forensics": True, "temporal_tracking": True}
+    assert r.headers["Access-Control-Allow-Origin"] == "*"
+    r = client.get("/stats")
+    assert r.status_code == 200
+    s = r.get_json()
+    assert {"frame_count", "temporal_average", "stability_score", "confidence_level", "history_length", "voting", "device"} <= set(s)
+    assert set(s["voting"]) == {"fake_count", "real_count", "total_frames"}
+    r = client.post("/reset")
+    assert r.status_code == 200 and r.get_json()["success"] is True
+
+
+def test_analyze_rejects_missing_and_garbage(client, pkg):
+    assert client.post("/analyze").status_code == 400                       # no 'frame' field
+    pkg.backend_server._last_request_time = 0.0
+    r = _post(client, b"not_an_image")
+    assert r.status_code == 400 and "error" in r.get_json()                 # garbage bytes -> 400, not 500
+    pkg.backend_server._last_request_time = 0.0
+    assert _post(client, b"").status_code in (400, 500)
+
+
+def test_rate_limiter_429(client):
+    first = _post(client, b"junk")
+    second = _post(client, b"junk")                                         # < 100 ms later
+    assert first.status_code == 400 and second.status_code == 429
+    body = second.get_json()
+    assert body["error"] == "Rate limited" and 0 <= body["retry_after_ms"] <= 100
+    time.sleep(0.12)
+    assert _post(client, b"junk").status_code == 400                        # spaced request passes the limiter
+
+
+def test_decode_image_formats(pkg):
+    f = F.face_frame(96, 64, 1)
+    for fmt in ("PNG", "BMP"):
+        out = pkg.backend_server.decode_image(_encode(f, fmt))
+        assert out.shape == f.shape and np.array_equal(out, f)              # lossless formats round-trip to BGR
+    j = pkg.backend_server.decode_image(_encode(f, "JPEG", quality=85))
+    assert j.shape == f.shape and j.dtype == np.uint8
+    assert pkg.backend_server.decode_image(b"nope") is None
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,name,kw", [("JPEG", "frame.png", {"quality": 85}), ("PNG", "frame.png", {}), ("BMP", "f.bmp", {})])
+def test_analyze_round_trip(client, pkg, b0_handle, fmt, name, kw):
+    pkg.runtime.set_default_handle(b0_handle)
+    client.post("/reset")
+    frame = F.natural_like(480, 640, 21) if fmt != "BMP" else F.blank_frame()
+    pkg.backend_server._last_request_time = 0.0
+    r = _post(client, _encode(frame, fmt, **kw), name)
+    assert r.status_code == 200, r.get_data()
+    b = r.get_json()
+    base = {"success", "analysis_mode", "faces_detected", "fake_probability", "frame_forensic_probability",
+            "real_probability", "confidence_level", "temporal_average", "stability_score", "frame_count",
+            "processing_time_ms"}
+    assert base <= set(b) and b["success"] is True and 0.0 <= b["fake_probability"] <= 1.0
+    assert b["analysis_mode"] in ("face+frame", "frame_only") and b["confidence_level"] == "UNCERTAIN"
+    if b["analysis_mode"] == "face+frame":
+        assert {"face_probability", "face_bbox"} <= set(b) and set(b["face_bbox"]) == {"x", "y", "width", "height"}
+    assert b["frame_count"] == 1
+    assert client.get("/stats").get_json()["history_length"] == 1
+    client.post("/reset")
+    assert client.get("/stats").get_json()["frame_count"] == 0
