@@ -167,6 +167,19 @@ int dfd_analyze_frame(dfd_handle* h, int stream_id, const uint8_t* bgr, int heig
                       double* scores_out, double* forensic_prob_out, int32_t* xywh_out,
                       int* n_faces_out, float* logits_out);
 
+/* ---- many frames, resident in HBM (throughput path; BASELINE.json configs[2]/[3]) ----------
+ * frames_dev: n packed 8-bit BGR frames of height x width on the handle's device (row stride
+ * width*3).  Runs the detector on all frames in one launch set; then, per frame, classifies
+ * either the detected boxes (forced_xywh == NULL, at most max_faces) or the caller's forced_k
+ * boxes per frame (forced_xywh: n*forced_k quadruples - used by the benchmark so that the crop
+ * workload does not depend on what a random-weight detector fires on).  with_forensics != 0 also
+ * computes the stateless six-signal probability of every frame.
+ *   xywh_out [n][max_faces][4], n_faces_out [n], logits_out [n][max_faces], forensic_prob_out [n]. */
+int dfd_analyze_batch_device(dfd_handle* h, const uint8_t* frames_dev, int n, int height, int width,
+                             const int32_t* forced_xywh, int forced_k, float conf_thr, int max_faces,
+                             int apply_clahe, int with_forensics, int32_t* xywh_out, int* n_faces_out,
+                             float* logits_out, double* forensic_prob_out);
+
 #ifdef __cplusplus
 }
 #endif

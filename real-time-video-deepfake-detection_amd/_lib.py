@@ -58,6 +58,9 @@ SIGNATURES = {
                               C.c_size_t, C.POINTER(C.c_size_t)]),
     "dfd_analyze_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
+    "dfd_analyze_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                           C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
     "dfd_forensics": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "dfd_forensics_reset": (C.c_int, [C.c_void_p, C.c_int]),
@@ -311,6 +314,27 @@ class Handle:
                                                 _ptr(logits)))
         scores = {k: float(v) for k, v in zip(self.FORENSIC_KEYS, sc) if not np.isnan(v)}
         return scores, float(prob.value), [tuple(int(v) for v in boxes[i]) for i in range(n.value)], logits[: n.value].copy()
+
+    def analyze_batch_device(self, frames_dev: int, n: int, height: int, width: int, forced_boxes=None,
+                             confidence_threshold: float = 0.5, max_faces: int = 4, apply_clahe: bool = True,
+                             with_forensics: bool = False):
+        """n frames resident in HBM -> (boxes per frame, logits per frame, forensic probabilities or None)."""
+        forced = None
+        forced_k = 0
+        if forced_boxes is not None:
+            forced = np.ascontiguousarray(np.asarray(forced_boxes, np.int32).reshape(n, -1, 4))
+            forced_k = forced.shape[1]
+        xy = np.zeros((n, max_faces, 4), np.int32)
+        nf = np.zeros(n, np.int32)
+        lg = np.zeros((n, max_faces), np.float32)
+        fp = np.zeros(n, np.float64)
+        self._check(self._lib.dfd_analyze_batch_device(
+            self._p, frames_dev, int(n), int(height), int(width), _ptr(forced) if forced is not None else None, forced_k,
+            float(confidence_threshold), int(max_faces), int(bool(apply_clahe)), int(bool(with_forensics)),
+            _ptr(xy), _ptr(nf), _ptr(lg), _ptr(fp)))
+        boxes = [[tuple(int(v) for v in xy[f, i]) for i in range(nf[f])] for f in range(n)]
+        logits = [lg[f, : nf[f]].copy() for f in range(n)]
+        return boxes, logits, (fp if with_forensics else None)
 
     def ssd_tap(self, frame, name: str, capacity: int) -> np.ndarray:
         a = self._as_bgr(frame)

@@ -115,8 +115,15 @@ int forensics_run(dfd_handle* h, int stream_id, const uint8_t* frame_dev, int hh
                   double* scores_out, double* prob_out, double* stats_out);
 int detect_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, float conf_thr, int32_t* xywh_out,
                float* conf_out, int max_out, int* n_out);
+// frame_offs: per-crop byte offset of its frame inside frame_dev (null = single frame)
 int preprocess_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, const int32_t* xywh, int n,
-                   int apply_clahe);
+                   int apply_clahe, const size_t* frame_offs = nullptr);
+// DetectionOutput of `n` frames already resized to 300x300 -> rows/count on the host
+int detect_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes,
+                     float conf_thr, int max_faces, int32_t* xywh_out, int* n_out);
+// stateless six-signal forensic probability of `n` device frames (temporal signal = first-frame value 0)
+int forensics_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes,
+                        double* prob_out, double* scores_out);
 
 // b0_plan.cpp
 int b0_build_plan(dfd_handle* h);

@@ -74,42 +74,11 @@ double pop_std(const double* v, int n, double* mean_out) {
 
 double clip01(double v) { return v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }
 
-}  // namespace
-
-namespace dfd {
-
-// the analyzer on a frame that is already in HBM (shared by dfd_forensics and dfd_analyze_frame)
-int forensics_run(dfd_handle* h, int stream_id, const uint8_t* frame_dev, int hh, int ww, int stride, int full,
-                  double* scores_out, double* prob_out, double* stats_out) {
-    if (!h->has_color) return fail(h, DFD_ERR_STATE, "forensics needs the colour tables (blob packed without luts)");
-    int rc = state_init(h, 1);
-    if (rc) return rc;
-    ForensicState& F = *h->forensic;
-    ForensicStream& S = F.streams[stream_id];
-    if (!S.prev_gray) {
-        DFD_HIP_TRY(h, hipMalloc(&S.prev_gray, 65536));
-        h->owned.push_back(S.prev_gray);
-    }
-    S.frame_count += 1;                                              // frame_analysis.py:68,110
-
-    launch_resize_bgr(frame_dev, 1, hh, ww, stride, 0, F.buf.rs, 256, 256, h->stream);
-    launch_forensics(F.buf, 1, full != 0, h->color, F.twiddle, h->stream);
-    double mean_diff = -1.0;
-    if (S.has_prev) launch_absdiff(F.buf.gray, (const uint8_t*)S.prev_gray, F.diff_part, h->stream);
-    double st[FORENSIC_STATS], noise[64], ela[64], dpart[256];
-    DFD_HIP_TRY(h, hipMemcpyAsync(st, F.buf.stats, sizeof st, hipMemcpyDeviceToHost, h->stream));
-    if (full) {
-        DFD_HIP_TRY(h, hipMemcpyAsync(noise, F.buf.stats_noise, sizeof noise, hipMemcpyDeviceToHost, h->stream));
-        DFD_HIP_TRY(h, hipMemcpyAsync(ela, F.buf.stats_ela, sizeof ela, hipMemcpyDeviceToHost, h->stream));
-    }
-    if (S.has_prev) DFD_HIP_TRY(h, hipMemcpyAsync(dpart, F.diff_part, sizeof dpart, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipMemcpyAsync(S.prev_gray, F.buf.gray, 65536, hipMemcpyDeviceToDevice, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
-    DFD_HIP_TRY(h, hipGetLastError());
-
+// the five stateless signals from the device statistics (frame_analysis.py:150-347); sc[5] (temporal) = 0
+void static_scores(const double* st, const double* noise, const double* ela, bool full, double* sc, double* ex) {
     const double nan = std::nan("");
-    double sc[6] = {0, nan, nan, 0, nan, 0};      // frequency, noise, ela, edge, color, temporal
-    // ---- frequency (frame_analysis.py:150-180)
+    sc[0] = 0; sc[1] = nan; sc[2] = nan; sc[3] = 0; sc[4] = nan; sc[5] = 0;
+    // ---- frequency (:150-180)
     const double lo = st[ST_FREQ_LOW], mi = st[ST_FREQ_MID], hi = st[ST_FREQ_HIGH];
     const double total = lo + mi + hi + 1e-10, hr = hi / total, mr = mi / total;
     const double mid_cv = st[ST_FREQ_MID_STD] / (mi + 1e-10);
@@ -145,6 +114,50 @@ int forensics_run(dfd_handle* h, int stream_id, const uint8_t* frame_dev, int hh
         if (st[ST_HUES] < 30) s += 0.25; else if (st[ST_HUES] < 50) s += 0.1;
         sc[4] = clip01(s);
     }
+    const double e[10] = {lo, mi, hi, hr, mr, mid_cv, noise_mean, noise_cv, ela_mean, ela_cv};
+    for (int i = 0; i < 10; ++i) ex[i] = e[i];
+}
+
+}  // namespace
+
+namespace dfd {
+
+// the analyzer on a frame that is already in HBM (shared by dfd_forensics and dfd_analyze_frame)
+int forensics_run(dfd_handle* h, int stream_id, const uint8_t* frame_dev, int hh, int ww, int stride, int full,
+                  double* scores_out, double* prob_out, double* stats_out) {
+    if (!h->has_color) return fail(h, DFD_ERR_STATE, "forensics needs the colour tables (blob packed without luts)");
+    int rc = state_init(h, 1);
+    if (rc) return rc;
+    ForensicState& F = *h->forensic;
+    ForensicStream& S = F.streams[stream_id];
+    if (!S.prev_gray) {
+        DFD_HIP_TRY(h, hipMalloc(&S.prev_gray, 65536));
+        h->owned.push_back(S.prev_gray);
+    }
+    S.frame_count += 1;                                              // frame_analysis.py:68,110
+
+    launch_resize_bgr(frame_dev, 1, hh, ww, stride, 0, F.buf.rs, 256, 256, h->stream);
+    launch_forensics(F.buf, 1, full != 0, h->color, F.twiddle, h->stream);
+    double mean_diff = -1.0;
+    if (S.has_prev) launch_absdiff(F.buf.gray, (const uint8_t*)S.prev_gray, F.diff_part, h->stream);
+    double st[FORENSIC_STATS], noise[64], ela[64], dpart[256];
+    DFD_HIP_TRY(h, hipMemcpyAsync(st, F.buf.stats, sizeof st, hipMemcpyDeviceToHost, h->stream));
+    if (full) {
+        DFD_HIP_TRY(h, hipMemcpyAsync(noise, F.buf.stats_noise, sizeof noise, hipMemcpyDeviceToHost, h->stream));
+        DFD_HIP_TRY(h, hipMemcpyAsync(ela, F.buf.stats_ela, sizeof ela, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (S.has_prev) DFD_HIP_TRY(h, hipMemcpyAsync(dpart, F.diff_part, sizeof dpart, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipMemcpyAsync(S.prev_gray, F.buf.gray, 65536, hipMemcpyDeviceToDevice, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, hipGetLastError());
+
+    const double nan = std::nan("");
+    double sc[6], ex[10];
+    static_scores(st, noise, ela, full != 0, sc, ex);
+    const double lo = ex[0], mi = ex[1], hi = ex[2], hr = ex[3], mr = ex[4], mid_cv = ex[5];
+    const double noise_mean = ex[6], noise_cv = ex[7], ela_mean = ex[8], ela_cv = ex[9];
+    const double density = st[ST_EDGE_COUNT] / 65536.0, lap_var = st[ST_LAP_VAR];
+    double s = 0.0;
     // ---- temporal (:358-389)
     double temporal_cv = nan;
     if (!S.has_prev) {
@@ -183,6 +196,35 @@ int forensics_run(dfd_handle* h, int stream_id, const uint8_t* frame_dev, int hh
                                                  density, lap_var, full ? st[ST_SAT_STD] : nan, full ? st[ST_VAL_STD] : nan,
                                                  full ? st[ST_HUES] : nan, mean_diff, temporal_cv, (double)S.frame_count};
         for (int i = 0; i < DFD_FORENSIC_NSTATS; ++i) stats_out[i] = out[i];
+    }
+    return DFD_OK;
+}
+
+// Stateless batch variant for throughput runs: n device frames -> six-signal probability each, the
+// temporal signal taking its first-frame value 0 (frame_analysis.py:358-360).  One launch set for all frames.
+int forensics_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes,
+                        double* prob_out, double* scores_out) {
+    if (!h->has_color) return fail(h, DFD_ERR_STATE, "forensics needs the colour tables (blob packed without luts)");
+    int rc = state_init(h, n);
+    if (rc) return rc;
+    ForensicState& F = *h->forensic;
+    launch_resize_bgr(frames_dev, n, hh, ww, stride, frame_bytes, F.buf.rs, 256, 256, h->stream);
+    launch_forensics(F.buf, n, true, h->color, F.twiddle, h->stream);
+    std::vector<double> st((size_t)n * FORENSIC_STATS), noise((size_t)n * 64), ela((size_t)n * 64);
+    DFD_HIP_TRY(h, hipMemcpyAsync(st.data(), F.buf.stats, st.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipMemcpyAsync(noise.data(), F.buf.stats_noise, noise.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipMemcpyAsync(ela.data(), F.buf.stats_ela, ela.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, hipGetLastError());
+    const double w[6] = {0.25, 0.20, 0.20, 0.15, 0.10, 0.10};
+    for (int f = 0; f < n; ++f) {
+        double sc[6], ex[10];
+        static_scores(&st[(size_t)f * FORENSIC_STATS], &noise[(size_t)f * 64], &ela[(size_t)f * 64], true, sc, ex);
+        double comb = 0.0;
+        for (int i = 0; i < 6; ++i) comb += sc[i] * w[i];
+        prob_out[f] = clip01(comb);
+        if (scores_out)
+            for (int i = 0; i < 6; ++i) scores_out[(size_t)f * 6 + i] = sc[i];
     }
     return DFD_OK;
 }

@@ -76,7 +76,8 @@ int upload_frame(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride) 
 }
 
 // validates the boxes, lays the packed crops out in the scratch buffers, uploads descriptors
-int stage_crops(dfd_handle* h, int hh, int ww, const int32_t* xywh, int n, size_t* total, int* max_pixels) {
+int stage_crops(dfd_handle* h, int hh, int ww, const int32_t* xywh, int n, size_t* total, int* max_pixels,
+                const size_t* frame_offs = nullptr) {
     if (!xywh || n <= 0) return fail(h, DFD_ERR_ARG, "crops: null boxes or n <= 0");
     if (n > h->max_batch) return fail(h, DFD_ERR_CAPACITY, "crops: %d boxes exceed handle capacity %d", n, h->max_batch);
     std::vector<CropDesc> d(n);
@@ -86,7 +87,7 @@ int stage_crops(dfd_handle* h, int hh, int ww, const int32_t* xywh, int n, size_
         const int x = xywh[4 * i], y = xywh[4 * i + 1], w = xywh[4 * i + 2], hgt = xywh[4 * i + 3];
         if (w <= 0 || hgt <= 0 || x < 0 || y < 0 || x + w > ww || y + hgt > hh)
             return fail(h, DFD_ERR_ARG, "crops: box %d (%d,%d,%d,%d) outside the %dx%d frame", i, x, y, w, hgt, ww, hh);
-        d[i] = CropDesc{x, y, w, hgt, off};
+        d[i] = CropDesc{x, y, w, hgt, off, frame_offs ? frame_offs[i] : 0};
         off += ((size_t)w * hgt * 3 + 255) & ~(size_t)255;
         if (w * hgt > mp) mp = w * hgt;
     }
@@ -101,10 +102,10 @@ int stage_crops(dfd_handle* h, int hh, int ww, const int32_t* xywh, int n, size_
 
 // frame already on the device -> normalised NCHW crops in h->in_nchw
 int preprocess_on_device(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride,
-                         const int32_t* xywh, int n, int apply_clahe) {
+                         const int32_t* xywh, int n, int apply_clahe, const size_t* frame_offs = nullptr) {
     size_t total = 0;
     int mp = 0, rc;
-    if ((rc = stage_crops(h, hh, ww, xywh, n, &total, &mp))) return rc;
+    if ((rc = stage_crops(h, hh, ww, xywh, n, &total, &mp, frame_offs))) return rc;
     const CropDesc* dd = static_cast<const CropDesc*>(h->desc_buf.p);
     if (apply_clahe) {
         if (!h->has_color) return fail(h, DFD_ERR_STATE, "CLAHE needs the colour tables (blob packed without luts)");
@@ -123,8 +124,8 @@ int preprocess_on_device(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww
 
 namespace dfd {
 int preprocess_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, const int32_t* xywh, int n,
-                   int apply_clahe) {
-    return preprocess_on_device(h, frame_dev, hh, ww, stride, xywh, n, apply_clahe);
+                   int apply_clahe, const size_t* frame_offs) {
+    return preprocess_on_device(h, frame_dev, hh, ww, stride, xywh, n, apply_clahe, frame_offs);
 }
 }  // namespace dfd
 

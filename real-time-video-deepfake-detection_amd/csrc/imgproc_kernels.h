@@ -15,6 +15,7 @@ struct ColorTables {
 struct CropDesc {
     int x, y, w, h;        // box in the frame
     size_t offset;         // byte offset of this crop's packed w*h*3 region in the scratch buffers
+    size_t src_off;        // byte offset of the crop's frame inside the frame buffer (batched frames)
 };
 
 void launch_resize_bgr(const uint8_t* src, int n, int sh, int sw, size_t sstride, size_t simg,

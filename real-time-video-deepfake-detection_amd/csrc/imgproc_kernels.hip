@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void clahe_hist_kernel(const uint8_t* __restri
     for (int i = tid; i < tw * th; i += 256) {
         const int ex = tx * tw + i % tw, ey = ty * th + i / tw;
         const int sx = reflect101(ex, cd.w), sy = reflect101(ey, cd.h);
-        const uint8_t* p = frame + (size_t)(cd.y + sy) * fstride + (size_t)(cd.x + sx) * 3;
+        const uint8_t* p = frame + cd.src_off + (size_t)(cd.y + sy) * fstride + (size_t)(cd.x + sx) * 3;
         int L, A, B;
         bgr2lab(T, p[0], p[1], p[2], L, A, B);
         atomicAdd(&hist[L], 1);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void crop_norm_kernel(const uint8_t* __restric
         p00 = b + ((size_t)y0 * cd.w + x0) * 3; p01 = b + ((size_t)y0 * cd.w + x1) * 3;
         p10 = b + ((size_t)y1 * cd.w + x0) * 3; p11 = b + ((size_t)y1 * cd.w + x1) * 3;
     } else {
-        const uint8_t* b = frame + (size_t)cd.y * fstride + (size_t)cd.x * 3;
+        const uint8_t* b = frame + cd.src_off + (size_t)cd.y * fstride + (size_t)cd.x * 3;
         p00 = b + (size_t)y0 * fstride + x0 * 3; p01 = b + (size_t)y0 * fstride + x1 * 3;
         p10 = b + (size_t)y1 * fstride + x0 * 3; p11 = b + (size_t)y1 * fstride + x1 * 3;
     }

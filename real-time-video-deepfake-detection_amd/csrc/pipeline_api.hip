@@ -1,0 +1,65 @@
+// Batched, device-resident end-to-end path (BASELINE.json configs[2]/[3]): n frames already in
+// HBM -> detector (one launch set for all frames) -> crops -> CLAHE -> 224x224 -> classifier,
+// optionally with the six forensic signals.  The per-frame semantics are those of
+// dfd_analyze_frame; this entry point exists for throughput (no per-frame host round trips
+// except the small DetectionOutput read-back that sizes the crop batch).
+#include "b0_kernels.h"
+#include "dfd_common.h"
+
+using namespace dfd;
+
+extern "C" {
+
+int dfd_analyze_batch_device(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, const int32_t* forced_xywh,
+                             int forced_k, float conf_thr, int max_faces, int apply_clahe, int with_forensics,
+                             int32_t* xywh_out, int* n_faces_out, float* logits_out, double* forensic_prob_out) {
+    if (!h) return DFD_ERR_ARG;
+    if (!frames_dev || n <= 0 || hh <= 0 || ww <= 0 || max_faces <= 0 || !xywh_out || !n_faces_out || !logits_out)
+        return fail(h, DFD_ERR_ARG, "analyze_batch: bad pointer or geometry");
+    if (forced_xywh && (forced_k <= 0 || forced_k > max_faces))
+        return fail(h, DFD_ERR_ARG, "analyze_batch: forced_k must be in 1..max_faces");
+    if (with_forensics && !forensic_prob_out) return fail(h, DFD_ERR_ARG, "analyze_batch: forensic_prob_out is null");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    const int stride = ww * 3;
+    const size_t frame_bytes = (size_t)hh * stride;
+    int rc;
+    if (with_forensics && (rc = forensics_batch_run(h, frames_dev, n, hh, ww, stride, frame_bytes, forensic_prob_out, nullptr)))
+        return rc;
+    // detector on every frame (its boxes are used unless the caller forces boxes)
+    std::vector<int32_t> det((size_t)n * max_faces * 4);
+    std::vector<int> ndet(n);
+    if ((rc = detect_batch_run(h, frames_dev, n, hh, ww, stride, frame_bytes, conf_thr, max_faces, det.data(), ndet.data())))
+        return rc;
+    // crop list across frames
+    std::vector<int32_t> boxes;
+    std::vector<size_t> offs;
+    for (int f = 0; f < n; ++f) {
+        const int k = forced_xywh ? forced_k : ndet[f];
+        const int32_t* src = forced_xywh ? forced_xywh + (size_t)f * forced_k * 4 : det.data() + (size_t)f * max_faces * 4;
+        n_faces_out[f] = k;
+        for (int i = 0; i < k; ++i) {
+            for (int c = 0; c < 4; ++c) {
+                boxes.push_back(src[4 * i + c]);
+                xywh_out[((size_t)f * max_faces + i) * 4 + c] = src[4 * i + c];
+            }
+            offs.push_back((size_t)f * frame_bytes);
+        }
+    }
+    // classify in chunks of the handle's batch capacity
+    const int total = (int)offs.size();
+    std::vector<float> logits(total);
+    for (int start = 0; start < total; start += h->max_batch) {
+        const int m = std::min(h->max_batch, total - start);
+        if ((rc = preprocess_run(h, frames_dev, hh, ww, stride, boxes.data() + (size_t)start * 4, m, apply_clahe, offs.data() + start)))
+            return rc;
+        if ((rc = b0_forward(h, h->in_nchw, m, h->logits, nullptr, nullptr))) return rc;
+        DFD_HIP_TRY(h, hipMemcpyAsync(logits.data() + start, h->logits, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
+        DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    int k = 0;
+    for (int f = 0; f < n; ++f)
+        for (int i = 0; i < n_faces_out[f]; ++i) logits_out[(size_t)f * max_faces + i] = logits[k++];
+    return DFD_OK;
+}
+
+}  // extern "C"

@@ -304,6 +304,27 @@ int detect_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stri
     return DFD_OK;
 }
 
+// the same for n frames resident in HBM (frame f at frames_dev + f * frame_bytes): one launch set
+int detect_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes,
+                     float conf_thr, int max_faces, int32_t* xywh_out, int* n_out) {
+    for (int f = 0; f < n; ++f) n_out[f] = 0;
+    if (hh < 30 || ww < 30) return DFD_OK;
+    if (!h->ssd || !h->ssd->ready) return fail(h, DFD_ERR_STATE, "detector weights were not packed into the blob (weights.pack_all)");
+    int rc;
+    if ((rc = ensure(h, &h->ssd->in_u8, (size_t)n * SSD_IN * SSD_IN * 3))) return rc;
+    launch_resize_bgr(frames_dev, n, hh, ww, stride, frame_bytes, (uint8_t*)h->ssd->in_u8.p, SSD_IN, SSD_IN, h->stream);
+    if ((rc = ssd_forward(h, (const uint8_t*)h->ssd->in_u8.p, n, nullptr, nullptr, 0, nullptr))) return rc;
+    std::vector<float> rows((size_t)n * SSD_KEEP * 5);
+    std::vector<int> cnt(n);
+    DFD_HIP_TRY(h, hipMemcpyAsync(cnt.data(), h->ssd->count.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipMemcpyAsync(rows.data(), h->ssd->rows.p, rows.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (int f = 0; f < n; ++f)
+        n_out[f] = ssd_postprocess(rows.data() + (size_t)f * SSD_KEEP * 5, cnt[f], hh, ww, conf_thr,
+                                   xywh_out + (size_t)f * max_faces * 4, nullptr, max_faces);
+    return DFD_OK;
+}
+
 }  // namespace dfd
 
 extern "C" {
