@@ -67,6 +67,42 @@ def cpu_baseline(sd_np, sample_crops=32, chunk=16):
             "batch1_crops_per_s": round(1.0 / dt1, 2)}
 
 
+def e2e_frames(h, rank, dist, local_rank, frames_per_step=16, steps=10, warmup=2):
+    """BASELINE.json configs[2]/[3] as an extra: 1080p synthetic frames resident in HBM ->
+    SSD detect (every frame) + 4 forced >=224x224 boxes per frame -> CLAHE -> 224x224 -> B0, without and
+    with the six forensic signals.  Frames: np.random.default_rng(7 + rank).integers(50, 200)."""
+    import torch
+
+    H, W, K = 1080, 1920, 4
+    rng = np.random.default_rng(7 + rank)
+    frames = rng.integers(50, 200, (frames_per_step, H, W, 3), dtype=np.uint8)
+    fd = h.alloc(frames.nbytes).upload(frames)
+    boxes = [[(200, 150, 320, 400), (900, 300, 256, 256), (1400, 500, 400, 480), (600, 700, 224, 224)]] * frames_per_step
+    res = {"workload": f"{frames_per_step} x 1080p frames/step, SSD detect + {K} forced boxes/frame -> CLAHE -> 224 -> B0 fp32",
+           "frames_per_step": frames_per_step}
+    for key, forensic in (("detect_classify", False), ("detect_classify_forensics", True)):
+        for _ in range(warmup):
+            h.analyze_batch_device(fd.ptr, frames_per_step, H, W, forced_boxes=boxes, max_faces=K, with_forensics=forensic)
+        h.sync()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            h.analyze_batch_device(fd.ptr, frames_per_step, H, W, forced_boxes=boxes, max_faces=K, with_forensics=forensic)
+        h.sync()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        world = 1 if dist is None else dist.get_world_size()
+        res[key] = {"frames_per_s": round(frames_per_step * steps * world / dt, 1),
+                    "crops_per_s": round(frames_per_step * K * steps * world / dt, 1),
+                    "ms_per_frame": round(dt / (frames_per_step * steps) * 1e3, 3)}
+    fd.free()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +111,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the 1080p end-to-end extra (configs[2]/[3])")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,7 +136,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     sd = rtdfd_amd.weights.seeded_state_dict(0)
-    h = rtdfd_amd._lib.Handle(rtdfd_amd.weights.pack_b0(sd), device=local_rank, max_batch=args.batch)
+    blob = rtdfd_amd.weights.pack_all(sd, rtdfd_amd.weights.seeded_ssd_state_dict(0))
+    h = rtdfd_amd._lib.Handle(blob, device=local_rank, max_batch=args.batch)
 
     # synthetic crops of configs[1]: torch.manual_seed(1); randn(256,3,224,224) (seed + rank on other ranks)
     g = torch.Generator().manual_seed(1 + rank)
@@ -164,6 +202,8 @@ def main():
                      "share_of_step": round(dw_ms / all_ms, 4) if all_ms else None},
         "kernel_ms_per_step": round(all_ms, 3),
     }
+    if not args.no_e2e:
+        out["e2e"] = e2e_frames(h, rank, dist, local_rank)
     if rank == 0:
         if args.layers:
             agg = {}
