@@ -55,6 +55,10 @@ int dfd_create(int device, const void* blob, size_t blob_len, int max_batch, dfd
 void dfd_destroy(dfd_handle* h);
 const char* dfd_last_error(const dfd_handle* h);
 int dfd_max_batch(const dfd_handle* h);
+/* Tuning switches (results stay within the parity tolerances either way):
+ *   "fuse_expand" (default 1, env DFD_FUSE_EXPAND): MBConv blocks 1-5 compute the 1x1 expand conv
+ *   inside the depthwise kernel instead of writing the expanded tensor to HBM. */
+int dfd_set_option(dfd_handle* h, const char* name, int value);
 
 /* ---- device memory and stream plumbing (no reference counterpart) -------------- */
 int dfd_device_alloc(dfd_handle* h, size_t bytes, void** dptr);

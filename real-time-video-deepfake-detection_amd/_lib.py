@@ -33,6 +33,7 @@ SIGNATURES = {
     "dfd_destroy": (None, [C.c_void_p]),
     "dfd_last_error": (C.c_char_p, [C.c_void_p]),
     "dfd_max_batch": (C.c_int, [C.c_void_p]),
+    "dfd_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "dfd_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "dfd_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dfd_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -158,6 +159,9 @@ class Handle:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name: str, value: int):
+        self._check(self._lib.dfd_set_option(self._p, name.encode(), int(value)))
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)

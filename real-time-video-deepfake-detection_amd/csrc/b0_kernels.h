@@ -34,6 +34,12 @@ bool launch_depthwise(const float* X, const float* W /*[k][k][C]*/, const float*
                       float* P, int n, int H, int C, int k, int stride, int pad_lo,
                       int* tiles, hipStream_t s);
 int depthwise_tiles(int H, int C, int k, int stride);
+// MBConv front half in one kernel: 1x1 expand (+BN+swish) computed per LDS halo tile with MFMA, then the
+// depthwise conv as above.  Xin: block input [n][H][H][Cin]; We [C][Cin], be [C].  Returns false when no
+// instantiation covers the shape (callers then run launch_pointwise + launch_depthwise).
+bool launch_mbconv_front(const float* Xin, int Cin, const float* We, const float* be, const float* Wd,
+                         const float* bd, float* Y, float* P, int n, int H, int C, int k, int stride,
+                         int pad_lo, int* tiles, hipStream_t s);
 
 // squeeze-excite gate: mean over tiles*pixels -> FC(c_se)+swish -> FC(C)+sigmoid.
 void launch_se(const float* P, int tiles, float inv_hw, const float* w1, const float* b1,

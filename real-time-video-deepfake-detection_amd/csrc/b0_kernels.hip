@@ -19,7 +19,11 @@ namespace dfd {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float swish1(float x) { return __fdividef(x, 1.0f + __expf(-x)); }
+// swish(x) = x * sigmoid(x) as mul + v_exp_f32 + add + v_rcp_f32 + mul.  (`__fdividef` / `/` expand to the full
+// IEEE division sequence here - ~10 VALU instructions per element, which made the fused kernels VALU-bound.)
+// v_rcp_f32 and v_exp_f32 are accurate to 1 ulp; the 1e-3 logit bar holds with three orders of margin.
+__device__ __forceinline__ float sigmoid1(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float swish1(float x) { return x * sigmoid1(x); }
 __device__ __forceinline__ v4f swish4(v4f v) {
     v4f r;
     r.x = swish1(v.x); r.y = swish1(v.y); r.z = swish1(v.z); r.w = swish1(v.w);
@@ -207,13 +211,13 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ X,
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const v4f wf = *reinterpret_cast<const v4f*>(&wb[(nt * 16 + j) * BKP + cc * 16 + 4 * q]);
+                // the two pixel tiles alternate, so a dependent accumulate is two issues (64 cycles) behind
+                // its producer: v_mfma_f32_16x16x4_f32 issues every 32 cycles but has 40 cycles of latency
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.x, xcur[mt][cc].x, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.y, xcur[mt][cc].y, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.z, xcur[mt][cc].z, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf.w, xcur[mt][cc].w, acc[mt][nt], 0, 0, 0);
-                }
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[e], xcur[mt][cc][e], acc[mt][nt], 0, 0, 0);
             }
         }
         if (more) {
@@ -324,45 +328,27 @@ bool launch_conv_gemm(const float* X, const float* W, const float* bias, const f
 // the image: TF-SAME padding), weights too.  Thread = (channel quad, strip of RP outputs
 // along W); per kernel row it pulls the (RP-1)S+K input vectors of the strip into
 // registers once and reuses them across the K taps.
+template <int K, int S, int CB, int TH, int TW>
+struct DwShape {
+    static constexpr int CG = CB / 4;
+    static constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+};
+
+// depthwise conv of the LDS tile + folded BN + swish + store + per-tile SE partial sums.
+// Ends with a barrier-protected write of P; callers that reuse tile/wl/red afterwards must
+// __syncthreads() first.
 template <int K, int S, int CB, int TH, int TW, int RP>
-__global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X,
-                                                 const float* __restrict__ Wt,
-                                                 const float* __restrict__ bias,
-                                                 float* __restrict__ Y, float* __restrict__ P,
-                                                 int H, int Ho, int C, int pad_lo, int tiles_x,
-                                                 int tiles_sp) {
+__device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* red,
+                                           const v4f bv, float* __restrict__ Y,
+                                           float* __restrict__ P, int n, int Ho, int C, int c0, int ty0,
+                                           int tx0, int t, int tiles_sp) {
     constexpr int CG = CB / 4;
-    constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+    constexpr int IW = (TW - 1) * S + K;
     constexpr int SX = TW / RP, NSTRIP = TH * SX, NSLOT = 256 / CG;
     constexpr int NIN = (RP - 1) * S + K;
     static_assert(TW % RP == 0 && (CG & (CG - 1)) == 0 && CG <= 64, "tile shape");
-    __shared__ v4f tile[IH * IW * CG];
-    __shared__ v4f wl[K * K * CG];
-    __shared__ v4f red[4 * CG];
-
     const int tid = threadIdx.x;
-    const int n = blockIdx.y;
-    const int t = blockIdx.x % tiles_sp, chunk = blockIdx.x / tiles_sp;
-    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW, c0 = chunk * CB;
-
-    for (int i = tid; i < K * K * CG; i += 256)
-        wl[i] = ldg4(Wt + (size_t)(i / CG) * C + c0 + 4 * (i % CG));
-
-    const float* xb = X + (size_t)n * H * H * C + c0;
-    const int iy0 = ty0 * S - pad_lo, ix0 = tx0 * S - pad_lo;
-#pragma unroll 4
-    for (int i = tid; i < IH * IW * CG; i += 256) {
-        const int cg = i % CG, pix = i / CG;
-        const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
-        v4f v = (v4f){0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H)
-            v = ldg4(xb + ((size_t)iy * H + ix) * C + 4 * cg);
-        tile[i] = v;
-    }
-    __syncthreads();
-
     const int cg = tid % CG, slot = tid / CG;
-    const v4f bv = ldg4(bias + c0 + 4 * cg);
     v4f psum = (v4f){0.f, 0.f, 0.f, 0.f};
     float* yb = Y + (size_t)n * Ho * Ho * C + c0 + 4 * cg;
     for (int strip = slot; strip < NSTRIP; strip += NSLOT) {
@@ -418,7 +404,146 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X,
     }
 }
 
-struct DwCfg { int k, s, H, cb, th, tw; };
+template <int K, int S, int CB, int TH, int TW, int RP>
+__global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X,
+                                                 const float* __restrict__ Wt,
+                                                 const float* __restrict__ bias,
+                                                 float* __restrict__ Y, float* __restrict__ P,
+                                                 int H, int Ho, int C, int pad_lo, int tiles_x,
+                                                 int tiles_sp) {
+    using Sh = DwShape<K, S, CB, TH, TW>;
+    constexpr int CG = Sh::CG, IH = Sh::IH, IW = Sh::IW;
+    __shared__ v4f tile[IH * IW * CG];
+    __shared__ v4f wl[K * K * CG];
+    __shared__ v4f red[4 * CG];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.y;
+    const int t = blockIdx.x % tiles_sp, chunk = blockIdx.x / tiles_sp;
+    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW, c0 = chunk * CB;
+    const v4f bv = ldg4(bias + c0 + 4 * (tid % CG));      // issued with the tile loads, used after the barrier
+    for (int i = tid; i < K * K * CG; i += 256)
+        wl[i] = ldg4(Wt + (size_t)(i / CG) * C + c0 + 4 * (i % CG));
+    const int iy0 = ty0 * S - pad_lo, ix0 = tx0 * S - pad_lo;
+    const float* xb = X + (size_t)n * H * H * C + c0;
+#pragma unroll 4
+    for (int i = tid; i < IH * IW * CG; i += 256) {
+        const int cg = i % CG, pix = i / CG;
+        const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
+        v4f v = (v4f){0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H)
+            v = ldg4(xb + ((size_t)iy * H + ix) * C + 4 * cg);
+        tile[i] = v;
+    }
+    __syncthreads();
+    dw_compute<K, S, CB, TH, TW, RP>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
+}
+
+// MBConv front half in ONE kernel (blocks 1-5): X is the block INPUT [n][H][H][Cin]; for every
+// pixel of the halo tile the 1x1 expand conv (+ folded BN + swish) runs on
+// v_mfma_f32_16x16x4_f32 with pixels as MFMA columns, so a lane ends with the 4 consecutive
+// channels of one pixel = exactly one float4 slot of the LDS tile; pixels outside the image stay
+// zero (the padding applies to the expanded tensor).  The 6x-expanded activation never touches
+// HBM.  A block walks NSUB channel chunks of CB channels over the same spatial tile: the input
+// fragments of all its pixels are loaded ONCE, up front (one batch of loads in flight), and reused
+// for every chunk.  Price: the halo's expand FLOPs are recomputed (1.1-1.65x).
+template <int K, int S, int CB, int TH, int TW, int RP, int KC, int NSUB>
+__global__ __launch_bounds__(256) void mbconv_kernel(const float* __restrict__ X,
+                                                     const float* __restrict__ We,
+                                                     const float* __restrict__ be,
+                                                     const float* __restrict__ Wt,
+                                                     const float* __restrict__ bias,
+                                                     float* __restrict__ Y, float* __restrict__ P,
+                                                     int H, int Ho, int C, int Cin, int pad_lo,
+                                                     int tiles_x, int tiles_sp) {
+    using Sh = DwShape<K, S, CB, TH, TW>;
+    constexpr int CG = Sh::CG, IH = Sh::IH, IW = Sh::IW;
+    constexpr int NTB = CB / 16;                        // 16-channel MFMA row tiles per chunk
+    constexpr int NP = IH * IW, NMT = (NP + 15) / 16, NIT = (NMT + 3) / 4;
+    __shared__ v4f tile[IH * IW * CG];
+    __shared__ v4f wl[K * K * CG];
+    __shared__ v4f red[4 * CG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+    const int n = blockIdx.y;
+    const int t = blockIdx.x % tiles_sp, group = blockIdx.x / tiles_sp;
+    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
+    const int iy0 = ty0 * S - pad_lo, ix0 = tx0 * S - pad_lo;
+
+    // B operand for all of this wave's pixel tiles: lane (pixel j, k-quad q); loaded once
+    const float* xb = X + (size_t)n * H * H * Cin;
+    v4f xf[NIT][KC];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = (wave + 4 * it) * 16 + j;
+        const int iy = iy0 + p / IW, ix = ix0 + p % IW;
+        const bool inside = p < NP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
+        const float* px = xb + ((size_t)(inside ? iy : 0) * H + (inside ? ix : 0)) * Cin;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            const int k = kk * 16 + 4 * q;
+            const v4f v = ldg4(px + (k < Cin ? k : 0));          // unconditional load, masked value
+            xf[it][kk] = (inside && k < Cin) ? v : (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    // small per-chunk operands (depthwise weights, expand weights A operand, biases) are fetched one
+    // chunk AHEAD into registers, so their latency hides under the previous chunk's depthwise phase
+    constexpr int WLR = (K * K * CG + 255) / 256;
+    v4f wlr[WLR], wf[NTB][KC], bex[NTB], bv;
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int r = 0; r < WLR; ++r) {
+            const int i = tid + r * 256, ii = i < K * K * CG ? i : 0;
+            wlr[r] = ldg4(Wt + (size_t)(ii / CG) * C + c0 + 4 * (ii % CG));
+        }
+        bv = ldg4(bias + c0 + 4 * (tid % CG));
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt) {
+            bex[nt] = ldg4(be + c0 + nt * 16 + 4 * q);
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                const int k = kk * 16 + 4 * q;
+                const v4f v = ldg4(We + (size_t)(c0 + nt * 16 + j) * Cin + (k < Cin ? k : 0));
+                wf[nt][kk] = k < Cin ? v : (v4f){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    fetch(group * NSUB * CB);
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const int c0 = (group * NSUB + sub) * CB;
+        if (sub > 0) __syncthreads();                            // previous chunk done with tile/wl/red
+#pragma unroll
+        for (int r = 0; r < WLR; ++r)
+            if (tid + r * 256 < K * K * CG) wl[tid + r * 256] = wlr[r];
+        const v4f bv_cur = bv;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int mt = wave + 4 * it;
+            if (mt < NMT) {                                      // wave-uniform
+                v4f acc[NTB];
+#pragma unroll
+                for (int nt = 0; nt < NTB; ++nt) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int nt = 0; nt < NTB; ++nt)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][kk][e], xf[it][kk][e], acc[nt], 0, 0, 0);
+                const int p = mt * 16 + j;
+                const int iy = iy0 + p / IW, ix = ix0 + p % IW;
+                const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
+                if (p < NP) {
+#pragma unroll
+                    for (int nt = 0; nt < NTB; ++nt)
+                        tile[p * CG + nt * 4 + q] = inside ? swish4(acc[nt] + bex[nt]) : (v4f){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        if (sub + 1 < NSUB) fetch(c0 + CB);                      // in flight during dw_compute
+        __syncthreads();
+        dw_compute<K, S, CB, TH, TW, RP>(tile, wl, red, bv_cur, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
+    }
+}
 
 template <int K, int S, int CB, int TH, int TW, int RP>
 static void dw_launch(const float* X, const float* W, const float* b, float* Y, float* P, int n,
@@ -429,6 +554,17 @@ static void dw_launch(const float* X, const float* W, const float* b, float* Y, 
     *tiles = tiles_sp;
     hipLaunchKernelGGL((dw_kernel<K, S, CB, TH, TW, RP>), dim3(tiles_sp * (C / CB), n), dim3(256), 0,
                        s, X, W, b, Y, P, H, Ho, C, pad_lo, tx, tiles_sp);
+}
+
+template <int K, int S, int CB, int TH, int TW, int RP, int KC, int NSUB>
+static void mb_launch(const float* X, int Cin, const float* We, const float* be, const float* W, const float* b,
+                      float* Y, float* P, int n, int H, int C, int pad_lo, int* tiles, hipStream_t s) {
+    const int Ho = (H + S - 1) / S;
+    const int tx = (Ho + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
+    const int tiles_sp = tx * ty;
+    *tiles = tiles_sp;
+    hipLaunchKernelGGL((mbconv_kernel<K, S, CB, TH, TW, RP, KC, NSUB>), dim3(tiles_sp * (C / (CB * NSUB)), n),
+                       dim3(256), 0, s, X, We, be, W, b, Y, P, H, Ho, C, Cin, pad_lo, tx, tiles_sp);
 }
 
 // tile shapes per B0 depthwise layer class: (k, stride, H_in, C) -> <K,S,CB,TH,TW,RP>
@@ -455,6 +591,29 @@ bool launch_depthwise(const float* X, const float* W, const float* bias, float* 
     }
     DFD_DW_TABLE(DFD_DW_DISPATCH)
 #undef DFD_DW_DISPATCH
+    return false;
+}
+
+// expand (1x1 + BN + swish) fused into the depthwise kernel; only the five large-spatial MBConv
+// blocks (1..5) are instantiated: there the expanded tensor dominates HBM traffic and C_in <= 48.
+// (k, stride, H, C, Cin) -> <K,S,CB,TH,TW,RP, KC = ceil(Cin/16), NSUB = channel chunks per block>
+#define DFD_MB_TABLE(OP)                            \
+    OP(3, 2, 112, 96, 16, 32, 8, 8, 2, 1, 3)        \
+    OP(3, 1, 56, 144, 24, 16, 8, 14, 2, 2, 9)       \
+    OP(5, 2, 56, 144, 24, 16, 7, 14, 2, 2, 9)       \
+    OP(5, 1, 28, 240, 40, 16, 14, 14, 2, 3, 5)      \
+    OP(3, 2, 28, 240, 40, 16, 7, 14, 2, 3, 5)
+
+bool launch_mbconv_front(const float* Xin, int Cin, const float* We, const float* be, const float* Wd,
+                         const float* bd, float* Y, float* P, int n, int H, int C, int k, int stride,
+                         int pad_lo, int* tiles, hipStream_t s) {
+#define DFD_MB_DISPATCH(KK, SS, HH, CC, CI, CB, TH, TW, RP, KC, NSUB)                                     \
+    if (k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                    \
+        mb_launch<KK, SS, CB, TH, TW, RP, KC, NSUB>(Xin, Cin, We, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s); \
+        return true;                                                                                     \
+    }
+    DFD_MB_TABLE(DFD_MB_DISPATCH)
+#undef DFD_MB_DISPATCH
     return false;
 }
 
@@ -498,16 +657,18 @@ __global__ __launch_bounds__(1024) void se_kernel(const float* __restrict__ P, i
     __syncthreads();
     {   // FC1: wave w owns outputs w, w+16, w+32
         float s[3] = {0.f, 0.f, 0.f};
+        // every load is unconditional (indices clamped, the VALUE is masked): a load under a
+        // runtime condition makes hipcc branch around it and wait per element (guide section 5, trap (c))
 #pragma unroll
         for (int i = 0; i < SE_MAXC / 64; ++i) {
             const int c = lane + 64 * i;
-            if (c < C) {
-                const float mv = mean[c];
+            const int cc = c < C ? c : 0;
+            const float mv = c < C ? mean[cc] : 0.f;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int o = wave + 16 * k;
-                    if (o < c_se) s[k] += mv * w1[(size_t)o * C + c];
-                }
+            for (int k = 0; k < 3; ++k) {
+                const int o = wave + 16 * k;
+                const int oo = o < c_se ? o : c_se - 1;
+                s[k] += mv * w1[(size_t)oo * C + cc];
             }
         }
 #pragma unroll
@@ -522,10 +683,12 @@ __global__ __launch_bounds__(1024) void se_kernel(const float* __restrict__ P, i
     __syncthreads();
     for (int c = tid; c < C; c += 1024) {
         float s = b2[c];
+        float wv[SE_MAXSE];                     // all 48 loads issued before the first use
 #pragma unroll
-        for (int o = 0; o < SE_MAXSE; ++o)
-            if (o < c_se) s += z[o] * w2t[(size_t)o * C + c];
-        gate[(size_t)n * C + c] = 1.0f / (1.0f + __expf(-s));
+        for (int o = 0; o < SE_MAXSE; ++o) wv[o] = w2t[(size_t)(o < c_se ? o : 0) * C + c];
+#pragma unroll
+        for (int o = 0; o < SE_MAXSE; ++o) s += (o < c_se ? z[o < c_se ? o : 0] : 0.f) * wv[o];
+        gate[(size_t)n * C + c] = sigmoid1(s);
     }
 }
 

@@ -189,18 +189,30 @@ int b0_forward(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* t
         const int m_in = n * b.h_in * b.h_in, m_out = n * b.h_out * b.h_out;
         const std::string q = "b" + std::to_string(bi);
         const float* dw_in = cur;
-        if (b.expand != 1) {
+        int tiles = 0;
+        bool fused = false;
+        if (b.expand != 1 && h->fuse_expand &&
+            launch_mbconv_front(cur, b.c_in, b.exp_w, b.exp_b, b.dw_w, b.dw_b, h->dwbuf, h->pool, n, b.h_in, b.c_exp,
+                                b.kernel, b.stride, b.pad_lo, &tiles, s)) {
+            fused = true;
+            mk.mark(layer_name(bi, "dw"));            // expand + depthwise in one launch
+            if (tap && tap->name && q + ".exp" == tap->name)
+                return fail(h, DFD_ERR_STATE, "tap '%s': the expanded tensor is not materialised when expand is fused "
+                                              "(dfd_set_option(h, \"fuse_expand\", 0))", tap->name);
+        }
+        if (!fused && b.expand != 1) {
             launch_pointwise(cur, b.exp_w, b.exp_b, nullptr, nullptr, h->expbuf, m_in, b.c_in, b.c_exp,
                              b.h_in * b.h_in, ACT_SWISH, s);
             mk.mark(layer_name(bi, "exp"));
             if ((rc = tap_out(h, tap, q + ".exp", h->expbuf, (size_t)m_in * b.c_exp))) return rc;
             dw_in = h->expbuf;
         }
-        int tiles = 0;
-        if (!launch_depthwise(dw_in, b.dw_w, b.dw_b, h->dwbuf, h->pool, n, b.h_in, b.c_exp, b.kernel,
-                              b.stride, b.pad_lo, &tiles, s))
-            return fail(h, DFD_ERR_STATE, "no depthwise kernel for block %d", bi);
-        mk.mark(layer_name(bi, "dw"));
+        if (!fused) {
+            if (!launch_depthwise(dw_in, b.dw_w, b.dw_b, h->dwbuf, h->pool, n, b.h_in, b.c_exp, b.kernel,
+                                  b.stride, b.pad_lo, &tiles, s))
+                return fail(h, DFD_ERR_STATE, "no depthwise kernel for block %d", bi);
+            mk.mark(layer_name(bi, "dw"));
+        }
         if ((rc = tap_out(h, tap, q + ".dw", h->dwbuf, (size_t)m_out * b.c_exp))) return rc;
         launch_se(h->pool, tiles, 1.0f / (float)(b.h_out * b.h_out), b.se_w1, b.se_b1, b.se_w2, b.se_b2,
                   h->gate, n, b.c_exp, b.c_se, s);

@@ -26,6 +26,7 @@ int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, in
         return fail(h, DFD_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
     h->device = device;
     h->max_batch = max_batch;
+    if (const char* e = getenv("DFD_FUSE_EXPAND")) h->fuse_expand = atoi(e) != 0;
     DFD_HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     DFD_HIP_TRY(h, hipEventCreate(&h->ev0));
     DFD_HIP_TRY(h, hipEventCreate(&h->ev1));
@@ -109,6 +110,12 @@ void dfd_destroy(dfd_handle* h) { destroy_impl(h); }
 const char* dfd_last_error(const dfd_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int dfd_max_batch(const dfd_handle* h) { return h ? h->max_batch : DFD_ERR_ARG; }
+
+int dfd_set_option(dfd_handle* h, const char* name, int value) {
+    if (!h || !name) return DFD_ERR_ARG;
+    if (strcmp(name, "fuse_expand") == 0) { h->fuse_expand = value != 0; return DFD_OK; }
+    return fail(h, DFD_ERR_ARG, "unknown option '%s'", name);
+}
 
 int dfd_device_alloc(dfd_handle* h, size_t bytes, void** dptr) {
     if (!h || !dptr) return DFD_ERR_ARG;

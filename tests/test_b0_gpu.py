@@ -34,13 +34,18 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous().numpy() if t.dim() == 4 else t.numpy()
 
 
-def test_taps_match_oracle(b0_handle, ref):
+@pytest.mark.parametrize("fuse", [0, 1])
+def test_taps_match_oracle(b0_handle, ref, fuse):
+    """fuse=0: every layer as its own kernel (the expand outputs exist and are checked);
+    fuse=1: blocks 1-5 compute expand inside the depthwise kernel (the default)."""
     x, _, taps = ref
     n = x.shape[0]
     xd = b0_handle.alloc(x.nbytes).upload(x)
+    b0_handle.set_option("fuse_expand", fuse)
     names = ["stem"]
     for i in range(16):
-        names += ([f"b{i}.exp"] if i else []) + [f"b{i}.dw", f"b{i}.gate", f"b{i}.out"]
+        has_exp = i >= 1 and not (fuse and 1 <= i <= 5)
+        names += ([f"b{i}.exp"] if has_exp else []) + [f"b{i}.dw", f"b{i}.gate", f"b{i}.out"]
     names += ["head"]
     worst = {}
     for name in names:
@@ -51,8 +56,22 @@ def test_taps_match_oracle(b0_handle, ref):
         err = float(np.abs(got - want).max())
         worst[name] = err
         assert err <= LOGIT_TOL, f"{name}: max|d|={err:.3e} (ref absmax {np.abs(want).max():.2f})"
+    if fuse:
+        with pytest.raises(Exception):
+            b0_handle.tap(xd.ptr, n, "b1.exp", 10)             # not materialised when fused: loud, not silent
+    b0_handle.set_option("fuse_expand", 1)
     xd.free()
     print("worst tap errors:", sorted(worst.items(), key=lambda kv: -kv[1])[:5])
+
+
+def test_fused_and_unfused_logits_agree(b0_handle, ref):
+    x, want, _ = ref
+    b0_handle.set_option("fuse_expand", 0)
+    a = b0_handle.classify(x)
+    b0_handle.set_option("fuse_expand", 1)
+    b = b0_handle.classify(x)
+    assert np.abs(a - want).max() <= LOGIT_TOL and np.abs(b - want).max() <= LOGIT_TOL
+    assert np.abs(a - b).max() <= 1e-4
 
 
 def test_logits_match_oracle(b0_handle, ref):
