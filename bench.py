@@ -197,7 +197,7 @@ def main():
                    "batch_per_gpu": args.batch, "parallelism": f"frame-shard x{world}, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "dfd::dw_kernel<K,S,CB,TH,TW,RP> (16 depthwise launches per step)",
+                     "kernel": "dfd::dw_kernel<...> / dfd::mbconv_kernel<...> (the 16 depthwise launches per step; blocks 1-5 compute their 1x1 expand inside the launch)",
                      "algorithmic_bytes_per_step": dw_bytes, "ms_per_step": round(dw_ms, 4),
                      "share_of_step": round(dw_ms / all_ms, 4) if all_ms else None},
         "kernel_ms_per_step": round(all_ms, 3),

@@ -15,6 +15,8 @@
 // arithmetic of each layer is checked against oracle/b0_ref.py by tests/test_b0_gpu.py.
 #include "b0_kernels.h"
 
+#include <cstdlib>
+
 namespace dfd {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -85,7 +87,6 @@ void launch_stem(const float* x, const float* w, const float* b, float* y, int n
 // i.e. one 16-byte NHWC store.  Each lane fetches 4 consecutive k (one b128) per 16-wide K
 // chunk and feeds element s to MFMA s, so MFMA s sums k = {s, 4+s, 8+s, 12+s}: the same
 // permutation on both operands, which is all the contraction needs.
-constexpr int PW_MT = 2;           // 16-pixel tiles per wave
 constexpr int PW_BK = 32;          // K per LDS stage
 constexpr int PW_BKP = PW_BK + 8;  // +8 floats: conflict-free ds_read_b128 of 16 rows x 4 k-quads
 
@@ -94,7 +95,7 @@ constexpr int PW_BKP = PW_BK + 8;  // +8 floats: conflict-free ds_read_b128 of 1
 // stage (C_in % 32 == 0) lies inside one tap and the X fragment is still one 16-byte load per
 // lane from the NHWC input, zero outside the image.  res_first: add R before the activation
 // (ResNet basic block) instead of after it (MBConv skip).
-template <int NT, bool CONV>
+template <int NT, bool CONV, int MT, bool GATE>
 __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ X,
                                                  const float* __restrict__ W,
                                                  const float* __restrict__ bias,
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ X,
                                                  float* __restrict__ Y, int M, int K, int N,
                                                  int HW, int act, int mblocks, int nblocks,
                                                  ConvGeom cg, int res_first) {
-    constexpr int MT = PW_MT, BK = PW_BK, BKP = PW_BKP;
+    constexpr int BK = PW_BK, BKP = PW_BKP;
     constexpr int BN = NT * 16, BM = 4 * MT * 16;
     constexpr int WLOADS = (BN * (BK / 4) + 255) / 256;
     __shared__ __attribute__((aligned(16))) float ws[2][BN * BKP];
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ X,
             iy0[mt] = oy * cg.stride - cg.pad;
             ix0[mt] = ox * cg.stride - cg.pad;
         } else {
-            gbase[mt] = gate ? (size_t)(m[mt] < M ? m[mt] / HW : 0) * K : 0;
+            gbase[mt] = GATE ? (size_t)(m[mt] < M ? m[mt] / HW : 0) * K : 0;
             iy0[mt] = ix0[mt] = 0;
         }
     }
@@ -143,29 +144,42 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ X,
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+    // Operand loads are UNCONDITIONAL (addresses clamped into the tensor) and nothing touches a loaded
+    // value until the step that consumes it: a load under a branch, or an ALU op right behind it (the SE
+    // gate multiply used to sit here), makes hipcc wait vmcnt(0) on the spot, and the "prefetch" of the next
+    // K-step then overlaps nothing.  Rows >= M are clamped to M-1 (never stored); k >= K is clamped to K-4
+    // and meets zero weights (the W tile is zero-filled there at store time).
     v4f wreg[WLOADS];
     v4f xcur[MT][2], xnext[MT][2];
+    v4f gcur[MT][2], gnext[MT][2];      // raw SE gate fragments (GATE only), multiplied in at use
+    int mclamp[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) mclamp[mt] = m[mt] < M ? m[mt] : M - 1;
 
+    auto w_ok = [&](int t, int kc) {
+        const int e = tid + t * 256;
+        return e < BN * (BK / 4) && n0 + (e >> 3) < N && kc + 4 * (e & 7) < K;
+    };
     auto load_w = [&](int kc) {
 #pragma unroll
         for (int t = 0; t < WLOADS; ++t) {
             const int e = tid + t * 256;
-            const int row = e >> 3, c4 = e & 7;
-            const int n = n0 + row, k = kc + 4 * c4;
-            v4f v = (v4f){0.f, 0.f, 0.f, 0.f};
-            if (e < BN * (BK / 4) && n < N && k < K) v = ldg4(W + (size_t)n * K + k);
-            wreg[t] = v;
+            int n = n0 + (e >> 3), k = kc + 4 * (e & 7);
+            n = n < N ? n : N - 1;
+            k = k < K ? k : K - 4;
+            wreg[t] = ldg4(W + (size_t)n * K + k);
         }
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](int buf, int kc) {
 #pragma unroll
         for (int t = 0; t < WLOADS; ++t) {
             const int e = tid + t * 256;
             const int row = e >> 3, c4 = e & 7;
-            if (e < BN * (BK / 4)) *reinterpret_cast<v4f*>(&ws[buf][row * BKP + 4 * c4]) = wreg[t];
+            if (e < BN * (BK / 4))
+                *reinterpret_cast<v4f*>(&ws[buf][row * BKP + 4 * c4]) = w_ok(t, kc) ? wreg[t] : (v4f){0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto load_x = [&](int kc, v4f (&xf)[MT][2]) {
+    auto load_x = [&](int kc, v4f (&xf)[MT][2], v4f (&gf)[MT][2]) {
         if constexpr (CONV) {
             const int tap = kc / cg.Cin, ci0 = kc - tap * cg.Cin;      // wave-uniform
             const int ky = tap / cg.ksize, kx = tap - ky * cg.ksize;
@@ -173,59 +187,71 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ X,
             for (int mt = 0; mt < MT; ++mt) {
                 const int iy = iy0[mt] + ky * cg.dil, ix = ix0[mt] + kx * cg.dil;
                 const bool ok = m[mt] < M && (unsigned)iy < (unsigned)cg.H && (unsigned)ix < (unsigned)cg.W;
-                const float* p = X + gbase[mt] + ((size_t)iy * cg.W + ix) * cg.Cin + ci0 + 4 * q;
+                const float* p = X + gbase[mt] + ((size_t)(ok ? iy : 0) * cg.W + (ok ? ix : 0)) * cg.Cin + ci0 + 4 * q;
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc)
-                    xf[mt][cc] = ok ? ldg4(p + cc * 16) : (v4f){0.f, 0.f, 0.f, 0.f};
+                for (int cc = 0; cc < 2; ++cc) {
+                    xf[mt][cc] = ldg4(p + cc * 16);
+                    gf[mt][cc] = ok ? (v4f){1.f, 1.f, 1.f, 1.f} : (v4f){0.f, 0.f, 0.f, 0.f};   // zero padding, applied at use
+                }
             }
         } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
-                    const int k = kc + cc * 16 + 4 * q;
-                    v4f v = (v4f){0.f, 0.f, 0.f, 0.f};
-                    if (m[mt] < M && k < K) {
-                        v = ldg4(X + (size_t)m[mt] * K + k);
-                        if (gate) v *= ldg4(gate + gbase[mt] + k);
-                    }
-                    xf[mt][cc] = v;
+                    int k = kc + cc * 16 + 4 * q;
+                    k = k < K ? k : K - 4;
+                    xf[mt][cc] = ldg4(X + (size_t)mclamp[mt] * K + k);
+                    if constexpr (GATE) gf[mt][cc] = ldg4(gate + gbase[mt] + k);
                 }
         }
     };
 
     const int nk = (K + BK - 1) / BK;
     load_w(0);
-    load_x(0, xcur);
-    store_w(0);
+    load_x(0, xcur, gcur);
+    store_w(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) {
-            load_w((kt + 1) * BK);
-            load_x((kt + 1) * BK, xnext);
+        // branch-free body: the last iteration re-loads its own step (unused).  An `if (more)` around the
+        // prefetch makes a join point where hipcc must assume nothing newer is in flight and emits
+        // vmcnt(0) before the MFMAs - which on the common path drains the prefetch it just issued.
+        const int kn = (kt + 1 < nk ? kt + 1 : kt) * BK;
+        load_w(kn);
+        load_x(kn, xnext, gnext);
+        if constexpr (GATE || CONV) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                xcur[mt][0] *= gcur[mt][0];
+                xcur[mt][1] *= gcur[mt][1];
+            }
         }
         const float* wb = ws[kt & 1];
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
+            // all NT weight fragments of this 16-wide K chunk are read before the first MFMA
+            v4f wfa[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const v4f wf = *reinterpret_cast<const v4f*>(&wb[(nt * 16 + j) * BKP + cc * 16 + 4 * q]);
-                // the two pixel tiles alternate, so a dependent accumulate is two issues (64 cycles) behind
-                // its producer: v_mfma_f32_16x16x4_f32 issues every 32 cycles but has 40 cycles of latency
+            for (int nt = 0; nt < NT; ++nt)
+                wfa[nt] = *reinterpret_cast<const v4f*>(&wb[(nt * 16 + j) * BKP + cc * 16 + 4 * q]);
+            // every accumulator gets one MFMA per k-quad e before any gets its next: a dependent accumulate is
+            // MT*NT issues behind its producer (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle latency)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[e], xcur[mt][cc][e], acc[mt][nt], 0, 0, 0);
-            }
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfa[nt][e], xcur[mt][cc][e], acc[mt][nt], 0, 0, 0);
         }
-        if (more) {
-            store_w((kt + 1) & 1);
+        store_w((kt + 1) & 1, kn);              // the other buffer: nobody reads it after the last step
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                xcur[mt][0] = xnext[mt][0];
-                xcur[mt][1] = xnext[mt][1];
+        for (int mt = 0; mt < MT; ++mt) {
+            xcur[mt][0] = xnext[mt][0];
+            xcur[mt][1] = xnext[mt][1];
+            if constexpr (GATE || CONV) {
+                gcur[mt][0] = gnext[mt][0];
+                gcur[mt][1] = gnext[mt][1];
             }
         }
         __syncthreads();
@@ -268,57 +294,63 @@ __global__ __launch_bounds__(256) void pw_kernel(const float* __restrict__ X,
     }
 }
 
-static int pick_nt(int N) {
-    // fewest n-blocks first (X is re-read once per n-block), then least padding
+// Tile choice: a wave computes MT 16-pixel tiles x NT 16-channel tiles; a block is 4 waves (64*MT pixels).
+// Late layers have few pixels (batch*49 or batch*196), so the largest tile starves the 256 CUs: prefer the
+// biggest per-wave tile (MFMAs per operand load) among the choices that still launch >= 3 blocks per CU.
+struct PwTile { int mt, nt, mblocks, nblocks; };
+static PwTile pick_tile(int M, int N) {
     const int tiles = (N + 15) / 16;
-    int best = 1, best_blocks = 1 << 30, best_waste = 1 << 30;
-    for (int nt = 1; nt <= 10; ++nt) {
-        const int blocks = (tiles + nt - 1) / nt, waste = blocks * nt - tiles;
-        if (blocks < best_blocks || (blocks == best_blocks && waste < best_waste)) {
-            best = nt; best_blocks = blocks; best_waste = waste;
+    PwTile best{2, 1, 0, 0};
+    double best_score = -1.0;
+    static const double fill_target = getenv("DFD_PW_FILL") ? atof(getenv("DFD_PW_FILL")) : 768.0;
+    static const double one_nb_bonus = getenv("DFD_PW_BONUS") ? atof(getenv("DFD_PW_BONUS")) : 1.15;
+    static const int mt_max = getenv("DFD_PW_MTMAX") ? atoi(getenv("DFD_PW_MTMAX")) : 2;
+    for (int mt = 1; mt <= mt_max; ++mt)
+        for (int nt = 1; nt <= 10; ++nt) {
+            const int mb = (M + 64 * mt - 1) / (64 * mt), nb = (tiles + nt - 1) / nt;
+            const double blocks = (double)mb * nb;
+            const double useful = (double)tiles / ((double)nb * nt);          // padding waste of the last n-block
+            // work per wave-step, discounted when the grid cannot fill the chip (768 = 3 blocks per CU)
+            const double fill = blocks >= fill_target ? 1.0 : blocks / fill_target;
+            const double score = mt * nt * useful * fill * (nb == 1 ? one_nb_bonus : 1.0);   // one n-block: X read once
+            if (score > best_score) { best_score = score; best = PwTile{mt, nt, mb, nb}; }
         }
-    }
     return best;
+}
+
+#define DFD_PW_NT_CASES(OP) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10)
+
+template <bool CONV, bool GATE>
+static void pw_dispatch(const PwTile& t, const float* X, const float* W, const float* bias, const float* gate,
+                        const float* R, float* Y, int M, int K, int N, int HW, int act, const ConvGeom& g,
+                        int res_first, hipStream_t s) {
+    const int grid = ((t.mblocks + 7) / 8) * 8 * t.nblocks;
+#define DFD_PW_CASE(NTV)                                                                                             \
+    case NTV:                                                                                                        \
+        if (t.mt == 2)                                                                                               \
+            hipLaunchKernelGGL((pw_kernel<NTV, CONV, 2, GATE>), dim3(grid), dim3(256), 0, s, X, W, bias, gate, R, Y, \
+                               M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first);                                \
+        else                                                                                                         \
+            hipLaunchKernelGGL((pw_kernel<NTV, CONV, 1, GATE>), dim3(grid), dim3(256), 0, s, X, W, bias, gate, R, Y, \
+                               M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first);                                \
+        break;
+    switch (t.nt) { DFD_PW_NT_CASES(DFD_PW_CASE) }
+#undef DFD_PW_CASE
 }
 
 void launch_pointwise(const float* X, const float* W, const float* bias, const float* gate,
                       const float* R, float* Y, int M, int K, int N, int HW, int act,
                       hipStream_t s) {
-    const int nt = pick_nt(N);
-    const int BM = 4 * PW_MT * 16, BN = nt * 16;
-    const int mblocks = (M + BM - 1) / BM, nblocks = (N + BN - 1) / BN;
-    const int grid = ((mblocks + 7) / 8) * 8 * nblocks;
     const ConvGeom none{};
-#define DFD_PW_CASE(NTV)                                                                               \
-    case NTV:                                                                                          \
-        hipLaunchKernelGGL((pw_kernel<NTV, false>), dim3(grid), dim3(256), 0, s, X, W, bias, gate, R, Y, \
-                           M, K, N, HW, act, mblocks, nblocks, none, 0);                               \
-        break;
-    switch (nt) {
-        DFD_PW_CASE(1) DFD_PW_CASE(2) DFD_PW_CASE(3) DFD_PW_CASE(4) DFD_PW_CASE(5)
-        DFD_PW_CASE(6) DFD_PW_CASE(7) DFD_PW_CASE(8) DFD_PW_CASE(9) DFD_PW_CASE(10)
-    }
-#undef DFD_PW_CASE
+    if (gate) pw_dispatch<false, true>(pick_tile(M, N), X, W, bias, gate, R, Y, M, K, N, HW, act, none, 0, s);
+    else pw_dispatch<false, false>(pick_tile(M, N), X, W, bias, nullptr, R, Y, M, K, N, HW, act, none, 0, s);
 }
 
 bool launch_conv_gemm(const float* X, const float* W, const float* bias, const float* R, float* Y, int n_img,
                       const ConvGeom& g, int Cout, int act, bool res_first, hipStream_t s) {
     if (g.Cin % PW_BK != 0) return false;                  // a K stage must not straddle two taps
-    const int M = n_img * g.Ho * g.Wo, K = g.ksize * g.ksize * g.Cin, N = Cout;
-    const int nt = pick_nt(N);
-    const int BM = 4 * PW_MT * 16, BN = nt * 16;
-    const int mblocks = (M + BM - 1) / BM, nblocks = (N + BN - 1) / BN;
-    const int grid = ((mblocks + 7) / 8) * 8 * nblocks;
-#define DFD_CV_CASE(NTV)                                                                                  \
-    case NTV:                                                                                             \
-        hipLaunchKernelGGL((pw_kernel<NTV, true>), dim3(grid), dim3(256), 0, s, X, W, bias, nullptr, R, Y, \
-                           M, K, N, 1, act, mblocks, nblocks, g, res_first ? 1 : 0);                      \
-        break;
-    switch (nt) {
-        DFD_CV_CASE(1) DFD_CV_CASE(2) DFD_CV_CASE(3) DFD_CV_CASE(4) DFD_CV_CASE(5)
-        DFD_CV_CASE(6) DFD_CV_CASE(7) DFD_CV_CASE(8) DFD_CV_CASE(9) DFD_CV_CASE(10)
-    }
-#undef DFD_CV_CASE
+    const int M = n_img * g.Ho * g.Wo, K = g.ksize * g.ksize * g.Cin;
+    pw_dispatch<true, false>(pick_tile(M, Cout), X, W, bias, nullptr, R, Y, M, K, Cout, 1, act, g, res_first ? 1 : 0, s);
     return true;
 }
 
