@@ -57,7 +57,9 @@ const char* dfd_last_error(const dfd_handle* h);
 int dfd_max_batch(const dfd_handle* h);
 /* Tuning switches (results stay within the parity tolerances either way):
  *   "fuse_expand" (default 1, env DFD_FUSE_EXPAND): MBConv blocks 1-5 compute the 1x1 expand conv
- *   inside the depthwise kernel instead of writing the expanded tensor to HBM. */
+ *   inside the depthwise kernel instead of writing the expanded tensor to HBM.
+ *   "fuse_stem" (default 1, env DFD_FUSE_STEM): the stem conv is computed inside block 0's depthwise
+ *   kernel (the 112x112x32 stem activation stays in LDS). */
 int dfd_set_option(dfd_handle* h, const char* name, int value);
 
 /* ---- device memory and stream plumbing (no reference counterpart) -------------- */

@@ -10,6 +10,12 @@ enum Act { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
 void launch_stem(const float* x_nchw, const float* w /*[3][3][3][32]*/, const float* b,
                  float* y, int n, hipStream_t s);
 
+// stem + block-0 depthwise fused (the stem activation stays in LDS); stem_out may be null, or a buffer
+// [n][112][112][32] that receives a copy of the stem activation for parity taps.  The tile count (98) is
+// that of launch_depthwise for block 0.
+void launch_stem_dw(const float* x_nchw, const float* ws, const float* bs, const float* Wd, const float* bd,
+                    float* Y, float* P, float* stem_out, int n, int* tiles, hipStream_t s);
+
 // pointwise conv as GEMM: Y[m][o] = act( sum_k X[m][k]*gate[m/HW][k] * W[o][k] + b[o] ) + R[m][o]
 // gate / R may be null.  X rows have stride K, Y/R rows stride N.
 void launch_pointwise(const float* X, const float* W, const float* bias, const float* gate,

@@ -437,7 +437,7 @@ __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* 
 }
 
 template <int K, int S, int CB, int TH, int TW, int RP>
-__global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ X,
+__global__ __launch_bounds__(256, 4) void dw_kernel(const float* __restrict__ X,
                                                  const float* __restrict__ Wt,
                                                  const float* __restrict__ bias,
                                                  float* __restrict__ Y, float* __restrict__ P,
@@ -517,17 +517,14 @@ __global__ __launch_bounds__(256) void mbconv_kernel(const float* __restrict__ X
         }
     }
 
-    // small per-chunk operands (depthwise weights, expand weights A operand, biases) are fetched one
-    // chunk AHEAD into registers, so their latency hides under the previous chunk's depthwise phase
-    constexpr int WLR = (K * K * CG + 255) / 256;
-    v4f wlr[WLR], wf[NTB][KC], bex[NTB], bv;
-    auto fetch = [&](int c0) {
-#pragma unroll
-        for (int r = 0; r < WLR; ++r) {
-            const int i = tid + r * 256, ii = i < K * K * CG ? i : 0;
-            wlr[r] = ldg4(Wt + (size_t)(ii / CG) * C + c0 + 4 * (ii % CG));
-        }
-        bv = ldg4(bias + c0 + 4 * (tid % CG));
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const int c0 = (group * NSUB + sub) * CB;
+        if (sub > 0) __syncthreads();                            // previous chunk done with tile/wl/red
+        for (int i = tid; i < K * K * CG; i += 256)
+            wl[i] = ldg4(Wt + (size_t)(i / CG) * C + c0 + 4 * (i % CG));
+        const v4f bv = ldg4(bias + c0 + 4 * (tid % CG));
+        // A operand: this chunk's expand weights, lane (channel j, k-quad q)
+        v4f wf[NTB][KC], bex[NTB];
 #pragma unroll
         for (int nt = 0; nt < NTB; ++nt) {
             bex[nt] = ldg4(be + c0 + nt * 16 + 4 * q);
@@ -538,15 +535,6 @@ __global__ __launch_bounds__(256) void mbconv_kernel(const float* __restrict__ X
                 wf[nt][kk] = k < Cin ? v : (v4f){0.f, 0.f, 0.f, 0.f};
             }
         }
-    };
-    fetch(group * NSUB * CB);
-    for (int sub = 0; sub < NSUB; ++sub) {
-        const int c0 = (group * NSUB + sub) * CB;
-        if (sub > 0) __syncthreads();                            // previous chunk done with tile/wl/red
-#pragma unroll
-        for (int r = 0; r < WLR; ++r)
-            if (tid + r * 256 < K * K * CG) wl[tid + r * 256] = wlr[r];
-        const v4f bv_cur = bv;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int mt = wave + 4 * it;
@@ -571,10 +559,94 @@ __global__ __launch_bounds__(256) void mbconv_kernel(const float* __restrict__ X
                 }
             }
         }
-        if (sub + 1 < NSUB) fetch(c0 + CB);                      // in flight during dw_compute
         __syncthreads();
-        dw_compute<K, S, CB, TH, TW, RP>(tile, wl, red, bv_cur, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
+        dw_compute<K, S, CB, TH, TW, RP>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
     }
+}
+
+// Stem + block-0 depthwise in ONE kernel.  Block = image x 8x16 output tile x all 32 channels.  The
+// 21x37x3 input patch (NCHW network input) is staged in LDS with row-contiguous loads, the 3x3 s2 stem
+// conv (+BN+swish) of the 10x18 halo tile is computed from it straight into the depthwise LDS tile
+// (zero outside the 112x112 stem output = the depthwise padding), then dw_compute runs as usual.
+// The 112x112x32 stem activation (1.6 MB per crop, read back with a 1.4x halo) never touches HBM.
+__global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict__ x, const float* __restrict__ ws_g,
+                                                      const float* __restrict__ bs, const float* __restrict__ Wt,
+                                                      const float* __restrict__ bias, float* __restrict__ Y,
+                                                      float* __restrict__ P, float* __restrict__ stem_out,
+                                                      int tiles_x, int tiles_sp) {
+    constexpr int K = 3, S = 1, CB = 32, TH = 8, TW = 16, RP = 4, CG = 8;
+    constexpr int IH = TH + 2, IW = TW + 2;                 // 10 x 18 stem pixels
+    constexpr int PH = (IH - 1) * 2 + 3, PW = (IW - 1) * 2 + 3, PWP = PW + 1;   // 21 x 37 input patch
+    __shared__ v4f tile[IH * IW * CG];
+    __shared__ v4f wl[K * K * CG];
+    __shared__ v4f red[4 * CG];
+    __shared__ float patch[3 * PH * PWP];
+    __shared__ float ws[27 * 32];
+    const int tid = threadIdx.x, n = blockIdx.y, t = blockIdx.x;
+    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
+    for (int i = tid; i < 27 * 32; i += 256) ws[i] = ws_g[i];
+    for (int i = tid; i < K * K * CG; i += 256) wl[i] = ldg4(Wt + (size_t)(i / CG) * 32 + 4 * (i % CG));
+    const v4f bv = ldg4(bias + 4 * (tid % CG));
+    // stem pixel (sy, sx) = (ty0 - 1 + py, tx0 - 1 + px) reads input rows 2*sy .. 2*sy+2 (TF-SAME: pad high only)
+    const int r0 = 2 * (ty0 - 1), c0 = 2 * (tx0 - 1);
+    const float* xb = x + (size_t)n * 3 * 224 * 224;
+    for (int i = tid; i < 3 * PH * PW; i += 256) {
+        const int ci = i / (PH * PW), r = (i / PW) % PH, c = i % PW;
+        const int iy = r0 + r, ix = c0 + c;
+        float v = 0.f;
+        if ((unsigned)iy < 224u && (unsigned)ix < 224u) v = xb[(size_t)ci * 224 * 224 + iy * 224 + ix];
+        patch[(ci * PH + r) * PWP + c] = v;
+    }
+    __syncthreads();
+    const int cg = tid & 7;
+    const v4f bsv = ldg4(bs + 4 * cg);
+    // thread = 4 output channels x 6 of the 180 halo pixels; taps outermost so each weight vector is read
+    // from LDS once per thread, not once per pixel
+    constexpr int NPX = (IH * IW + 31) / 32;
+    v4f acc[NPX];
+    int poff[NPX];
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+        const int p = (tid >> 3) + 32 * i, pc = p < IH * IW ? p : 0;
+        acc[i] = bsv;
+        poff[i] = (2 * (pc / IW)) * PWP + 2 * (pc % IW);
+    }
+    // (ci, ky) stay rolled: fully unrolled, the compiler hoists all 27 weight vectors and 162 patch values
+    // (256 VGPRs, one wave per SIMD)
+#pragma unroll 1
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const v4f w = *reinterpret_cast<const v4f*>(&ws[((ky * 3 + kx) * 3 + ci) * 32 + 4 * cg]);
+                const float* pp = &patch[(ci * PH + ky) * PWP + kx];
+#pragma unroll
+                for (int i = 0; i < NPX; ++i) acc[i] += pp[poff[i]] * w;
+            }
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+        const int p = (tid >> 3) + 32 * i;
+        if (p < IH * IW) {
+            const int py = p / IW, px = p % IW;
+            const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
+            const bool inside = (unsigned)sy < 112u && (unsigned)sx < 112u;
+            const v4f v = inside ? swish4(acc[i]) : (v4f){0.f, 0.f, 0.f, 0.f};
+            tile[p * CG + cg] = v;
+            // optional copy of the stem activation (parity taps only): interior pixels of this tile
+            if (stem_out && inside && py >= 1 && py <= TH && px >= 1 && px <= TW)
+                stg4(stem_out + (((size_t)n * 112 + sy) * 112 + sx) * 32 + 4 * cg, v);
+        }
+    }
+    __syncthreads();
+    dw_compute<K, S, CB, TH, TW, RP>(tile, wl, red, bv, Y, P, n, 112, 32, 0, ty0, tx0, t, tiles_sp);
+}
+
+void launch_stem_dw(const float* x, const float* ws, const float* bs, const float* Wd, const float* bd, float* Y,
+                    float* P, float* stem_out, int n, int* tiles, hipStream_t s) {
+    const int tx = 112 / 16, ty = 112 / 8;
+    *tiles = tx * ty;
+    hipLaunchKernelGGL(stem_dw_kernel, dim3(tx * ty, n), dim3(256), 0, s, x, ws, bs, Wd, bd, Y, P, stem_out, tx, tx * ty);
 }
 
 template <int K, int S, int CB, int TH, int TW, int RP>
@@ -631,10 +703,10 @@ bool launch_depthwise(const float* X, const float* W, const float* bias, float* 
 // (k, stride, H, C, Cin) -> <K,S,CB,TH,TW,RP, KC = ceil(Cin/16), NSUB = channel chunks per block>
 #define DFD_MB_TABLE(OP)                            \
     OP(3, 2, 112, 96, 16, 32, 8, 8, 2, 1, 3)        \
-    OP(3, 1, 56, 144, 24, 16, 8, 14, 2, 2, 9)       \
-    OP(5, 2, 56, 144, 24, 16, 7, 14, 2, 2, 9)       \
-    OP(5, 1, 28, 240, 40, 16, 14, 14, 2, 3, 5)      \
-    OP(3, 2, 28, 240, 40, 16, 7, 14, 2, 3, 5)
+    OP(3, 1, 56, 144, 24, 16, 8, 14, 2, 2, 3)       \
+    OP(5, 2, 56, 144, 24, 16, 7, 14, 2, 2, 3)       \
+    OP(5, 1, 28, 240, 40, 16, 14, 14, 2, 3, 1)      \
+    OP(3, 2, 28, 240, 40, 16, 7, 14, 2, 3, 1)
 
 bool launch_mbconv_front(const float* Xin, int Cin, const float* We, const float* be, const float* Wd,
                          const float* bd, float* Y, float* P, int n, int H, int C, int k, int stride,

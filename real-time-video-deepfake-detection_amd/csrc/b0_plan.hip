@@ -179,8 +179,18 @@ int b0_forward(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* t
     Marks mk{prof, s};
     int rc;
     mk.mark("start");
-    launch_stem(x, P.stem_w, P.stem_b, h->io0, n, s);
-    mk.mark("stem");
+    // block 0 has no expand conv: its depthwise input IS the stem output, so the two fuse (option "fuse_stem")
+    const bool stem_fused = h->fuse_stem && P.blocks[0].expand == 1;
+    int stem_tiles = 0;
+    if (stem_fused) {
+        const bool want_stem = tap && tap->name && std::string(tap->name) == "stem";
+        launch_stem_dw(x, P.stem_w, P.stem_b, P.blocks[0].dw_w, P.blocks[0].dw_b, h->dwbuf, h->pool,
+                       want_stem ? h->io0 : nullptr, n, &stem_tiles, s);
+        mk.mark("b0.dw");                               // stem + depthwise of block 0 in one launch
+    } else {
+        launch_stem(x, P.stem_w, P.stem_b, h->io0, n, s);
+        mk.mark("stem");
+    }
     if ((rc = tap_out(h, tap, "stem", h->io0, (size_t)n * 112 * 112 * 32))) return rc;
     float* cur = h->io0;
     float* nxt = h->io1;
@@ -207,7 +217,9 @@ int b0_forward(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* t
             if ((rc = tap_out(h, tap, q + ".exp", h->expbuf, (size_t)m_in * b.c_exp))) return rc;
             dw_in = h->expbuf;
         }
-        if (!fused) {
+        if (bi == 0 && stem_fused) {
+            tiles = stem_tiles;
+        } else if (!fused) {
             if (!launch_depthwise(dw_in, b.dw_w, b.dw_b, h->dwbuf, h->pool, n, b.h_in, b.c_exp, b.kernel,
                                   b.stride, b.pad_lo, &tiles, s))
                 return fail(h, DFD_ERR_STATE, "no depthwise kernel for block %d", bi);

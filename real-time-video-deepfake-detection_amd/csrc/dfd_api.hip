@@ -27,6 +27,7 @@ int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, in
     h->device = device;
     h->max_batch = max_batch;
     if (const char* e = getenv("DFD_FUSE_EXPAND")) h->fuse_expand = atoi(e) != 0;
+    if (const char* e = getenv("DFD_FUSE_STEM")) h->fuse_stem = atoi(e) != 0;
     DFD_HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     DFD_HIP_TRY(h, hipEventCreate(&h->ev0));
     DFD_HIP_TRY(h, hipEventCreate(&h->ev1));
@@ -114,6 +115,7 @@ int dfd_max_batch(const dfd_handle* h) { return h ? h->max_batch : DFD_ERR_ARG; 
 int dfd_set_option(dfd_handle* h, const char* name, int value) {
     if (!h || !name) return DFD_ERR_ARG;
     if (strcmp(name, "fuse_expand") == 0) { h->fuse_expand = value != 0; return DFD_OK; }
+    if (strcmp(name, "fuse_stem") == 0) { h->fuse_stem = value != 0; return DFD_OK; }
     return fail(h, DFD_ERR_ARG, "unknown option '%s'", name);
 }
 

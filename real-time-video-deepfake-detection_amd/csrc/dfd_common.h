@@ -86,6 +86,7 @@ struct dfd_handle {
     dfd::DevBuf frame_buf, lab_buf, crop_buf, lut_buf, desc_buf, u8_out;
     dfd::ForensicState* forensic = nullptr;   // per-stream temporal state + work buffers
     dfd::SsdState* ssd = nullptr;             // detector plan + workspace (null: blob has no detector)
+    bool fuse_stem = true;               // stem conv computed inside block 0's depthwise kernel
     bool fuse_expand = true;             // MBConv blocks 1-5: expand conv computed inside the depthwise kernel
     dfd::B0Prof prof;                    // layer events between profile_begin/end
     int prof_steps = 0;

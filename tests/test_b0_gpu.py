@@ -42,6 +42,7 @@ def test_taps_match_oracle(b0_handle, ref, fuse):
     n = x.shape[0]
     xd = b0_handle.alloc(x.nbytes).upload(x)
     b0_handle.set_option("fuse_expand", fuse)
+    b0_handle.set_option("fuse_stem", fuse)            # fused: the stem tap is a side copy out of the fused kernel
     names = ["stem"]
     for i in range(16):
         has_exp = i >= 1 and not (fuse and 1 <= i <= 5)
@@ -60,6 +61,7 @@ def test_taps_match_oracle(b0_handle, ref, fuse):
         with pytest.raises(Exception):
             b0_handle.tap(xd.ptr, n, "b1.exp", 10)             # not materialised when fused: loud, not silent
     b0_handle.set_option("fuse_expand", 1)
+    b0_handle.set_option("fuse_stem", 1)
     xd.free()
     print("worst tap errors:", sorted(worst.items(), key=lambda kv: -kv[1])[:5])
 
@@ -67,8 +69,10 @@ def test_taps_match_oracle(b0_handle, ref, fuse):
 def test_fused_and_unfused_logits_agree(b0_handle, ref):
     x, want, _ = ref
     b0_handle.set_option("fuse_expand", 0)
+    b0_handle.set_option("fuse_stem", 0)
     a = b0_handle.classify(x)
     b0_handle.set_option("fuse_expand", 1)
+    b0_handle.set_option("fuse_stem", 1)
     b = b0_handle.classify(x)
     assert np.abs(a - want).max() <= LOGIT_TOL and np.abs(b - want).max() <= LOGIT_TOL
     assert np.abs(a - b).max() <= 1e-4
