@@ -123,6 +123,13 @@ int dfd_preprocess_crops(dfd_handle* h, const uint8_t* bgr, int height, int widt
 int dfd_classify_crops(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
                        const int32_t* xywh, int n, int apply_clahe, float* logits_out);
 
+/* compute_frequency_features, reference model.py:105-149: BGR (channels = 3) or gray (1) 8-bit
+ * image -> gray -> cv2.resize 224x224 -> channel 0 = min-max-normalised log1p|fftshift(fft2)|,
+ * channel 1 = min-max-normalised log1p|cv2.dct(gray/255)|.  out: (2,224,224) float32.  The model
+ * ignores this tensor (reference model.py:63-72); provided for API parity. */
+int dfd_frequency_features(dfd_handle* h, const uint8_t* img, int height, int width, int stride,
+                           int channels, float* out);
+
 /* ---- face detector ----------------------------------------------------------------------
  * _detect_dnn, reference face_detection.py:71-105, for a blob packed with detector weights
  * (weights.pack_all): cv2.resize to 300x300, mean (104,177,123) subtraction, SSD forward,

@@ -361,3 +361,21 @@ def crop_resize_normalize(face_bgr: np.ndarray) -> np.ndarray:
     mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
     std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
     return ((x - mean) / std)[0].numpy()
+
+
+def compute_frequency_features(image: np.ndarray, size: int = 224) -> np.ndarray:
+    """reference model.py:105-149: gray -> cv2.resize(size,size) -> float32; channel 0 = min-max of
+    log1p|fftshift(fft2)|, channel 1 = min-max of log1p|cv2.dct(gray/255)| (orthonormal DCT-II, here
+    via scipy.fft.dctn(type=2, norm='ortho'))."""
+    from scipy.fft import dctn
+
+    gray = bgr2gray_u8(image) if image.ndim == 3 else image
+    gray = resize_linear_u8(gray, size, size).astype(np.float32)
+
+    def norm(a):
+        lo, hi = a.min(), a.max()
+        return (a - lo) / (hi - lo) if hi - lo > 1e-6 else np.zeros_like(a)
+
+    mag = norm(np.log1p(np.abs(np.fft.fftshift(np.fft.fft2(gray)))))
+    d = norm(np.log1p(np.abs(dctn(gray / np.float32(255.0), type=2, norm="ortho"))))
+    return np.stack([mag, d], axis=0).astype(np.float32)

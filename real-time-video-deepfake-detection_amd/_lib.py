@@ -52,6 +52,7 @@ SIGNATURES = {
                                        C.c_int, C.c_void_p]),
     "dfd_classify_crops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                      C.c_int, C.c_void_p]),
+    "dfd_frequency_features": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dfd_detect_faces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                    C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dfd_has_detector": (C.c_int, [C.c_void_p]),
@@ -284,6 +285,15 @@ class Handle:
         fc, nd, hp = C.c_int(), C.c_int(), C.c_int()
         self._check(self._lib.dfd_forensics_state(self._p, int(stream_id), C.byref(fc), C.byref(nd), C.byref(hp)))
         return fc.value, nd.value, bool(hp.value)
+
+    def frequency_features(self, image) -> np.ndarray:
+        a = np.ascontiguousarray(np.asarray(image))
+        if a.dtype != np.uint8 or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
+            raise ValueError(f"expected (H,W,3) or (H,W) uint8 image, got {a.dtype} {a.shape}")
+        out = np.empty((2, 224, 224), np.float32)
+        self._check(self._lib.dfd_frequency_features(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0],
+                                                     3 if a.ndim == 3 else 1, _ptr(out)))
+        return out
 
     # -- face detector
     @property

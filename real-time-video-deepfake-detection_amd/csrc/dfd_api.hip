@@ -75,6 +75,7 @@ void destroy_impl(dfd_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     forensic_destroy(h);
     ssd_destroy(h);
+    freq_destroy(h);
     for (void* p : h->owned)
         if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);

@@ -18,6 +18,8 @@ namespace dfd {
 
 struct ForensicState;   // forensic_api.hip
 void forensic_destroy(dfd_handle* h);
+struct FreqState;       // freq_kernels.hip
+void freq_destroy(dfd_handle* h);
 struct SsdState;        // ssd_api.hip
 int ssd_init(dfd_handle* h);
 void ssd_destroy(dfd_handle* h);
@@ -85,6 +87,7 @@ struct dfd_handle {
     bool has_color = false;
     dfd::DevBuf frame_buf, lab_buf, crop_buf, lut_buf, desc_buf, u8_out;
     dfd::ForensicState* forensic = nullptr;   // per-stream temporal state + work buffers
+    dfd::FreqState* freq = nullptr;           // compute_frequency_features tables + scratch
     dfd::SsdState* ssd = nullptr;             // detector plan + workspace (null: blob has no detector)
     bool fuse_stem = true;               // stem conv computed inside block 0's depthwise kernel
     bool fuse_expand = true;             // MBConv blocks 1-5: expand conv computed inside the depthwise kernel

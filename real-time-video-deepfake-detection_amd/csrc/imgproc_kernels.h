@@ -20,6 +20,9 @@ struct CropDesc {
 
 void launch_resize_bgr(const uint8_t* src, int n, int sh, int sw, size_t sstride, size_t simg,
                        uint8_t* dst, int dh, int dw, hipStream_t s);
+// single-channel cv2.resize(INTER_LINEAR) and u8 -> float (x scale)
+void launch_resize_gray(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, hipStream_t s);
+void u8_to_float(const uint8_t* src, float* dst, int n, float scale, hipStream_t s);
 void launch_clahe(const uint8_t* frame, size_t fstride, const CropDesc* crops_dev, int n, uint8_t* lab,
                   uint8_t* luts, uint8_t* bgr_out, const ColorTables& T, int max_pixels, hipStream_t s);
 void launch_crop_norm(const uint8_t* frame, size_t fstride, const uint8_t* scratch, const CropDesc* crops_dev,

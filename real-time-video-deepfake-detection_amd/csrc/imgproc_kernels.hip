@@ -76,6 +76,21 @@ void launch_resize_bgr(const uint8_t* src, int n, int sh, int sw, size_t sstride
                        sw, sstride, simg, dst, dh, dw);
 }
 
+void launch_resize_gray(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, hipStream_t s) {
+    hipLaunchKernelGGL(resize_linear_u8_kernel<1>, dim3((dh * dw + 255) / 256, 1), dim3(256), 0, s, src, sh, sw,
+                       (size_t)sw, 0, dst, dh, dw);
+}
+
+__global__ __launch_bounds__(256) void u8_to_float_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int n,
+                                                          float scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i] * scale;
+}
+
+void u8_to_float(const uint8_t* src, float* dst, int n, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(u8_to_float_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n, scale);
+}
+
 // ------------------------------------------------------------------------------ Lab
 __device__ __forceinline__ void bgr2lab(const ColorTables& T, int b, int g, int r, int& L, int& A, int& B) {
     const long long R_ = T.gamma[r], G_ = T.gamma[g], B_ = T.gamma[b];

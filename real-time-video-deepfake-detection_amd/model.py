@@ -149,4 +149,17 @@ class DeepfakeEfficientNet:
         return self.net._conv_head
 
 
-__all__ = ["DeepfakeEfficientNet", "DfdError"]
+def compute_frequency_features(image_bgr_or_rgb, size: int = 224, *, handle: Optional[Handle] = None):
+    """FFT log-magnitude + DCT features, (2, size, size) float32 in [0,1] (reference model.py:105-149),
+    computed on the GPU.  Only ``size=224`` (the one value the reference ever passes,
+    deepfake_detection.py:392) is built."""
+    if size != 224:
+        raise ValueError("compute_frequency_features is built for size=224 only")
+    if handle is None:
+        from . import runtime
+
+        handle = runtime.default_handle()
+    return handle.frequency_features(image_bgr_or_rgb)
+
+
+__all__ = ["DeepfakeEfficientNet", "DfdError", "compute_frequency_features"]
