@@ -33,6 +33,17 @@ struct ConvGeom {
 bool launch_conv_gemm(const float* X, const float* W, const float* bias, const float* R, float* Y,
                       int n_img, const ConvGeom& g, int Cout, int act, bool res_first, hipStream_t s);
 
+// Split-precision variants (gemm_split.hip): same contracts, the weight operand is the three-plane bf16 split
+// of W [N][K] written by launch_split_weights (out: 3 * split_weights_count(N, K) bf16, zero-padded planes).
+// fp32-exact products, fp32 accumulate.
+size_t split_weights_count(int N, int K);
+void launch_split_weights(const float* W, unsigned short* out, int N, int K, hipStream_t s);
+bool split_gemm_supports(int K, int N);
+void launch_pointwise_split(const float* X, const unsigned short* W3, const float* bias, const float* gate,
+                            const float* R, float* Y, int M, int K, int N, int HW, int act, hipStream_t s);
+bool launch_conv_gemm_split(const float* X, const unsigned short* W3, const float* bias, const float* R, float* Y,
+                            int n_img, const ConvGeom& g, int Cout, int act, bool res_first, hipStream_t s);
+
 // depthwise kxk conv (k in {3,5}, stride in {1,2}, TF-SAME pad) + folded BN + swish, and
 // per-tile channel sums for the squeeze-excite pool: P[n][tile][c].  Returns the tile count
 // through *tiles.  Only the 16 shape classes of EfficientNet-B0 at 224x224 are instantiated.

@@ -136,6 +136,33 @@ int b0_build_plan(dfd_handle* h) {
     return ok ? DFD_OK : DFD_ERR_BLOB;
 }
 
+const unsigned short* split_weights(dfd_handle* h, const float* W, int N, int K) {
+    const size_t count = split_weights_count(N, K);
+    auto it = h->wsplit.find(W);
+    if (it != h->wsplit.end()) return it->second;
+    void* p = nullptr;
+    if (hipMalloc(&p, count * 3 * sizeof(unsigned short)) != hipSuccess) {
+        fail(h, DFD_ERR_HIP, "hipMalloc of %zu bytes for split weights failed", count * 6);
+        return nullptr;
+    }
+    h->owned.push_back(p);
+    launch_split_weights(W, static_cast<unsigned short*>(p), N, K, h->stream);
+    h->wsplit[W] = static_cast<unsigned short*>(p);
+    return static_cast<unsigned short*>(p);
+}
+
+int pointwise(dfd_handle* h, const float* X, const float* W, const float* bias, const float* gate, const float* R,
+              float* Y, int M, int K, int N, int HW, int act) {
+    if (h->split_gemm && N >= 16 && split_gemm_supports(K, N)) {       // never on M: batch-invariant results
+        const unsigned short* w3 = split_weights(h, W, N, K);
+        if (!w3) return DFD_ERR_HIP;
+        launch_pointwise_split(X, w3, bias, gate, R, Y, M, K, N, HW, act, h->stream);
+    } else {
+        launch_pointwise(X, W, bias, gate, R, Y, M, K, N, HW, act, h->stream);
+    }
+    return DFD_OK;
+}
+
 namespace {
 
 struct Marks {
@@ -211,8 +238,8 @@ int b0_forward(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* t
                                               "(dfd_set_option(h, \"fuse_expand\", 0))", tap->name);
         }
         if (!fused && b.expand != 1) {
-            launch_pointwise(cur, b.exp_w, b.exp_b, nullptr, nullptr, h->expbuf, m_in, b.c_in, b.c_exp,
-                             b.h_in * b.h_in, ACT_SWISH, s);
+            if ((rc = pointwise(h, cur, b.exp_w, b.exp_b, nullptr, nullptr, h->expbuf, m_in, b.c_in, b.c_exp,
+                                b.h_in * b.h_in, ACT_SWISH))) return rc;
             mk.mark(layer_name(bi, "exp"));
             if ((rc = tap_out(h, tap, q + ".exp", h->expbuf, (size_t)m_in * b.c_exp))) return rc;
             dw_in = h->expbuf;
@@ -230,8 +257,8 @@ int b0_forward(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* t
                   h->gate, n, b.c_exp, b.c_se, s);
         mk.mark(layer_name(bi, "se"));
         if ((rc = tap_out(h, tap, q + ".gate", h->gate, (size_t)n * b.c_exp))) return rc;
-        launch_pointwise(h->dwbuf, b.proj_w, b.proj_b, h->gate, b.skip ? cur : nullptr, nxt, m_out,
-                         b.c_exp, b.c_out, b.h_out * b.h_out, ACT_NONE, s);
+        if ((rc = pointwise(h, h->dwbuf, b.proj_w, b.proj_b, h->gate, b.skip ? cur : nullptr, nxt, m_out,
+                            b.c_exp, b.c_out, b.h_out * b.h_out, ACT_NONE))) return rc;
         mk.mark(layer_name(bi, "proj"));
         if ((rc = tap_out(h, tap, q + ".out", nxt, (size_t)m_out * b.c_out))) return rc;
         float* t = cur; cur = nxt; nxt = t;
@@ -239,8 +266,8 @@ int b0_forward(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* t
     }
     const B0Block& last = P.blocks.back();
     const int hw = last.h_out * last.h_out;
-    launch_pointwise(cur, P.head_w, P.head_b, nullptr, nullptr, h->headbuf, n * hw, last.c_out, 1280, hw,
-                     ACT_SWISH, s);
+    if ((rc = pointwise(h, cur, P.head_w, P.head_b, nullptr, nullptr, h->headbuf, n * hw, last.c_out, 1280, hw,
+                        ACT_SWISH))) return rc;
     mk.mark("head");
     if ((rc = tap_out(h, tap, "head", h->headbuf, (size_t)n * hw * 1280))) return rc;
     launch_avgpool(h->headbuf, h->feat, n, hw, 1280, s);

@@ -28,6 +28,7 @@ int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, in
     h->max_batch = max_batch;
     if (const char* e = getenv("DFD_FUSE_EXPAND")) h->fuse_expand = atoi(e) != 0;
     if (const char* e = getenv("DFD_FUSE_STEM")) h->fuse_stem = atoi(e) != 0;
+    if (const char* e = getenv("DFD_SPLIT_GEMM")) h->split_gemm = atoi(e) != 0;
     DFD_HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     DFD_HIP_TRY(h, hipEventCreate(&h->ev0));
     DFD_HIP_TRY(h, hipEventCreate(&h->ev1));
@@ -117,6 +118,7 @@ int dfd_set_option(dfd_handle* h, const char* name, int value) {
     if (!h || !name) return DFD_ERR_ARG;
     if (strcmp(name, "fuse_expand") == 0) { h->fuse_expand = value != 0; return DFD_OK; }
     if (strcmp(name, "fuse_stem") == 0) { h->fuse_stem = value != 0; return DFD_OK; }
+    if (strcmp(name, "split_gemm") == 0) { h->split_gemm = value != 0; return DFD_OK; }
     return fail(h, DFD_ERR_ARG, "unknown option '%s'", name);
 }
 

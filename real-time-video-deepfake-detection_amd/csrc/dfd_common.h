@@ -91,6 +91,8 @@ struct dfd_handle {
     dfd::SsdState* ssd = nullptr;             // detector plan + workspace (null: blob has no detector)
     bool fuse_stem = true;               // stem conv computed inside block 0's depthwise kernel
     bool fuse_expand = true;             // MBConv blocks 1-5: expand conv computed inside the depthwise kernel
+    bool split_gemm = true;              // 1x1 / k x k convs on the bf16x3-split MFMA path (gemm_split.hip)
+    std::map<const float*, unsigned short*> wsplit;   // fp32 weight tensor -> its three-plane bf16 split
     dfd::B0Prof prof;                    // layer events between profile_begin/end
     int prof_steps = 0;
     std::string err;
@@ -130,7 +132,12 @@ int detect_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, in
 int forensics_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes,
                         double* prob_out, double* scores_out);
 
-// b0_plan.cpp
+// b0_plan.hip
+// three-plane bf16 split of a weight tensor of the handle, made on first use; null (+ error set) on failure
+const unsigned short* split_weights(dfd_handle* h, const float* W, int N, int K);
+// 1x1 conv through the split path when enabled and the shape allows, else the fp32 MFMA kernel
+int pointwise(dfd_handle* h, const float* X, const float* W, const float* bias, const float* gate, const float* R,
+              float* Y, int M, int K, int N, int HW, int act);
 int b0_build_plan(dfd_handle* h);
 // Runs the classifier on h->stream.  `stop_at_features`: leave after the pooled 1280-vector.
 int b0_forward(dfd_handle* h, const float* nchw_dev, int n, float* logits_dev, B0Tap* tap,

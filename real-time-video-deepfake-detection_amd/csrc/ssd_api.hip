@@ -83,6 +83,18 @@ static const float* wt(dfd_handle* h, const std::string& name, size_t count, boo
     return it->second.dev;
 }
 
+// k x k conv on the split-precision MFMA path when enabled, else on the fp32 MFMA kernel
+static bool conv_gemm(dfd_handle* h, const float* X, const float* W, const float* bias, const float* R, float* Y,
+                      int n, const ConvGeom& g, int Cout, int act, bool res_first) {
+    if (!W) return true;                                     // missing tensor: reported by wt()
+    const int K = g.ksize * g.ksize * g.Cin;
+    if (h->split_gemm && g.Cin % 32 == 0 && split_gemm_supports(K, Cout)) {
+        const unsigned short* w3 = split_weights(h, W, Cout, K);
+        if (w3 && launch_conv_gemm_split(X, w3, bias, R, Y, n, g, Cout, act, res_first, h->stream)) return true;
+    }
+    return launch_conv_gemm(X, W, bias, R, Y, n, g, Cout, act, res_first, h->stream);
+}
+
 // shapes, per-image workspace layout and the prior table
 int ssd_init(dfd_handle* h) {
     if (h->tensors.find("ssd.conv1.w") == h->tensors.end()) return DFD_OK;      // blob without a detector
@@ -214,9 +226,9 @@ int ssd_forward(dfd_handle* h, const uint8_t* in300, int n, const char* tap_name
                 ConvGeom g;
                 g.H = g.W = src.size; g.Ho = g.Wo = dst.size; g.Cin = L.cin; g.ksize = L.k; g.stride = L.stride;
                 g.pad = L.pad; g.dil = L.dil;
-                if (!launch_conv_gemm(ptr(L.src), W_(q + ".w", (size_t)L.cout * L.k * L.k * L.cin), W_(q + ".b", L.cout),
-                                      L.res ? ptr(L.res) : nullptr, ptr(L.name), n, g, L.cout,
-                                      L.relu ? ACT_RELU : ACT_NONE, true, s))
+                if (!conv_gemm(h, ptr(L.src), W_(q + ".w", (size_t)L.cout * L.k * L.k * L.cin), W_(q + ".b", L.cout),
+                               L.res ? ptr(L.res) : nullptr, ptr(L.name), n, g, L.cout,
+                               L.relu ? ACT_RELU : ACT_NONE, true))
                     return fail(h, DFD_ERR_STATE, "detector layer %s: C_in not a multiple of 32", L.name);
                 break;
             }
@@ -232,8 +244,8 @@ int ssd_forward(dfd_handle* h, const uint8_t* in300, int n, const char* tap_name
         const std::string hn = std::string(src.tensor) + ".head", q = std::string("ssd.") + src.tensor + ".head";
         ConvGeom g;
         g.H = g.W = g.Ho = g.Wo = src.map; g.Cin = src.c; g.ksize = 3; g.stride = 1; g.pad = 1; g.dil = 1;
-        launch_conv_gemm(ptr(src.tensor), W_(q + ".w", (size_t)p * 6 * 9 * src.c), W_(q + ".b", p * 6), nullptr, ptr(hn), n,
-                         g, p * 6, ACT_NONE, false, s);
+        conv_gemm(h, ptr(src.tensor), W_(q + ".w", (size_t)p * 6 * 9 * src.c), W_(q + ".b", p * 6), nullptr, ptr(hn), n,
+                  g, p * 6, ACT_NONE, false);
         if ((rc = tap(hn))) return rc;
         H.out[i] = ptr(hn);
         H.first[i] = first;
