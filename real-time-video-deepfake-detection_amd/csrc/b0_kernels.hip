@@ -423,7 +423,7 @@ __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* 
 }
 
 template <int K, int S, int CB, int TH, int TW, int RP>
-__global__ __launch_bounds__(256, 4) void dw_kernel(const float* __restrict__ X,
+__global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const float* __restrict__ X,
                                                  const float* __restrict__ Wt,
                                                  const float* __restrict__ bias,
                                                  float* __restrict__ Y, float* __restrict__ P,

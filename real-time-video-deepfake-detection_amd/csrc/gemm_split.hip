@@ -24,6 +24,8 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <type_traits>
+#include <vector>
 
 namespace dfd {
 
@@ -31,8 +33,14 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));      // (HIP's uint4 struct does not always leave the stack)
 
 constexpr int S6_BK = 32;                 // K per LDS stage = K of one MFMA
-// rows of a zero-padded weight plane: the last n-block of any tile (NT <= 8) stays inside it
-__host__ __device__ constexpr int s6_np(int N) { return ((N + 15) / 16 + 7) * 16; }
+#ifndef S6_XD
+#define S6_XD 3                           // pw6: K-steps of activation prefetch in flight (1 or 3)
+#endif
+#ifndef S6_WD
+#define S6_WD 2                           // K-steps of weight prefetch in flight (<= S6_XD in pw6, 1 or 2 in pw7)
+#endif
+// rows of a zero-padded weight plane: the last n-block of any tile (block width <= 192) stays inside it
+__host__ __device__ constexpr int s6_np(int N) { return ((N + 15) / 16 + 11) * 16; }
 constexpr int S6_ROWB = 3 * 64;           // bytes per weight row per stage: 3 planes x 32 bf16 = twelve 16-byte chunks
 // LDS image of a row: chunk c (= plane * 4 + k-octet) sits at chunk position (c + 6 * ((row >> 2) & 1)) % 12.
 // ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) with bank = dword % 64
@@ -84,6 +92,47 @@ __device__ __forceinline__ void split8(const v4f lo, const v4f hi, bf8& s0, bf8&
     }
 }
 
+// epilogue shared by both kernels: the lane holds Y[m[mt]][n .. n+3] for n = nbase + 16 * nt
+template <int MT, int NT>
+__device__ __forceinline__ void s6_epilogue(const v4f (&acc)[MT][NT], const int (&m)[MT], int nbase,
+                                            const float* __restrict__ bias, const float* __restrict__ R,
+                                            float* __restrict__ Y, int M, int N, int act, int res_first) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nbase + nt * 16;
+        if (n >= N) continue;
+        const bool vec = n + 3 < N;
+        v4f bv = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (vec) bv = ldg4(bias + n);
+        else
+            for (int r = 0; r < 4; ++r)
+                if (n + r < N) bv[r] = bias[n + r];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (m[mt] >= M) continue;
+            v4f v = acc[mt][nt] + bv;
+            v4f rv = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (R) {
+                if (vec) rv = ldg4(R + (size_t)m[mt] * N + n);
+                else
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < N) rv[r] = R[(size_t)m[mt] * N + n + r];
+            }
+            if (res_first) v += rv;
+            if (act == ACT_SWISH) v = swish4(v);
+            else if (act == ACT_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (!res_first) v += rv;
+            float* yp = Y + (size_t)m[mt] * N + n;
+            if (vec) stg4(yp, v);
+            else
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < N) yp[r] = v[r];
+        }
+    }
+}
+
 template <int NT, bool CONV, int MT, bool GATE>
 __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X,
                                                      const unsigned short* __restrict__ W3, int plane, int Kp,
@@ -92,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
                                                      const float* __restrict__ R,
                                                      float* __restrict__ Y, int M, int K, int N,
                                                      int HW, int act, int mblocks, int nblocks,
-                                                     ConvGeom cg, int res_first) {
+                                                     ConvGeom cg, int res_first, unsigned xbytes, unsigned gbytes) {
     constexpr int BK = S6_BK;
     constexpr int BN = NT * 16, BM = 4 * MT * 16;
     constexpr int CHUNKS = BN * 12;                       // 16-byte chunks per stage: row x plane x k-octet
@@ -132,37 +181,71 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+    // Operands come through buffer loads: a per-lane byte offset fixed for the whole K loop (VGPR) plus the K
+    // position as the scalar offset, so a K-step costs no vector address arithmetic and no clamps.
+    //
     // weight chunk t of this thread: (row, plane, k-octet) -> fixed global / LDS offsets.  The planes are
     // zero-padded to [Np][Kp], so loads and LDS stores are unconditional and select-free (k >= K meets zero
-    // weights, whatever the clamped X load returned); threads past the last chunk repeat the last chunk (same
-    // value to the same address).  A store under a branch makes hipcc sink the global load into that branch
-    // with a vmcnt(0) behind it: one exposed memory latency per K-step.
-    int woff[WLOADS], wlds[WLOADS];
+    // weights, whatever the X load returned); threads past the last chunk repeat the last chunk (same value to
+    // the same address).  A store under a branch makes hipcc sink the global load into that branch with a
+    // vmcnt(0) behind it: one exposed memory latency per K-step.
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W3), 0, 6 * plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATE ? gate : X), 0, GATE ? gbytes : xbytes, 0x00020000);
+    int wvo[WLOADS], wlds[WLOADS];
 #pragma unroll
     for (int t = 0; t < WLOADS; ++t) {
         const int e = tid + t * 256 < CHUNKS ? tid + t * 256 : CHUNKS - 1;
         const int row = e / 12, rem = e - row * 12, pl = rem >> 2, c = rem & 3;
-        woff[t] = pl * plane + (n0 + row) * Kp + 8 * c;
+        wvo[t] = 2 * (pl * plane + (n0 + row) * Kp + 8 * c);
         wlds[t] = row * S6_ROWB + s6_chunk_pos(row, pl * 4 + c) * 16;
     }
-    u4 wreg[WLOADS];
-    auto load_w = [&](int kc) {
-#pragma unroll
-        for (int t = 0; t < WLOADS; ++t) wreg[t] = *reinterpret_cast<const u4*>(W3 + woff[t] + kc);
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int t = 0; t < WLOADS; ++t) *reinterpret_cast<u4*>(&ws[buf][wlds[t]]) = wreg[t];
-    };
 
-    int mclamp[MT];
+    // Register rings: the activation stream comes from HBM / Infinity Cache (1-2 us under load, several
+    // K-steps of MFMA work at these tile sizes) and is prefetched XD steps ahead; weights and gates are L2
+    // hits and stay one step ahead.  The K loop is unrolled by the ring size U = XD + 1, so every ring slot is
+    // a fixed register set and nothing is ever copied into place.
+    constexpr int XD = MT == 1 ? S6_XD : 1, U = XD + 1;      // the deep rings of MT = 2 do not fit 256 VGPRs
+    static_assert(U % 2 == 0, "the LDS / gate ping-pong needs an even unroll");
+    constexpr int WD = MT == 1 ? S6_WD : 1;
+    static_assert(WD >= 1 && WD <= XD, "weight prefetch distance");
+    u4 wr[U][WLOADS];      // weights in flight: slot = K-step % U (WD slots live at a time)
+    v4f xr[U][MT][2];
+    v4f gr[2][MT][2];      // GATE: raw squeeze-excite gate fragments, multiplied in at use
+    bool okr[U][MT];       // CONV: tap inside the image (zero padding applied at use)
+    const int nk = (K + BK - 1) / BK;
+    // X / gate rows are not padded: in the last K-step of a K that is not a multiple of 32, lanes past the row
+    // end re-read its last 8 values instead (they meet zero weights)
+    int xvo[MT], xvo_last[MT], gvo[MT], gvo_last[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) mclamp[mt] = m[mt] < M ? m[mt] : M - 1;
-
-    v4f xcur[MT][2], xnext[MT][2];
-    v4f gcur[MT][2], gnext[MT][2];      // GATE: raw squeeze-excite gate fragments, multiplied in at use
-    bool okcur[MT], oknext[MT];         // CONV: tap inside the image (zero padding applied at use)
-    auto load_x = [&](int kc, v4f (&xf)[MT][2], v4f (&gf)[MT][2], bool (&okf)[MT]) {
+    for (int mt = 0; mt < MT; ++mt) {
+        const int mc = m[mt] < M ? m[mt] : M - 1;
+        const int over = (nk - 1) * BK + 8 * q - (K - 8);
+        xvo[mt] = 4 * (mc * K + 8 * q);
+        xvo_last[mt] = xvo[mt] - 4 * (over > 0 ? over : 0);
+        gvo[mt] = 4 * ((int)gbase[mt] + 8 * q);
+        gvo_last[mt] = gvo[mt] - 4 * (over > 0 ? over : 0);
+    }
+    auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int vo, int so) {
+        return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
+    };
+    auto load_w = [&](int kstep, u4 (&w)[WLOADS]) {
+#pragma unroll
+        for (int t = 0; t < WLOADS; ++t) w[t] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[t], 2 * kstep * BK, 0);
+    };
+    auto load_g = [&](int kstep, v4f (&g)[MT][2]) {
+        if constexpr (GATE) {
+            const bool last = kstep == nk - 1;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int go = last ? gvo_last[mt] : gvo[mt];
+                g[mt][0] = ld(rg, go, 4 * kstep * BK);
+                g[mt][1] = ld(rg, go + 16, 4 * kstep * BK);
+            }
+        }
+    };
+    auto load_x = [&](int kstep, v4f (&x)[MT][2], bool (&okf)[MT]) {
+        const int kc = kstep * BK;
         if constexpr (CONV) {
             const int tap = kc / cg.Cin, ci0 = kc - tap * cg.Cin;      // wave-uniform
             const int ky = tap / cg.ksize, kx = tap - ky * cg.ksize;
@@ -170,52 +253,40 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
             for (int mt = 0; mt < MT; ++mt) {
                 const int iy = iy0[mt] + ky * cg.dil, ix = ix0[mt] + kx * cg.dil;
                 const bool ok = m[mt] < M && (unsigned)iy < (unsigned)cg.H && (unsigned)ix < (unsigned)cg.W;
-                const float* p = X + gbase[mt] + ((size_t)(ok ? iy : 0) * cg.W + (ok ? ix : 0)) * cg.Cin + ci0 + 8 * q;
-                xf[mt][0] = ldg4(p);
-                xf[mt][1] = ldg4(p + 4);
+                const int vo = 4 * ((int)gbase[mt] + ((ok ? iy : 0) * cg.W + (ok ? ix : 0)) * cg.Cin + 8 * q);
+                x[mt][0] = ld(rx, vo, 4 * ci0);
+                x[mt][1] = ld(rx, vo + 16, 4 * ci0);
                 okf[mt] = ok;
             }
         } else {
+            const bool last = kstep == nk - 1;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                int k = kc + 8 * q;
-                k = k < K ? k : K - 8;
-                const float* p = X + (size_t)mclamp[mt] * K + k;
-                xf[mt][0] = ldg4(p);
-                xf[mt][1] = ldg4(p + 4);
-                if constexpr (GATE) {
-                    gf[mt][0] = ldg4(gate + gbase[mt] + k);
-                    gf[mt][1] = ldg4(gate + gbase[mt] + k + 4);
-                }
+                const int vo = last ? xvo_last[mt] : xvo[mt];
+                x[mt][0] = ld(rx, vo, 4 * kc);
+                x[mt][1] = ld(rx, vo + 16, 4 * kc);
                 okf[mt] = true;
             }
         }
     };
+    auto store_w = [&](const u4 (&w)[WLOADS], int buf) {
+#pragma unroll
+        for (int t = 0; t < WLOADS; ++t) *reinterpret_cast<u4*>(&ws[buf][wlds[t]]) = w[t];
+    };
 
     const int rd0 = s6_chunk_pos(j, q) * 16, rd1 = s6_chunk_pos(j, 4 + q) * 16, rd2 = s6_chunk_pos(j, 8 + q) * 16;
-    const int nk = (K + BK - 1) / BK;
-    load_w(0);
-    load_x(0, xcur, gcur, okcur);
-    store_w(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        // branch-free body; the last iteration re-loads its own step (see pw_kernel)
-        const int kn = (kt + 1 < nk ? kt + 1 : kt) * BK;
-        load_w(kn);
-        load_x(kn, xnext, gnext, oknext);
-        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch at the top of the step: a whole step to land
-
+    auto compute = [&](const v4f (&x)[MT][2], const v4f (&g)[MT][2], const bool (&okf)[MT], int buf) {
         bf8 xs[MT][3];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            v4f lo = xcur[mt][0], hi = xcur[mt][1];
-            if constexpr (GATE) { lo *= gcur[mt][0]; hi *= gcur[mt][1]; }
+            v4f lo = x[mt][0], hi = x[mt][1];
+            if constexpr (GATE) { lo *= g[mt][0]; hi *= g[mt][1]; }
             if constexpr (CONV) {
-                if (!okcur[mt]) { lo = (v4f){0.f, 0.f, 0.f, 0.f}; hi = lo; }
+                if (!okf[mt]) { lo = (v4f){0.f, 0.f, 0.f, 0.f}; hi = lo; }
             }
             split8(lo, hi, xs[mt][0], xs[mt][1], xs[mt][2]);
         }
-        const unsigned char* wb = ws[kt & 1];
+        const unsigned char* wb = ws[buf];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const unsigned char* wp = wb + (nt * 16 + j) * S6_ROWB;       // (nt * 16 + j) >> 2 has the parity of j >> 2
@@ -236,71 +307,285 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xs[mt][0], acc[mt][nt], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);      // ... and its consumers at the bottom
-        store_w((kt + 1) & 1);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            xcur[mt][0] = xnext[mt][0];
-            xcur[mt][1] = xnext[mt][1];
-            if constexpr (GATE) {
-                gcur[mt][0] = gnext[mt][0];
-                gcur[mt][1] = gnext[mt][1];
-            }
-            okcur[mt] = oknext[mt];
-        }
+    };
+    // One pipelined step, ring slot u = kstep % U: issue the loads (gate of step + 1, weights of step + WD,
+    // activations of step + XD, clamped to the last step: the repeats are never consumed), compute the step,
+    // then hand the weights of step + 1 to the other LDS buffer.  Every operand needs more than one step to
+    // arrive (an L2 hit is ~1 us under this load, a step of MFMAs 0.3-0.6 us), hence the rings.
+    // The sched_barriers keep the loads at the top (a whole step to land) and their first consumers at the
+    // bottom; left alone, hipcc sinks the loads to the end of the step and waits for them at once.
+    auto step = [&](auto uc, int kstep) {
+        constexpr int u = decltype(uc)::value;
+        const int k1 = kstep + 1 < nk ? kstep + 1 : nk - 1, kw = kstep + WD < nk ? kstep + WD : nk - 1,
+                  kd = kstep + XD < nk ? kstep + XD : nk - 1;
+        load_g(k1, gr[(u + 1) & 1]);
+        load_w(kw, wr[(u + WD) % U]);
+        load_x(kd, xr[(u + XD) % U], okr[(u + XD) % U]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(xr[u], gr[u & 1], okr[u], u & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_w(wr[(u + 1) % U], (u + 1) & 1);
         __syncthreads();
-    }
+    };
 
-    // epilogue: lane holds Y[m][n .. n+3]
+    load_w(0, wr[0]);
+    load_g(0, gr[0]);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + nt * 16 + 4 * q;
-        if (n >= N) continue;
-        const bool vec = n + 3 < N;
-        v4f bv = (v4f){0.f, 0.f, 0.f, 0.f};
-        if (vec) bv = ldg4(bias + n);
-        else
-            for (int r = 0; r < 4; ++r)
-                if (n + r < N) bv[r] = bias[n + r];
+    for (int d = 1; d < WD; ++d) load_w(d < nk ? d : nk - 1, wr[d]);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (m[mt] >= M) continue;
-            v4f v = acc[mt][nt] + bv;
-            v4f rv = (v4f){0.f, 0.f, 0.f, 0.f};
-            if (R) {
-                if (vec) rv = ldg4(R + (size_t)m[mt] * N + n);
-                else
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < N) rv[r] = R[(size_t)m[mt] * N + n + r];
-            }
-            if (res_first) v += rv;
-            if (act == ACT_SWISH) v = swish4(v);
-            else if (act == ACT_RELU) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-            if (!res_first) v += rv;
-            float* yp = Y + (size_t)m[mt] * N + n;
-            if (vec) stg4(yp, v);
-            else
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < N) yp[r] = v[r];
+    for (int d = 0; d < XD; ++d) load_x(d < nk ? d : nk - 1, xr[d], okr[d]);
+    store_w(wr[0], 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + U <= nk; kt += U) {
+        step(std::integral_constant<int, 0>{}, kt);
+        step(std::integral_constant<int, 1>{}, kt + 1);
+        if constexpr (U == 4) {
+            step(std::integral_constant<int, 2>{}, kt + 2);
+            step(std::integral_constant<int, 3>{}, kt + 3);
         }
     }
+    // remainder (kt is a multiple of U here, so slot u = step - kt)
+    if (kt < nk) step(std::integral_constant<int, 0>{}, kt);
+    if constexpr (U == 4) {
+        if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
+        if (kt + 2 < nk) step(std::integral_constant<int, 2>{}, kt + 2);
+    }
+
+    s6_epilogue<MT, NT>(acc, m, n0 + 4 * q, bias, R, Y, M, N, act, res_first);
 }
 
-struct S6Tile { int mt, nt, mblocks, nblocks; };
-static S6Tile make_tile(int M, int N, int mt, int nt) {
-    return S6Tile{mt, nt, (M + 64 * mt - 1) / (64 * mt), ((N + 15) / 16 + nt - 1) / nt};
+// ------------------------------------------------------------------------------------------------------
+// pw7_kernel: both operands through LDS.  In pw6 every wave owns its rows and splits its own activation
+// fragments: ~45 VALU instructions per 16 rows x 32 k, repeated by every n-block, next to only 6 * NT MFMAs -
+// with few rows (batch * 49 or * 196) there are too few waves to hide that.  Here the 4 waves form a WM x WN
+// grid over a (WM*MT*16) x (WN*NT*16) block tile: the activation tile is split ONCE per block, cooperatively
+// (each thread 8 values of one row per 64 rows), written to LDS as three bf16 planes in the same rotated row
+// image as the weights, and every wave reads the MT fragments it needs.  MFMAs per split instruction go up by
+// WN * NT / (pw6's NT): the kernel for small M and for wide N.
+// The raw activations are prefetched two K-steps ahead (register ring of two, the K loop is unrolled by two),
+// the weights one step ahead.
+template <int WM, int WN, int MT, int NT, bool CONV, bool GATE>
+__global__ __launch_bounds__(256, 2) void pw7_kernel(const float* __restrict__ X,
+                                                     const unsigned short* __restrict__ W3, int plane, int Kp,
+                                                     const float* __restrict__ bias,
+                                                     const float* __restrict__ gate,
+                                                     const float* __restrict__ R,
+                                                     float* __restrict__ Y, int M, int K, int N,
+                                                     int HW, int act, int mblocks, int nblocks,
+                                                     ConvGeom cg, int res_first, unsigned xbytes, unsigned gbytes) {
+    static_assert(WM * WN == 4, "four waves per block");
+    constexpr int BK = S6_BK;
+    constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
+    constexpr int WCHUNKS = BN * 12, WLOADS = (WCHUNKS + 255) / 256;
+    constexpr int XUNITS = BM * 4, XL = (XUNITS + 255) / 256;      // unit = 8 consecutive k of one row
+    __shared__ __attribute__((aligned(16))) unsigned char ws[2][BN * S6_ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char xsm[2][BM * S6_ROWB];
+
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int mblk = (idx / nblocks) * 8 + xcd, nblk = idx % nblocks;
+    if (mblk >= mblocks) return;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = mblk * BM, n0 = nblk * BN;
+
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W3), 0, 6 * plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATE ? gate : X), 0, GATE ? gbytes : xbytes, 0x00020000);
+    auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int vo, int so) {
+        return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
+    };
+    const int nk = (K + BK - 1) / BK;
+
+    // weight chunks of this thread (as in pw6)
+    int wvo[WLOADS], wlds[WLOADS];
+#pragma unroll
+    for (int t = 0; t < WLOADS; ++t) {
+        const int e = tid + t * 256 < WCHUNKS ? tid + t * 256 : WCHUNKS - 1;
+        const int row = e / 12, rem = e - row * 12, pl = rem >> 2, c = rem & 3;
+        wvo[t] = 2 * (pl * plane + (n0 + row) * Kp + 8 * c);
+        wlds[t] = row * S6_ROWB + s6_chunk_pos(row, pl * 4 + c) * 16;
+    }
+    // activation units of this thread: row = unit / 4, k-octet = unit % 4 (4 lanes = 128 contiguous bytes)
+    int xvo[XL], xvo_last[XL], gvo[XL], gvo_last[XL], xlds[XL][3];
+    int ubase[XL], uy0[XL], ux0[XL];
+    bool uvalid[XL];
+#pragma unroll
+    for (int t = 0; t < XL; ++t) {
+        const int e = tid + t * 256 < XUNITS ? tid + t * 256 : XUNITS - 1;
+        const int row = e >> 2, ko = e & 3;
+        const int mm = m0 + row;
+        const int mc = mm < M ? mm : M - 1;
+        uvalid[t] = mm < M;
+        const int over = (nk - 1) * BK + 8 * ko - (K - 8);
+        if constexpr (CONV) {
+            const int img = mc / (cg.Ho * cg.Wo), r = mc - img * (cg.Ho * cg.Wo);
+            const int oy = r / cg.Wo, ox = r - oy * cg.Wo;
+            ubase[t] = img * cg.H * cg.W * cg.Cin + 8 * ko;
+            uy0[t] = oy * cg.stride - cg.pad;
+            ux0[t] = ox * cg.stride - cg.pad;
+            xvo[t] = xvo_last[t] = gvo[t] = gvo_last[t] = 0;
+        } else {
+            ubase[t] = uy0[t] = ux0[t] = 0;
+            xvo[t] = 4 * (mc * K + 8 * ko);
+            xvo_last[t] = xvo[t] - 4 * (over > 0 ? over : 0);
+            gvo[t] = GATE ? 4 * ((mc / HW) * K + 8 * ko) : 0;
+            gvo_last[t] = gvo[t] - 4 * (over > 0 ? over : 0);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xlds[t][pl] = row * S6_ROWB + s6_chunk_pos(row, pl * 4 + ko) * 16;
+    }
+
+    u4 wr[2][WLOADS];      // weights, ring of two K-steps
+    v4f xr[2][XL][2];      // raw activations, ring of two K-steps
+    v4f gr[2][XL][2];      // GATE: raw squeeze-excite gate
+    bool okr[2][XL];       // CONV: tap inside the image
+    auto load_w = [&](int kstep, u4 (&w)[WLOADS]) {
+#pragma unroll
+        for (int t = 0; t < WLOADS; ++t) w[t] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[t], 2 * kstep * BK, 0);
+    };
+    auto load_x = [&](int kstep, v4f (&x)[XL][2], v4f (&g)[XL][2], bool (&okf)[XL]) {
+        const int kc = kstep * BK;
+        if constexpr (CONV) {
+            const int tap = kc / cg.Cin, ci0 = kc - tap * cg.Cin;      // block-uniform
+            const int ky = tap / cg.ksize, kx = tap - ky * cg.ksize;
+#pragma unroll
+            for (int t = 0; t < XL; ++t) {
+                const int iy = uy0[t] + ky * cg.dil, ix = ux0[t] + kx * cg.dil;
+                const bool ok = uvalid[t] && (unsigned)iy < (unsigned)cg.H && (unsigned)ix < (unsigned)cg.W;
+                const int vo = 4 * (ubase[t] + ((ok ? iy : 0) * cg.W + (ok ? ix : 0)) * cg.Cin);
+                x[t][0] = ld(rx, vo, 4 * ci0);
+                x[t][1] = ld(rx, vo + 16, 4 * ci0);
+                okf[t] = ok;
+            }
+        } else {
+            const bool last = kstep == nk - 1;
+#pragma unroll
+            for (int t = 0; t < XL; ++t) {
+                const int vo = last ? xvo_last[t] : xvo[t];
+                x[t][0] = ld(rx, vo, 4 * kc);
+                x[t][1] = ld(rx, vo + 16, 4 * kc);
+                if constexpr (GATE) {
+                    const int go = last ? gvo_last[t] : gvo[t];
+                    g[t][0] = ld(rg, go, 4 * kc);
+                    g[t][1] = ld(rg, go + 16, 4 * kc);
+                }
+                okf[t] = true;
+            }
+        }
+    };
+    auto store_w = [&](const u4 (&w)[WLOADS], int buf) {
+#pragma unroll
+        for (int t = 0; t < WLOADS; ++t) *reinterpret_cast<u4*>(&ws[buf][wlds[t]]) = w[t];
+    };
+    // split this thread's units and write the three planes into the block's activation tile
+    auto store_x = [&](const v4f (&x)[XL][2], const v4f (&g)[XL][2], const bool (&okf)[XL], int buf) {
+#pragma unroll
+        for (int t = 0; t < XL; ++t) {
+            v4f lo = x[t][0], hi = x[t][1];
+            if constexpr (GATE) { lo *= g[t][0]; hi *= g[t][1]; }
+            if constexpr (CONV) {
+                if (!okf[t]) { lo = (v4f){0.f, 0.f, 0.f, 0.f}; hi = lo; }
+            }
+            bf8 s0, s1, s2;
+            split8(lo, hi, s0, s1, s2);
+            *reinterpret_cast<bf8*>(&xsm[buf][xlds[t][0]]) = s0;
+            *reinterpret_cast<bf8*>(&xsm[buf][xlds[t][1]]) = s1;
+            *reinterpret_cast<bf8*>(&xsm[buf][xlds[t][2]]) = s2;
+        }
+    };
+
+    v4f acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    const int rd0 = s6_chunk_pos(j, q) * 16, rd1 = s6_chunk_pos(j, 4 + q) * 16, rd2 = s6_chunk_pos(j, 8 + q) * 16;
+    auto compute = [&](int buf) {
+        bf8 xs[MT][3];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const unsigned char* xp = xsm[buf] + ((wm * MT + mt) * 16 + j) * S6_ROWB;
+            xs[mt][0] = *reinterpret_cast<const bf8*>(xp + rd0);
+            xs[mt][1] = *reinterpret_cast<const bf8*>(xp + rd1);
+            xs[mt][2] = *reinterpret_cast<const bf8*>(xp + rd2);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const unsigned char* wp = ws[buf] + ((wn * NT + nt) * 16 + j) * S6_ROWB;
+            const bf8 w0 = *reinterpret_cast<const bf8*>(wp + rd0);
+            const bf8 w1 = *reinterpret_cast<const bf8*>(wp + rd1);
+            const bf8 w2 = *reinterpret_cast<const bf8*>(wp + rd2);
+            // the same six products in the same order as pw6: a result never depends on the kernel or tile chosen
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, xs[mt][0], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xs[mt][1], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xs[mt][2], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xs[mt][0], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xs[mt][1], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xs[mt][0], acc[mt][nt], 0, 0, 0);
+        }
+    };
+    // step kstep, ring slot u = kstep & 1: loads for step + 2 (into the slots whose contents went to LDS at the
+    // bottom of the previous step); MFMAs of this step; then the tiles of step + 1 go to the other LDS buffers
+    // (weights as loaded, activations split) from the other ring slot.
+    auto step = [&](auto uc, int kstep) {
+        constexpr int u = decltype(uc)::value;
+        const int k2 = kstep + 2 < nk ? kstep + 2 : nk - 1;
+        load_w(k2, wr[u]);
+        load_x(k2, xr[u], gr[u], okr[u]);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(u);
+        __builtin_amdgcn_sched_barrier(0);
+        store_w(wr[u ^ 1], u ^ 1);
+        store_x(xr[u ^ 1], gr[u ^ 1], okr[u ^ 1], u ^ 1);
+        __syncthreads();
+    };
+
+    load_w(0, wr[0]);
+    load_x(0, xr[0], gr[0], okr[0]);
+    load_w(nk > 1 ? 1 : 0, wr[1]);
+    load_x(nk > 1 ? 1 : 0, xr[1], gr[1], okr[1]);
+    store_w(wr[0], 0);
+    store_x(xr[0], gr[0], okr[0], 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        step(std::integral_constant<int, 0>{}, kt);
+        step(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    if (kt < nk) step(std::integral_constant<int, 0>{}, kt);
+
+    int m[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) m[mt] = m0 + (wm * MT + mt) * 16 + j;
+    s6_epilogue<MT, NT>(acc, m, n0 + wn * NT * 16 + 4 * q, bias, R, Y, M, N, act, res_first);
 }
 
-// Heuristic tile (used when measuring is switched off): the biggest per-wave tile that still fills the chip.
+// kind 0: pw6 (block = 4 waves x MT*16 rows, NT*16 columns); kind 1: pw7 (WM x WN waves of MT x NT tiles)
+struct S6Tile { int kind, wm, wn, mt, nt, mblocks, nblocks; };
+static S6Tile make_tile(int M, int N, int kind, int wm, int wn, int mt, int nt) {
+    const int bm = wm * mt * 16, bn = wn * nt * 16;
+    return S6Tile{kind, wm, wn, mt, nt, (M + bm - 1) / bm, (N + bn - 1) / bn};
+}
+static S6Tile make_tile6(int M, int N, int mt, int nt) { return make_tile(M, N, 0, 4, 1, mt, nt); }
+
+// Heuristic tile (used when measuring is switched off): the biggest per-wave pw6 tile that still fills the chip.
 static S6Tile pick_tile6(int M, int N) {
     const int tiles = (N + 15) / 16;
-    S6Tile best = make_tile(M, N, 1, 1);
+    S6Tile best = make_tile6(M, N, 1, 1);
     double best_score = -1.0;
     for (int mt = 1; mt <= 2; ++mt)
         for (int nt = 1; nt <= 8; ++nt) {
-            const S6Tile t = make_tile(M, N, mt, nt);
+            const S6Tile t = make_tile6(M, N, mt, nt);
             const double blocks = (double)t.mblocks * t.nblocks;
             const double useful = (double)tiles / ((double)t.nblocks * nt);
             const double fill = blocks >= 512.0 ? 1.0 : blocks / 512.0;
@@ -311,6 +596,11 @@ static S6Tile pick_tile6(int M, int N) {
 }
 
 #define DFD_S6_NT_CASES(OP) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8)
+// pw7 instances: (WM, WN, MT, NT)
+#define DFD_S7_CONFIGS(OP)                                                                       \
+    OP(1, 4, 2, 1) OP(1, 4, 2, 2) OP(1, 4, 2, 3) OP(1, 4, 4, 1) OP(1, 4, 4, 2) OP(1, 4, 4, 3)     \
+    OP(2, 2, 1, 2) OP(2, 2, 1, 3) OP(2, 2, 1, 4) OP(2, 2, 1, 6) OP(2, 2, 2, 2) OP(2, 2, 2, 3)     \
+    OP(2, 2, 2, 4) OP(2, 2, 2, 6) OP(2, 2, 4, 2) OP(2, 2, 4, 3)
 
 template <bool CONV, bool GATE>
 static void s6_dispatch(const S6Tile& t, const float* X, const unsigned short* W3, const float* bias,
@@ -318,14 +608,27 @@ static void s6_dispatch(const S6Tile& t, const float* X, const unsigned short* W
                         const ConvGeom& g, int res_first, hipStream_t s) {
     const int grid = ((t.mblocks + 7) / 8) * 8 * t.nblocks;
     const int Kp = (K + S6_BK - 1) / S6_BK * S6_BK, plane = s6_np(N) * Kp;
+    const unsigned xbytes = CONV ? (unsigned)((size_t)(M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin * 4) : (unsigned)((size_t)M * K * 4);
+    const unsigned gbytes = GATE ? (unsigned)((size_t)(M / HW) * K * 4) : 0u;
+    if (t.kind == 1) {
+#define DFD_S7_CASE(WMV, WNV, MTV, NTV)                                                                              \
+    if (t.wm == WMV && t.wn == WNV && t.mt == MTV && t.nt == NTV) {                                                  \
+        hipLaunchKernelGGL((pw7_kernel<WMV, WNV, MTV, NTV, CONV, GATE>), dim3(grid), dim3(256), 0, s, X, W3, plane,  \
+                           Kp, bias, gate, R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes); \
+        return;                                                                                                      \
+    }
+        DFD_S7_CONFIGS(DFD_S7_CASE)
+#undef DFD_S7_CASE
+        return;
+    }
 #define DFD_S6_CASE(NTV)                                                                                          \
     case NTV:                                                                                                     \
         if (t.mt == 2)                                                                                            \
             hipLaunchKernelGGL((pw6_kernel<NTV, CONV, 2, GATE>), dim3(grid), dim3(256), 0, s, X, W3, plane, Kp, bias, \
-                               gate, R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first);                 \
+                               gate, R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes); \
         else                                                                                                      \
             hipLaunchKernelGGL((pw6_kernel<NTV, CONV, 1, GATE>), dim3(grid), dim3(256), 0, s, X, W3, plane, Kp, bias, \
-                               gate, R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first);                 \
+                               gate, R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes); \
         break;
     switch (t.nt) { DFD_S6_NT_CASES(DFD_S6_CASE) }
 #undef DFD_S6_CASE
@@ -362,26 +665,33 @@ static void s6_run(const float* X, const unsigned short* W3, const float* bias, 
         hipEvent_t e0, e1;
         if (tune && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
             const int tiles = (N + 15) / 16;
-            float best_ms = 1e30f;
+            std::vector<S6Tile> cands;
             for (int mt = 1; mt <= 2; ++mt)
-                for (int nt = 1; nt <= 8 && nt <= tiles; ++nt) {
-                    const S6Tile t = make_tile(M, N, mt, nt);
-                    if ((double)tiles / ((double)t.nblocks * nt) < 0.7) continue;      // mostly padding
-                    if ((long long)t.mblocks * t.nblocks > (1 << 20)) continue;
+                for (int nt = 1; nt <= 8 && nt <= tiles; ++nt) cands.push_back(make_tile6(M, N, mt, nt));
+#define DFD_S7_CAND(WMV, WNV, MTV, NTV) cands.push_back(make_tile(M, N, 1, WMV, WNV, MTV, NTV));
+            DFD_S7_CONFIGS(DFD_S7_CAND)
+#undef DFD_S7_CAND
+            float best_ms = 1e30f;
+            for (const S6Tile& t : cands) {
+                const int bn_tiles = t.kind == 0 ? t.nt : t.wn * t.nt;
+                if ((double)tiles / ((double)t.nblocks * bn_tiles) < 0.7) continue;      // mostly padding
+                if ((long long)t.mblocks * t.nblocks > (1 << 20)) continue;
+                s6_dispatch<CONV, GATE>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
+                hipEventRecord(e0, s);
+                for (int r = 0; r < 3; ++r)
                     s6_dispatch<CONV, GATE>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
-                    hipEventRecord(e0, s);
-                    for (int r = 0; r < 3; ++r)
-                        s6_dispatch<CONV, GATE>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
-                    hipEventRecord(e1, s);
-                    float ms = 0.f;
-                    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
-                    if (ms < best_ms) { best_ms = ms; tile = t; }
-                }
+                hipEventRecord(e1, s);
+                float ms = 0.f;
+                if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+                if (getenv("DFD_S6_VERBOSE") && atoi(getenv("DFD_S6_VERBOSE")) > 1)
+                    fprintf(stderr, "[dfd]   kind %d %dx%d mt=%d nt=%d: %.1f us\n", t.kind, t.wm, t.wn, t.mt, t.nt, ms * 1000.f / 3.f);
+                if (ms < best_ms) { best_ms = ms; tile = t; }
+            }
             hipEventDestroy(e0);
             hipEventDestroy(e1);
             if (getenv("DFD_S6_VERBOSE"))
-                fprintf(stderr, "[dfd] split gemm M=%d K=%d N=%d mode=%d -> mt=%d nt=%d (%.1f us)\n", M, K, N, key.mode,
-                        tile.mt, tile.nt, best_ms * 1000.f / 3.f);
+                fprintf(stderr, "[dfd] split gemm M=%d K=%d N=%d mode=%d -> kind %d %dx%d mt=%d nt=%d (%.1f us)\n", M, K, N,
+                        key.mode, tile.kind, tile.wm, tile.wn, tile.mt, tile.nt, best_ms * 1000.f / 3.f);
         }
         std::lock_guard<std::mutex> lk(g_tiles_mu);
         g_tiles[key] = tile;
@@ -389,7 +699,7 @@ static void s6_run(const float* X, const unsigned short* W3, const float* bias, 
     s6_dispatch<CONV, GATE>(tile, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
 }
 
-bool split_gemm_supports(int K, int N) { return K % 8 == 0 && K >= 16 && split_weights_count(N, K) * 3 < (1ull << 31); }
+bool split_gemm_supports(int K, int N) { return K % 8 == 0 && K >= 16 && split_weights_count(N, K) * 6 < (1ull << 31); }
 
 void launch_pointwise_split(const float* X, const unsigned short* W3, const float* bias, const float* gate,
                             const float* R, float* Y, int M, int K, int N, int HW, int act, hipStream_t s) {
