@@ -59,7 +59,10 @@ int dfd_max_batch(const dfd_handle* h);
  *   "fuse_expand" (default 1, env DFD_FUSE_EXPAND): MBConv blocks 1-5 compute the 1x1 expand conv
  *   inside the depthwise kernel instead of writing the expanded tensor to HBM.
  *   "fuse_stem" (default 1, env DFD_FUSE_STEM): the stem conv is computed inside block 0's depthwise
- *   kernel (the 112x112x32 stem activation stays in LDS). */
+ *   kernel (the 112x112x32 stem activation stays in LDS).
+ *   "split_gemm" (default 1, env DFD_SPLIT_GEMM): 1x1 convs (N >= 16) and the detector's k x k convs run on
+ *   the split-precision GEMM (each fp32 operand = exact sum of three bf16 terms, six products on the bf16
+ *   MFMA, fp32 accumulate: fp32-dot-product accuracy); 0 = the fp32 MFMA kernel everywhere. */
 int dfd_set_option(dfd_handle* h, const char* name, int value);
 
 /* ---- device memory and stream plumbing (no reference counterpart) -------------- */

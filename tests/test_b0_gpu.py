@@ -142,3 +142,32 @@ def test_errors_are_loud(pkg, b0_handle):
         b0_handle.classify(np.zeros((1, 3, 32, 32), np.float32))
     with pytest.raises(pkg._lib.DfdError):
         pkg._lib.Handle(b"not a blob", device=0, max_batch=1)
+
+
+def test_split_gemm_matches_fp32_mfma_and_oracle(b0_handle, ref):
+    """The split-precision GEMM (three exact bf16 terms per fp32 operand, six products on bf16 MFMA) and the
+    plain fp32 MFMA kernel are two evaluations of the same fp32 dot products: both meet the oracle bound and
+    they agree with each other to fp32 rounding noise at every 1x1-conv output."""
+    x, y, taps = ref
+    n = x.shape[0]
+    xd = b0_handle.alloc(x.nbytes).upload(x)
+    got = {}
+    try:
+        for mode in (0, 1):
+            b0_handle.set_option("split_gemm", mode)
+            got[mode] = {name: b0_handle.tap(xd.ptr, n, name, _nhwc(taps[name]).size)
+                         for name in ("b7.out", "b12.out", "b15.out", "head")}
+            got[mode]["logits"] = b0_handle.classify(x).reshape(-1)
+    finally:
+        b0_handle.set_option("split_gemm", 1)
+    for name, want in taps.items():
+        if name not in got[0]:
+            continue
+        w = _nhwc(want).reshape(-1)
+        for mode in (0, 1):
+            assert np.abs(got[mode][name] - w).max() <= LOGIT_TOL, (name, mode)
+        scale = max(1.0, float(np.abs(w).max()))
+        assert np.abs(got[0][name] - got[1][name]).max() <= 2e-5 * scale, name
+    for mode in (0, 1):
+        assert np.abs(got[mode]["logits"] - y.reshape(-1)).max() <= LOGIT_TOL, mode
+    assert np.abs(got[0]["logits"] - got[1]["logits"]).max() <= 5e-5
