@@ -62,7 +62,8 @@ int dfd_max_batch(const dfd_handle* h);
  *   kernel (the 112x112x32 stem activation stays in LDS).
  *   "split_gemm" (default 1, env DFD_SPLIT_GEMM): 1x1 convs (N >= 16) and the detector's k x k convs run on
  *   the split-precision GEMM (each fp32 operand = exact sum of three bf16 terms, six products on the bf16
- *   MFMA, fp32 accumulate: fp32-dot-product accuracy); 0 = the fp32 MFMA kernel everywhere. */
+ *   MFMA, fp32 accumulate: fp32-dot-product accuracy); 0 = the fp32 MFMA kernel everywhere.
+ *   "mtcnn" (default 1): align every crop with the MTCNN cascade when the blob carries one. */
 int dfd_set_option(dfd_handle* h, const char* name, int value);
 
 /* ---- device memory and stream plumbing (no reference counterpart) -------------- */
@@ -148,6 +149,27 @@ int dfd_has_detector(const dfd_handle* h);
  * "<source>.head", "prob", "boxes" (per prior) or "rows" (DetectionOutput: score,x1,y1,x2,y2). */
 int dfd_ssd_tap(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
                 const char* name, float* out, size_t capacity, size_t* count);
+
+/* ---- MTCNN align/crop -------------------------------------------------
+ * The reference runs facenet-pytorch's MTCNN(select_largest=False, post_process=False) on every
+ * already-cropped face before the classifier (deepfake_detection.py:24-28, 376-380): P-Net over a
+ * 0.709 scale pyramid, R-Net, O-Net (thresholds .6/.7/.7, NMS .5/.7/.7/.7-Min), the box with the
+ * highest probability, then PIL crop + 8-bit BILINEAR resize to 160x160.  Present when the blob
+ * carries "mtcnn.*" tensors (weights.pack_mtcnn_tensors); the classify entry points
+ * (dfd_classify_crops, dfd_preprocess_crops, dfd_analyze_frame, dfd_analyze_batch_device) then align
+ * every crop with it and return a NaN logit where it finds no face (the reference returns None
+ * there); dfd_set_option(h, "mtcnn", 0) bypasses the stage.
+ *   face_chw_out : NULL or 3*160*160 floats, RGB planes 0..255 (what MTCNN.forward returns)
+ *   box_out      : NULL or 5 floats (x1, y1, x2, y2, probability) of the selected box
+ *   found        : 1 / 0 */
+int dfd_has_mtcnn(const dfd_handle* h);
+int dfd_mtcnn_align(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
+                    float* face_chw_out, float* box_out, int* found);
+/* One named cascade intermediate for parity tests: "pnet.prob.<level>" [H][W], "pnet.reg.<level>"
+ * [H][W][4], "rnet.prob" / "onet.prob" [n] and "rnet.reg" / "onet.reg" [n][4] of the candidate windows in
+ * order, "stage1" / "stage2" / "stage3" rows (x1,y1,x2,y2,score); dims[3] receives the shape. */
+int dfd_mtcnn_tap(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
+                  const char* name, float* out, size_t capacity, size_t* count, int* dims);
 
 /* ---- frame forensics ------------------------------------------------------------------
  * FrameForensicAnalyzer.analyze (full != 0) / analyze_fast (full == 0), reference

@@ -58,6 +58,11 @@ SIGNATURES = {
     "dfd_has_detector": (C.c_int, [C.c_void_p]),
     "dfd_ssd_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p,
                               C.c_size_t, C.POINTER(C.c_size_t)]),
+    "dfd_has_mtcnn": (C.c_int, [C.c_void_p]),
+    "dfd_mtcnn_align": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.POINTER(C.c_int)]),
+    "dfd_mtcnn_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p,
+                                C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
     "dfd_analyze_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "dfd_analyze_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -349,6 +354,33 @@ class Handle:
         boxes = [[tuple(int(v) for v in xy[f, i]) for i in range(nf[f])] for f in range(n)]
         logits = [lg[f, : nf[f]].copy() for f in range(n)]
         return boxes, logits, (fp if with_forensics else None)
+
+    @property
+    def has_mtcnn(self) -> bool:
+        return bool(self._lib.dfd_has_mtcnn(self._p))
+
+    def mtcnn_align(self, face_bgr):
+        """MTCNN.forward on an already-cropped face (reference deepfake_detection.py:376-377):
+        ((3,160,160) float32 RGB 0..255, (x1,y1,x2,y2,prob)) or (None, None) when no face passes."""
+        a = self._as_bgr(face_bgr)
+        face = np.empty((3, 160, 160), np.float32)
+        box = np.empty(5, np.float32)
+        found = C.c_int()
+        self._check(self._lib.dfd_mtcnn_align(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0], _ptr(face),
+                                              _ptr(box), C.byref(found)))
+        return (face, box) if found.value else (None, None)
+
+    def mtcnn_tap(self, face_bgr, name: str, capacity: int = 1 << 20) -> np.ndarray:
+        a = self._as_bgr(face_bgr)
+        out = np.empty(int(capacity), np.float32)
+        cnt = C.c_size_t()
+        dims = np.zeros(3, np.int32)
+        self._check(self._lib.dfd_mtcnn_tap(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0], name.encode(),
+                                            _ptr(out), out.size, C.byref(cnt), _ptr(dims)))
+        shape = tuple(int(d) for d in dims if d != 1) or (1,)
+        if dims[1] == 5 and dims[2] == 1:
+            shape = (int(dims[0]), 5)
+        return out[: cnt.value].reshape(shape) if cnt.value else out[:0].reshape((0,) + shape[1:])
 
     def ssd_tap(self, frame, name: str, capacity: int) -> np.ndarray:
         a = self._as_bgr(frame)

@@ -52,6 +52,7 @@ int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, in
     if ((rc = b0_build_plan(h))) return rc;
     if ((rc = color_tables_init(h))) return rc;
     if ((rc = ssd_init(h))) return rc;
+    if ((rc = mtcnn_init(h))) return rc;
 
     const B0Plan& P = h->b0;
     const size_t nb = (size_t)max_batch;
@@ -76,6 +77,7 @@ void destroy_impl(dfd_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     forensic_destroy(h);
     ssd_destroy(h);
+    mtcnn_destroy(h);
     freq_destroy(h);
     for (void* p : h->owned)
         if (p) hipFree(p);
@@ -119,6 +121,7 @@ int dfd_set_option(dfd_handle* h, const char* name, int value) {
     if (strcmp(name, "fuse_expand") == 0) { h->fuse_expand = value != 0; return DFD_OK; }
     if (strcmp(name, "fuse_stem") == 0) { h->fuse_stem = value != 0; return DFD_OK; }
     if (strcmp(name, "split_gemm") == 0) { h->split_gemm = value != 0; return DFD_OK; }
+    if (strcmp(name, "mtcnn") == 0) { h->use_mtcnn = value != 0; return DFD_OK; }
     return fail(h, DFD_ERR_ARG, "unknown option '%s'", name);
 }
 

@@ -23,6 +23,9 @@ void freq_destroy(dfd_handle* h);
 struct SsdState;        // ssd_api.hip
 int ssd_init(dfd_handle* h);
 void ssd_destroy(dfd_handle* h);
+struct MtcnnState;      // mtcnn_api.hip
+int mtcnn_init(dfd_handle* h);
+void mtcnn_destroy(dfd_handle* h);
 
 struct Tensor {
     const float* host = nullptr;   // into the caller's blob (valid during dfd_create only)
@@ -85,10 +88,13 @@ struct dfd_handle {
     // image pre-processing: colour LUTs + lazily grown scratch (frame upload, Lab/BGR crops)
     dfd::ColorTables color{};
     bool has_color = false;
-    dfd::DevBuf frame_buf, lab_buf, crop_buf, lut_buf, desc_buf, u8_out;
+    dfd::DevBuf frame_buf, lab_buf, crop_buf, lut_buf, desc_buf, u8_out, face_batch;
+    std::vector<char> crop_valid;        // per crop of the last preprocess: 0 = the MTCNN stage found no face
     dfd::ForensicState* forensic = nullptr;   // per-stream temporal state + work buffers
     dfd::FreqState* freq = nullptr;           // compute_frequency_features tables + scratch
     dfd::SsdState* ssd = nullptr;             // detector plan + workspace (null: blob has no detector)
+    dfd::MtcnnState* mtcnn = nullptr;         // MTCNN cascade (null: blob has none)
+    bool use_mtcnn = true;                    // classify paths align each crop with the cascade when the blob has one
     bool fuse_stem = true;               // stem conv computed inside block 0's depthwise kernel
     bool fuse_expand = true;             // MBConv blocks 1-5: expand conv computed inside the depthwise kernel
     bool split_gemm = true;              // 1x1 / k x k convs on the bf16x3-split MFMA path (gemm_split.hip)
@@ -131,6 +137,12 @@ int detect_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, in
 // stateless six-signal forensic probability of `n` device frames (temporal signal = first-frame value 0)
 int forensics_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes,
                         double* prob_out, double* scores_out);
+
+// mtcnn_api.hip: MTCNN.forward on a BGR image in HBM -> selected box (x1,y1,x2,y2,prob), *found, and the
+// 160x160 BGR u8 crop at mtcnn_face_dev(h).  tap_* are for parity tests (null otherwise).
+int mtcnn_align_device(dfd_handle* h, const uint8_t* img_dev, int hh, int ww, size_t stride, float* box_out, int* found,
+                       const char* tap_name, std::vector<float>* tap, int* tap_dims);
+const uint8_t* mtcnn_face_dev(dfd_handle* h);
 
 // b0_plan.hip
 // three-plane bf16 split of a weight tensor of the handle, made on first use; null (+ error set) on failure

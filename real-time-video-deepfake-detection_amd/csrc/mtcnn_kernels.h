@@ -1,0 +1,29 @@
+// Launchers of the MTCNN-stage kernels (mtcnn_kernels.hip).  Activations NHWC fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace dfd {
+
+struct MtWindow { int x, y, w, h; };      // source window in pixels
+
+// interpolate(mode="area") of `n` windows of a u8 BGR image to oh x ow, RGB order, (x - 127.5) / 128
+void launch_mt_area_resize(const uint8_t* src, size_t stride, const MtWindow* win_dev, int n, int oh, int ow, float* dst,
+                           hipStream_t s);
+// valid k x k conv, weights [ci][ky][kx][co], + bias, + PReLU when slope != null
+void launch_mt_conv(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int ih, int iw,
+                    int ci, int co, int k, hipStream_t s);
+int mt_pool_out(int in, int k, int st);   // MaxPool2d(k, st, ceil_mode=True) output size
+void launch_mt_maxpool(const float* x, float* y, int n, int ih, int iw, int c, int k, int st, hipStream_t s);
+// y[n][out] = x[n][in] . w[in][out] + b (+ PReLU)
+void launch_mt_dense(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int in, int out,
+                     hipStream_t s);
+// z [n][2] -> softmax(z)[1]
+void launch_mt_softmax_face(const float* z, float* p, long long n, hipStream_t s);
+// one pass of Pillow's 8-bit resize; coeff [out][ksize] int32 (22 fractional bits), bounds [out][2] = (first, count)
+void launch_mt_pil_pass(const uint8_t* src, size_t stride, int x0, int y0, int sw, int sh, const int* coeff_dev,
+                        const int* bounds_dev, int ksize, int out, int vertical, uint8_t* dst, hipStream_t s);
+void launch_mt_face_chw(const uint8_t* bgr, float* out, int hw, hipStream_t s);
+
+}  // namespace dfd

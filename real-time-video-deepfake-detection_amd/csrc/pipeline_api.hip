@@ -3,6 +3,7 @@
 // optionally with the six forensic signals.  The per-frame semantics are those of
 // dfd_analyze_frame; this entry point exists for throughput (no per-frame host round trips
 // except the small DetectionOutput read-back that sizes the crop batch).
+#include <cmath>
 #include "b0_kernels.h"
 #include "dfd_common.h"
 
@@ -55,6 +56,8 @@ int dfd_analyze_batch_device(dfd_handle* h, const uint8_t* frames_dev, int n, in
         if ((rc = b0_forward(h, h->in_nchw, m, h->logits, nullptr, nullptr))) return rc;
         DFD_HIP_TRY(h, hipMemcpyAsync(logits.data() + start, h->logits, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
         DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < m; ++i)
+            if (!h->crop_valid[i]) logits[start + i] = NAN;      // MTCNN found no face in this crop
     }
     int k = 0;
     for (int f = 0; f < n; ++f)

@@ -240,14 +240,132 @@ def pack_ssd_tensors(sd: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
     return t
 
 
-def pack_all(b0_sd: Mapping[str, np.ndarray], ssd_sd: Mapping[str, np.ndarray] = None) -> bytes:
-    """One blob for `dfd_create`: classifier + colour tables (+ detector when given)."""
+# MTCNN (facenet-pytorch models/mtcnn.py: PNet / RNet / ONet), torch layouts: conv [co][ci][k][k], dense [out][in]
+MTCNN_CONVS = {
+    "pnet": [("conv1", 10, 3, 3), ("conv2", 16, 10, 3), ("conv3", 32, 16, 3), ("conv4_1", 2, 32, 1), ("conv4_2", 4, 32, 1)],
+    "rnet": [("conv1", 28, 3, 3), ("conv2", 48, 28, 3), ("conv3", 64, 48, 2)],
+    "onet": [("conv1", 32, 3, 3), ("conv2", 64, 32, 3), ("conv3", 64, 64, 3), ("conv4", 128, 64, 2)],
+}
+# dense layers: (name, out, in, (W, H, C) of the conv map the first one flattens, or None)
+MTCNN_DENSE = {
+    "pnet": [],
+    "rnet": [("dense4", 128, 576, (3, 3, 64)), ("dense5_1", 2, 128, None), ("dense5_2", 4, 128, None)],
+    "onet": [("dense5", 256, 1152, (3, 3, 128)), ("dense6_1", 2, 256, None), ("dense6_2", 4, 256, None),
+             ("dense6_3", 10, 256, None)],
+}
+MTCNN_PRELU = {"pnet": [("prelu1", 10), ("prelu2", 16), ("prelu3", 32)],
+               "rnet": [("prelu1", 28), ("prelu2", 48), ("prelu3", 64), ("prelu4", 128)],
+               "onet": [("prelu1", 32), ("prelu2", 64), ("prelu3", 64), ("prelu4", 128), ("prelu5", 256)]}
+
+
+def seeded_mtcnn_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
+    """Random-init MTCNN weights under facenet-pytorch's state_dict names (``pnet.conv1.weight`` ...).
+
+    The face-probability heads get a negative face-vs-background bias so that a random cascade lets a few
+    percent of the P-Net cells and a fraction of the R-/O-Net candidates through, as trained networks do
+    (with symmetric heads half of all cells fire and only NMS is exercised; with none the stage is inert).
+    """
+    rs = np.random.RandomState(seed + 2000)
+    sd: Dict[str, np.ndarray] = {}
+    head_bias = {"pnet.conv4_1": (-1.1, 1.0), "rnet.dense5_1": (1.6, 1.5), "onet.dense6_1": (0.8, 1.5)}   # (mean, std) of the face-vs-background logit
+    for net in ("pnet", "rnet", "onet"):
+        for name, co, ci, k in MTCNN_CONVS[net]:
+            q = f"{net}.{name}"
+            gain = 1.0 if q in head_bias or name == "conv4_2" else np.sqrt(2.0)
+            if name == "conv1":
+                gain *= 2.5                                      # (x - 127.5) / 128 has std ~0.35
+            sd[q + ".weight"] = (rs.randn(co, ci, k, k) * gain / np.sqrt(ci * k * k)).astype(np.float32)
+            sd[q + ".bias"] = (rs.randn(co) * 0.05).astype(np.float32)
+        for name, co, ci, _ in MTCNN_DENSE[net]:
+            q = f"{net}.{name}"
+            is_head = name.startswith("dense5_") or name.startswith("dense6_")
+            gain = 1.0 if is_head else np.sqrt(2.0)
+            sd[q + ".weight"] = (rs.randn(co, ci) * gain / np.sqrt(ci)).astype(np.float32)
+            sd[q + ".bias"] = (rs.randn(co) * 0.05).astype(np.float32)
+        for name, c in MTCNN_PRELU[net]:
+            sd[f"{net}.{name}.weight"] = (0.25 + 0.05 * rs.randn(c)).astype(np.float32)
+    _calibrate_mtcnn_heads(sd, rs, head_bias)
+    for q in ("pnet.conv4_2", "rnet.dense5_2", "onet.dense6_2"):  # box regression: small offsets
+        sd[q + ".weight"] *= 0.15
+    return sd
+
+
+def _calibrate_mtcnn_heads(sd: Dict[str, np.ndarray], rs, targets) -> None:
+    """Rescale / re-bias the three probability heads of a random cascade so that the face-vs-background logit
+    has the requested mean and spread on noise inputs.  Synthetic-weight generation only: a trained
+    checkpoint is used as it is.  (The positive mean of PReLU activations pushes the raw random heads by
+    5-20 logits one way: every candidate passes, or none.)"""
+    import torch
+    import torch.nn.functional as F
+
+    t = {k: torch.from_numpy(v) for k, v in sd.items()}
+
+    def trunk(net, x):
+        pools = {"pnet": [(2, 2)], "rnet": [(3, 2), (3, 2)], "onet": [(3, 2), (3, 2), (2, 2)]}[net]
+        convs = [c for c in MTCNN_CONVS[net] if not c[0].startswith("conv4_")]
+        for i, (name, _, _, _) in enumerate(convs):
+            x = F.prelu(F.conv2d(x, t[f"{net}.{name}.weight"], t[f"{net}.{name}.bias"]), t[f"{net}.prelu{i + 1}.weight"])
+            if i < len(pools):
+                x = F.max_pool2d(x, pools[i][0], pools[i][1], ceil_mode=True)
+        if net == "pnet":
+            return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
+        d = MTCNN_DENSE[net][0][0]
+        x = x.permute(0, 3, 2, 1).reshape(x.shape[0], -1)
+        return F.prelu(F.linear(x, t[f"{net}.{d}.weight"], t[f"{net}.{d}.bias"]), t[f"{net}.prelu{len(convs) + 1}.weight"])
+
+    with torch.no_grad():
+        for q, (mean, std) in targets.items():
+            net = q.split(".")[0]
+            size = {"pnet": 40, "rnet": 24, "onet": 48}[net]
+            # image-like inputs: a per-sample colour offset and a smooth ramp under the pixel noise
+            base = rs.randn(64, 3, 1, 1) * 0.3 + np.linspace(-0.3, 0.3, size).reshape(1, 1, 1, size) * rs.randn(64, 1, 1, 1)
+            x = torch.from_numpy((base + rs.randn(64, 3, size, size) * 0.15).astype(np.float32))
+            feat = trunk(net, x)
+            w = t[q + ".weight"].reshape(2, -1)
+            d = feat @ (w[1] - w[0])
+            k = std / float(d.std())
+            sd[q + ".weight"] = (sd[q + ".weight"] * k).astype(np.float32)
+            sd[q + ".bias"][0] = 0.0
+            sd[q + ".bias"][1] = np.float32(mean - k * float(d.mean()))
+
+
+def pack_mtcnn_tensors(sd: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Device layouts (names ``mtcnn.<net>.<layer>.w/.b/.a``): conv weights [ci][ky][kx][co] (consecutive output
+    channels contiguous), dense weights [in][out] with `in` re-ordered from the package's (W, H, C) flatten
+    (``x.permute(0, 3, 2, 1)``) to this build's NHWC (H, W, C) order, PReLU slopes as they are."""
+    t: Dict[str, np.ndarray] = {}
+    for net in ("pnet", "rnet", "onet"):
+        for name, co, ci, k in MTCNN_CONVS[net]:
+            w = np.asarray(sd[f"{net}.{name}.weight"], np.float32)
+            if w.shape != (co, ci, k, k):
+                raise ValueError(f"{net}.{name}.weight: shape {w.shape}")
+            t[f"mtcnn.{net}.{name}.w"] = np.ascontiguousarray(w.transpose(1, 2, 3, 0))
+            t[f"mtcnn.{net}.{name}.b"] = np.asarray(sd[f"{net}.{name}.bias"], np.float32)
+        for name, co, ci, whc in MTCNN_DENSE[net]:
+            w = np.asarray(sd[f"{net}.{name}.weight"], np.float32)
+            if w.shape != (co, ci):
+                raise ValueError(f"{net}.{name}.weight: shape {w.shape}")
+            if whc is not None:
+                W_, H_, C_ = whc
+                w = w.reshape(co, W_, H_, C_).transpose(0, 2, 1, 3).reshape(co, ci)      # (w,h,c) -> (h,w,c)
+            t[f"mtcnn.{net}.{name}.w"] = np.ascontiguousarray(w.T)
+            t[f"mtcnn.{net}.{name}.b"] = np.asarray(sd[f"{net}.{name}.bias"], np.float32)
+        for name, c in MTCNN_PRELU[net]:
+            t[f"mtcnn.{net}.{name}.a"] = np.asarray(sd[f"{net}.{name}.weight"], np.float32).reshape(c)
+    return t
+
+
+def pack_all(b0_sd: Mapping[str, np.ndarray], ssd_sd: Mapping[str, np.ndarray] = None,
+             mtcnn_sd: Mapping[str, np.ndarray] = None) -> bytes:
+    """One blob for `dfd_create`: classifier + colour tables (+ detector, + MTCNN cascade when given)."""
     from . import luts
 
     t = pack_b0_tensors(b0_sd)
     t.update(luts.as_float_tensors())
     if ssd_sd is not None:
         t.update(pack_ssd_tensors(ssd_sd))
+    if mtcnn_sd is not None:
+        t.update(pack_mtcnn_tensors(mtcnn_sd))
     return serialize(t)
 
 

@@ -36,3 +36,17 @@ def b0_handle(pkg, seeded_sd):
     h = pkg._lib.Handle(blob, device=0, max_batch=16)
     yield h
     h.close()
+
+
+@pytest.fixture(scope="session")
+def mtcnn_sd(pkg):
+    return pkg.weights.seeded_mtcnn_state_dict(0)
+
+
+@pytest.fixture(scope="session")
+def mt_handle(pkg, seeded_sd, mtcnn_sd):
+    """Classifier + detector + MTCNN cascade in one handle (the reference's full per-face path)."""
+    blob = pkg.weights.pack_all(seeded_sd, pkg.weights.seeded_ssd_state_dict(0), mtcnn_sd)
+    h = pkg._lib.Handle(blob, device=0, max_batch=8)
+    yield h
+    h.close()

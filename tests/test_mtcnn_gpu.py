@@ -1,0 +1,92 @@
+"""GPU parity of the MTCNN align/crop stage through the C ABI vs oracle/mtcnn_ref.py.
+
+Bars: network maps |d| <= 1e-4 (fp32, different summation order than torch's conv); stage boxes the same
+rows to 1e-2 px (float32 box arithmetic on 1e-4-accurate regressions); the selected 160x160 crop bit-exact
+(integer box corners, Pillow-exact 8-bit resize); the logit of the aligned crop within the classifier's 1e-3.
+A cell or candidate whose probability is within 1e-4 of its threshold may legitimately fall either way:
+the test asserts that no cell does with the seeded weights/images and says so if one ever does."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import b0_ref, imgproc_ref, mtcnn_ref as M
+from tests import mt_images
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sd(pkg, mtcnn_sd):
+    return pkg.weights.to_torch(mtcnn_sd)
+
+
+def _bgr(rgb):
+    return np.ascontiguousarray(rgb[..., ::-1])
+
+
+@pytest.mark.parametrize("idx", range(len(mt_images.CASES)))
+def test_cascade_matches_oracle(mt_handle, sd, idx):
+    rgb = mt_images.images()[idx]
+    taps = {}
+    want = M.mtcnn_forward(sd, rgb, taps)
+    bgr = _bgr(rgb)
+    assert mt_handle.has_mtcnn
+    for si in range(len(M.scale_pyramid(*rgb.shape[:2]))):
+        p = mt_handle.mtcnn_tap(bgr, f"pnet.prob.{si}")
+        r = mt_handle.mtcnn_tap(bgr, f"pnet.reg.{si}")
+        wp, wr = taps[f"pnet.prob.{si}"], taps[f"pnet.reg.{si}"].transpose(1, 2, 0)
+        assert p.shape == wp.shape and np.abs(p - wp).max() <= 1e-4, (si, p.shape, wp.shape)
+        assert np.abs(r.reshape(wr.shape) - wr).max() <= 1e-4
+        flip = (p >= np.float32(0.6)) != (wp >= np.float32(0.6))
+        assert not flip.any(), (f"level {si}: {int(flip.sum())} cells fall on different sides of the P-Net threshold "
+                                f"(margins {np.abs(wp[flip] - 0.6)}): threshold-ambiguous input, pick another seed")
+    for stage in ("stage1", "stage2", "stage3"):
+        got = mt_handle.mtcnn_tap(bgr, stage)
+        w = taps[stage]
+        assert got.shape[0] == len(w), (stage, got.shape, len(w))
+        if len(w):
+            assert np.abs(got[:, :4] - w[:, :4]).max() <= 1e-2 and np.abs(got[:, 4] - w[:, 4]).max() <= 1e-4, stage
+    face, box = mt_handle.mtcnn_align(bgr)
+    if want is None:
+        assert face is None
+    else:
+        assert face is not None
+        assert np.abs(box - taps["selected"]).max() <= 1e-2
+        assert np.array_equal(face, want)               # bit-exact 160x160 crop, RGB planes 0..255
+
+
+def test_undersized_and_option(mt_handle, sd):
+    tiny = _bgr(mt_images.textured(12, 40, 8))
+    assert mt_handle.mtcnn_align(tiny) == (None, None)
+
+
+def test_classify_crops_with_alignment(pkg, mt_handle, sd, seeded_sd):
+    """Integrated path (reference deepfake_detection.py:517-538 -> 372-398): CLAHE'd crop -> MTCNN.forward ->
+    224 bilinear + normalise -> B0; NaN where the cascade finds no face; option "mtcnn"=0 restores the bypass."""
+    rs = np.random.RandomState(11)
+    frame = rs.randint(40, 215, (480, 640, 3)).astype(np.uint8)
+    yy, xx = np.mgrid[0:480, 0:640]
+    frame = np.clip(frame * 0.4 + (110 + 60 * np.sin(xx / 19.0) * np.cos(yy / 27.0))[..., None] * 0.6, 0, 255).astype(np.uint8)
+    boxes = np.array([[20, 30, 300, 280], [330, 40, 200, 180], [100, 330, 90, 75], [400, 300, 230, 170]], np.int32)
+    got = mt_handle.classify_crops(frame, boxes, apply_clahe=True).reshape(-1)
+    b0 = pkg.weights.to_torch(seeded_sd)
+    want = []
+    for x, y, w, h in boxes:
+        crop = imgproc_ref.preprocess_face_quality(frame[y:y + h, x:x + w])
+        face = M.mtcnn_forward(sd, np.ascontiguousarray(crop[..., ::-1]))
+        if face is None:
+            want.append(np.nan)
+            continue
+        face_bgr = np.ascontiguousarray(face.transpose(1, 2, 0)[..., ::-1]).astype(np.uint8)
+        x224 = imgproc_ref.crop_resize_normalize(face_bgr)
+        want.append(float(b0_ref.forward(b0, torch.from_numpy(x224[None])).reshape(-1)[0]))
+    want = np.asarray(want, np.float32)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), (got, want)
+    ok = ~np.isnan(want)
+    assert ok.any() and np.abs(got[ok] - want[ok]).max() <= 1e-3, (got, want)
+    try:
+        mt_handle.set_option("mtcnn", 0)
+        plain = mt_handle.classify_crops(frame, boxes, apply_clahe=True).reshape(-1)
+    finally:
+        mt_handle.set_option("mtcnn", 1)
+    assert not np.isnan(plain).any() and np.abs(plain[ok] - got[ok]).max() > 1e-3     # a different crop reaches B0
