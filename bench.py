@@ -108,7 +108,39 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=64, steps=6, warmup=3)
                     "ms_per_frame": round(dt / (frames_per_step * steps) * 1e3, 3),
                     "repeats_frames_per_s": [round(frames_per_step * steps * world / d, 1) for d in dts]}
     fd.free()
+    if rank == 0 and world == 1:
+        res["detect_classify_mtcnn"] = e2e_mtcnn(frames[:8], boxes[:8], K)
     return res
+
+
+def e2e_mtcnn(frames, boxes, K):
+    """The same path with the reference's MTCNN align/crop between CLAHE and the 224x224 resize (row A5), on a
+    handle whose blob carries the (seeded) cascade.  One cascade per crop with host-side box bookkeeping between
+    its three stages: a latency figure, not yet a batched throughput path."""
+    import rtdfd_amd as pkg
+
+    W = pkg.weights
+    h = pkg._lib.Handle(W.pack_all(W.seeded_state_dict(0), W.seeded_ssd_state_dict(0), W.seeded_mtcnn_state_dict(0)),
+                        device=0, max_batch=8 * K)
+    n, H, Wd = frames.shape[:3]
+    fd = h.alloc(frames.nbytes).upload(frames)
+    out = {}
+    for key, flag in (("mtcnn_on", 1), ("mtcnn_off", 0)):
+        h.set_option("mtcnn", flag)
+        h.analyze_batch_device(fd.ptr, n, H, Wd, forced_boxes=boxes, max_faces=K, with_forensics=False)
+        h.sync()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            res = h.analyze_batch_device(fd.ptr, n, H, Wd, forced_boxes=boxes, max_faces=K, with_forensics=False)
+        h.sync()
+        dt = (time.perf_counter() - t0) / 2
+        flat = np.concatenate([np.asarray(l, np.float32).reshape(-1) for l in res[1]]) if len(res[1]) else np.zeros(0)
+        out[key] = {"frames_per_s": round(n / dt, 1), "ms_per_crop": round(dt / (n * K) * 1e3, 3),
+                    "crops_with_a_face": int((~np.isnan(flat)).sum()), "crops": int(flat.size)}
+    out["workload"] = f"{n} x 1080p frames, {K} forced boxes each; seeded random-init cascade"
+    fd.free()
+    h.close()
+    return out
 
 
 def main():

@@ -7,7 +7,8 @@ composed from the other oracle modules.
   PredictRef.request   reference backend_server.py:147-233 (`/analyze` body): forensics BEFORE the
                        counter moves, faces[0] only, one vote per request.
 
-analyze_face = CLAHE -> [MTCNN bypassed, SURVEY A5] -> bilinear 224 -> normalise -> B0 -> sigmoid
+analyze_face = CLAHE -> MTCNN.forward when `mtcnn_sd` is given (mtcnn_ref; a crop without a face yields no
+prediction: skipped by predict, frame-only response from the server) -> bilinear 224 -> normalise -> B0 -> sigmoid
 -> calibration (identity: no calibrator.pkl) -> +0.10 if h<80 or w<80 -> clip
 (reference deepfake_detection.py:357-406,445-455,489-550).  PARITY UNPINNED as a whole (it inherits
 that status from b0_ref / imgproc_ref / ssd_ref); the vote logic inside it is pinned (tracker_ref).
@@ -17,14 +18,14 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import b0_ref, imgproc_ref, ssd_ref
+from . import b0_ref, imgproc_ref, mtcnn_ref, ssd_ref
 from .forensics_ref import ForensicsRef
 from .tracker_ref import TrackerRef
 
 
 class PredictRef:
-    def __init__(self, b0_sd, ssd_sd, ssd_arch, detection_threshold=0.5):
-        self.b0_sd, self.ssd_sd, self.arch = b0_sd, ssd_sd, ssd_arch
+    def __init__(self, b0_sd, ssd_sd, ssd_arch, detection_threshold=0.5, mtcnn_sd=None):
+        self.b0_sd, self.ssd_sd, self.arch, self.mtcnn_sd = b0_sd, ssd_sd, ssd_arch, mtcnn_sd
         self.tracker = TrackerRef(window_size=60, high_confidence_threshold=0.6, voting_window=10,
                                   detection_threshold=detection_threshold)
         self.analyzer = ForensicsRef()
@@ -38,6 +39,11 @@ class PredictRef:
 
     def analyze_face(self, face):                                   # :517-550
         pre = imgproc_ref.preprocess_face_quality(face)
+        if self.mtcnn_sd is not None:                               # :376-380
+            aligned = mtcnn_ref.mtcnn_forward(self.mtcnn_sd, np.ascontiguousarray(pre[..., ::-1]))
+            if aligned is None:
+                return None, None
+            pre = np.ascontiguousarray(aligned.transpose(1, 2, 0)[..., ::-1]).astype(np.uint8)
         x = torch.from_numpy(imgproc_ref.crop_resize_normalize(pre)).unsqueeze(0)
         logit = b0_ref.forward(self.b0_sd, x).squeeze()
         p = torch.sigmoid(logit).item()
@@ -48,10 +54,13 @@ class PredictRef:
         self.frame_count += 1
         forensic = self.forensics(frame)
         faces = ssd_ref.detect_bounding_box(self.ssd_sd, self.arch, frame)
-        face_results, level = [], None
+        face_results, level = [], None          # None = the reference's local is unassigned (it raises at :679 when
+        # faces were detected and every analyze_face returned None)
         if len(faces) > 0:
             for (x, y, w, h) in faces:
                 p, logit = self.analyze_face(frame[y:y + h, x:x + w])
+                if p is None:                                       # :616-617
+                    continue
                 self.tracker.update(p)
                 level = self.tracker.confidence_level()
                 face_results.append({'face_prob': p, 'logit': logit, 'bbox': {'x': x, 'y': y, 'w': w, 'h': h}})
@@ -74,13 +83,14 @@ class PredictRef:
         if len(faces) > 0:
             x, y, w, h = faces[0]
             p, _ = self.analyze_face(frame[y:y + h, x:x + w])
-            self.tracker.update(p)
-            return {'analysis_mode': 'face+frame', 'faces_detected': len(faces), 'fake_probability': p,
-                    'face_probability': p, 'frame_forensic_probability': fprob, 'real_probability': 1 - p,
-                    'confidence_level': self.tracker.confidence_level(), 'frame_count': self.frame_count,
-                    'face_bbox': {'x': x, 'y': y, 'width': w, 'height': h}, 'votes': self.tracker.voting_stats()}
+            if p is not None:                                       # backend_server.py:166
+                self.tracker.update(p)
+                return {'analysis_mode': 'face+frame', 'faces_detected': len(faces), 'fake_probability': p,
+                        'face_probability': p, 'frame_forensic_probability': fprob, 'real_probability': 1 - p,
+                        'confidence_level': self.tracker.confidence_level(), 'frame_count': self.frame_count,
+                        'face_bbox': {'x': x, 'y': y, 'width': w, 'height': h}, 'votes': self.tracker.voting_stats()}
         self.tracker.update(fprob)
-        return {'analysis_mode': 'frame_only', 'faces_detected': 0, 'fake_probability': fprob,
+        return {'analysis_mode': 'frame_only', 'faces_detected': len(faces), 'fake_probability': fprob,
                 'frame_forensic_probability': fprob, 'real_probability': 1 - fprob,
                 'confidence_level': self.tracker.confidence_level(), 'frame_count': self.frame_count,
                 'votes': self.tracker.voting_stats()}

@@ -5,8 +5,10 @@ reference deepfake_detection.py:292-726 and the module keeps its globals (`DEVIC
 `mtcnn`, `detector`, `predict`, `predict_with_forensics`; :21-32,729-747).  Per frame the GPU
 does forensics, face detection, crop -> CLAHE -> 224x224 -> EfficientNet-B0 in ONE call
 (`dfd_analyze_frame`); calibration, the small-face heuristic and the vote stay on the host as in
-the reference.  Deliberate differences: no MTCNN re-crop (`mtcnn` is None),
-TTA and GradCAM are not implemented (both are disabled in the reference's shipped configurations,
+the reference.  The MTCNN align/crop of reference :376-380 runs inside the same library call when the handle's
+weights carry the cascade (`mtcnn` below is its module-level mirror); a crop in which it finds no face yields no
+prediction, exactly as the reference's `None` (:378-380, :616-617, backend_server.py:166).  Deliberate differences
+(DESIGN.md section 8): TTA and GradCAM are not implemented (both are disabled in the reference's shipped configurations,
 :730-736 and backend_server.py:57), frames are returned un-annotated, nothing is printed per frame.
 """
 from __future__ import annotations
@@ -28,7 +30,9 @@ from .tracker import TemporalTracker
 log = logging.getLogger(__name__)
 
 DEVICE = f"cuda:{runtime.device_index()}"
-mtcnn = None                     # reference :24-28; the MTCNN stage is bypassed
+from .mtcnn import MTCNN  # noqa: E402
+
+mtcnn = MTCNN(select_largest=False, post_process=False, device=DEVICE)     # reference :24-28
 
 
 def _sigmoid32(logit) -> float:
@@ -123,6 +127,9 @@ class DeepfakeDetector:
         return np.clip(fake_prob + adjustment, 0, 1)
 
     def _finish_face(self, logit, h, w):
+        """None when the MTCNN stage found no face in the crop (NaN logit from the library)."""
+        if logit is None or np.isnan(logit):
+            return None
         p = self.apply_calibration(_sigmoid32(logit))
         return self._heuristics_hw(p, h, w)
 
@@ -155,6 +162,8 @@ class DeepfakeDetector:
             with self._lock:
                 logit = self.handle.classify_crops(face, [(0, 0, w, h)], apply_clahe=True)[0, 0]
             p = self._finish_face(logit, h, w)
+            if p is None:
+                return None, None, None
             return p, p, None
         except (DfdError, ValueError) as e:
             log.warning("face analysis error: %s", e)
@@ -186,6 +195,8 @@ class DeepfakeDetector:
         if len(faces) > 0:
             for (x, y, w, h), logit in zip(faces, logits):
                 fake_prob = self._finish_face(logit, h, w)
+                if fake_prob is None:                                        # reference :616-617
+                    continue
                 self.temporal_tracker.update(fake_prob)
                 confidence_level = self.temporal_tracker.get_confidence_level()
                 if self.temporal_tracker.should_trigger_forensic_analysis():
@@ -224,9 +235,11 @@ class DeepfakeDetector:
         self.frame_count += 1
         tr = self.temporal_tracker
         fprob = frame_forensic['fake_probability']
+        fake_prob = None
         if len(faces) > 0 and not small:
             x, y, w, h = faces[0]
             fake_prob = self._finish_face(logits[0], h, w)
+        if fake_prob is not None:                                            # backend_server.py:166
             tr.update(fake_prob)
             return {'success': True, 'analysis_mode': 'face+frame', 'faces_detected': n_detected,
                     'fake_probability': float(fake_prob), 'face_probability': float(fake_prob),

@@ -50,8 +50,16 @@ def default_handle() -> Handle:
         if _default is None:
             # detector: the reference's Caffe files are not in its tree either (face_detection.py:19-20);
             # seeded random-init weights of the same topology stand in
-            ssd = W.seeded_ssd_state_dict(int(os.environ.get("DFD_SEED", "0")))
-            _default = Handle(W.pack_all(default_state_dict(), ssd), device=device_index(),
+            seed = int(os.environ.get("DFD_SEED", "0"))
+            ssd = W.seeded_ssd_state_dict(seed)
+            # MTCNN: facenet-pytorch ships its trained pnet/rnet/onet inside the pip package, which is absent here;
+            # $DFD_MTCNN_WEIGHTS = directory with pnet.pt / rnet.pt / onet.pt, else seeded random-init; DFD_MTCNN=0
+            # leaves the stage out (the detector crop then feeds the classifier directly)
+            mt = None
+            if os.environ.get("DFD_MTCNN", "1") != "0":
+                d = os.environ.get("DFD_MTCNN_WEIGHTS")
+                mt = W.load_mtcnn_checkpoints(d) if d else W.seeded_mtcnn_state_dict(seed)
+            _default = Handle(W.pack_all(default_state_dict(), ssd, mt), device=device_index(),
                               max_batch=int(os.environ.get("DFD_MAX_BATCH", "16")))
         return _default
 

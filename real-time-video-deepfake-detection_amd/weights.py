@@ -290,6 +290,21 @@ def seeded_mtcnn_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
     return sd
 
 
+def load_mtcnn_checkpoints(directory: str) -> Dict[str, np.ndarray]:
+    """facenet-pytorch's ``data/pnet.pt``, ``rnet.pt``, ``onet.pt`` (plain state_dicts) -> one dict with the
+    ``pnet.`` / ``rnet.`` / ``onet.`` prefixes `pack_mtcnn_tensors` expects."""
+    import os
+
+    import torch
+
+    out: Dict[str, np.ndarray] = {}
+    for net in ("pnet", "rnet", "onet"):
+        sd = torch.load(os.path.join(directory, net + ".pt"), map_location="cpu")
+        for k, v in sd.items():
+            out[f"{net}.{k}"] = v.detach().cpu().numpy().astype(np.float32)
+    return out
+
+
 def _calibrate_mtcnn_heads(sd: Dict[str, np.ndarray], rs, targets) -> None:
     """Rescale / re-bias the three probability heads of a random cascade so that the face-vs-background logit
     has the requested mean and spread on noise inputs.  Synthetic-weight generation only: a trained

@@ -47,6 +47,6 @@ def mtcnn_sd(pkg):
 def mt_handle(pkg, seeded_sd, mtcnn_sd):
     """Classifier + detector + MTCNN cascade in one handle (the reference's full per-face path)."""
     blob = pkg.weights.pack_all(seeded_sd, pkg.weights.seeded_ssd_state_dict(0), mtcnn_sd)
-    h = pkg._lib.Handle(blob, device=0, max_batch=8)
+    h = pkg._lib.Handle(blob, device=0, max_batch=64)       # predict classifies every detection of a frame
     yield h
     h.close()

@@ -25,6 +25,22 @@ def _stream(n, seed):
     return out
 
 
+def _mt_stream(n, seed):
+    """textured frames (dozens of detections, some of which survive the MTCNN cascade), face frames (mostly
+    rejected by it) and blank frames (no detection)"""
+    from tests import mt_images
+
+    out = []
+    for i in range(n):
+        if i % 4 == 3:
+            out.append(F.blank_frame(640, 480))
+        elif i % 4 == 1:
+            out.append(F.face_frame(640, 480, seed + i))
+        else:
+            out.append(mt_images.textured(480, 640, 20 + seed + i))
+    return out
+
+
 @pytest.fixture()
 def refs(pkg, seeded_sd, ssd_sd):
     return pkg.weights.to_torch(seeded_sd), pkg.weights.to_torch(ssd_sd), pkg.ssd_arch
@@ -96,3 +112,44 @@ def test_analyze_face_and_neutral_values(pkg, b0_handle, refs):
     assert region.shape == (220, 160, 3) and isinstance(boxes, list)
     drawn = pkg.face_detection.draw_bounding_boxes(F.face_frame(), boxes[:2])
     assert drawn.shape == F.face_frame().shape
+
+
+def test_streams_with_mtcnn_alignment_match_oracle(pkg, mt_handle, refs, mtcnn_sd):
+    """The reference's full per-face path (CLAHE -> MTCNN.forward -> 224 -> B0): faces in which the cascade finds
+    nothing are skipped by predict (reference deepfake_detection.py:616-617) and turn the server response into
+    the frame-only one with the detector's face count (backend_server.py:166,205-224).  Votes identical."""
+    mt = pkg.weights.to_torch(mtcnn_sd)
+    det = pkg.deepfake_detection.DeepfakeDetector(use_tta=False, num_tta_augmentations=1, detection_threshold=0.5,
+                                                  handle=mt_handle)
+    ref = PredictRef(*refs, detection_threshold=0.5, mtcnn_sd=mt)
+    skipped = kept = 0
+    for frame in _mt_stream(5, seed=3):
+        want = ref.predict(frame)
+        got = det.predict(frame)[3]
+        assert got['faces_detected'] == want['faces_detected'] and got['analysis_mode'] == want['analysis_mode']
+        assert [r['bbox'] for r in got['face_results']] == [r['bbox'] for r in want['face_results']]
+        for g, w in zip(got['face_results'], want['face_results']):
+            assert abs(g['face_prob'] - w['face_prob']) <= PROB_TOL
+        assert det.temporal_tracker.get_voting_stats() == want['votes']
+        if want['confidence_level'] is None:
+            # faces detected but none survived MTCNN: the reference reads an unassigned local at :679 and raises
+            # UnboundLocalError; this build reports the tracker's current level instead (DESIGN.md section 8)
+            assert got['confidence_level'] == det.temporal_tracker.get_confidence_level()
+        else:
+            assert got['confidence_level'] == want['confidence_level']
+        kept += len(want['face_results'])
+        skipped += min(want['faces_detected'], mt_handle.max_batch) - len(want['face_results'])
+    assert kept > 0 and skipped > 0, (kept, skipped)               # both outcomes occur in the stream
+    det2 = pkg.deepfake_detection.DeepfakeDetector(enable_gradcam=False, use_tta=False, num_tta_augmentations=1,
+                                                   detection_threshold=0.55, handle=mt_handle)
+    ref2 = PredictRef(*refs, detection_threshold=0.55, mtcnn_sd=mt)
+    modes = set()
+    for frame in _mt_stream(8, seed=5):
+        want = ref2.request(frame)
+        got = det2.analyze_request(frame)
+        for k in ('analysis_mode', 'faces_detected', 'confidence_level', 'frame_count'):
+            assert got[k] == want[k], k
+        assert abs(got['fake_probability'] - want['fake_probability']) <= PROB_TOL
+        assert det2.temporal_tracker.get_voting_stats() == want['votes']
+        modes.add((got['analysis_mode'], got['faces_detected'] > 0))
+    assert ('frame_only', False) in modes and ('face+frame', True) in modes
