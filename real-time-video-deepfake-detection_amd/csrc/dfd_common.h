@@ -140,6 +140,10 @@ int forensics_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh,
 
 // mtcnn_api.hip: MTCNN.forward on a BGR image in HBM -> selected box (x1,y1,x2,y2,prob), *found, and the
 // 160x160 BGR u8 crop at mtcnn_face_dev(h).  tap_* are for parity tests (null otherwise).
+struct MtImage { const uint8_t* src; int h, w; size_t stride; };
+// the same for `n` images of a step at once: faces_out [n][160*160*3] (device), boxes_out [n][5] or null, found [n]
+int mtcnn_align_batch_device(dfd_handle* h, const MtImage* imgs, int n, uint8_t* faces_out, float* boxes_out, char* found,
+                             const char* tap_name, std::vector<float>* tap, int* tap_dims);
 int mtcnn_align_device(dfd_handle* h, const uint8_t* img_dev, int hh, int ww, size_t stride, float* box_out, int* found,
                        const char* tap_name, std::vector<float>* tap, int* tap_dims);
 const uint8_t* mtcnn_face_dev(dfd_handle* h);

@@ -652,7 +652,14 @@ template <bool CONV, bool GATE>
 static void s6_run(const float* X, const unsigned short* W3, const float* bias, const float* gate, const float* R,
                    float* Y, int M, int K, int N, int HW, int act, const ConvGeom& g, int res_first, hipStream_t s) {
     static const bool tune = !(getenv("DFD_S6_TUNE") && atoi(getenv("DFD_S6_TUNE")) == 0);
-    const S6Key key{M, K, N, (CONV ? 1 : 0) | (GATE ? 2 : 0) | (CONV ? (g.ksize << 8) | (g.stride << 4) : 0)};
+    // M in 8 buckets per octave: data-dependent row counts (the MTCNN candidate windows) share a measurement
+    int mkey = M;
+    if (M > 64) {
+        int sh = 0;
+        while ((M >> sh) > 15) ++sh;
+        mkey = ((M + (1 << sh) - 1) >> sh) << sh;
+    }
+    const S6Key key{mkey, K, N, (CONV ? 1 : 0) | (GATE ? 2 : 0) | (CONV ? (g.ksize << 8) | (g.stride << 4) : 0)};
     S6Tile tile;
     bool have = false;
     {
@@ -696,6 +703,7 @@ static void s6_run(const float* X, const unsigned short* W3, const float* bias, 
         std::lock_guard<std::mutex> lk(g_tiles_mu);
         g_tiles[key] = tile;
     }
+    tile = make_tile(M, N, tile.kind, tile.wm, tile.wn, tile.mt, tile.nt);      // block counts for this call's M
     s6_dispatch<CONV, GATE>(tile, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
 }
 

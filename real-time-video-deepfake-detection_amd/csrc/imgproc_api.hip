@@ -119,24 +119,23 @@ int preprocess_on_device(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww
     if (h->use_mtcnn && h->mtcnn) {
         // reference deepfake_detection.py:376-380: MTCNN.forward on the (CLAHE'd) crop picks the face window and
         // resamples it to 160x160; that image, not the detector crop, feeds the 224x224 bilinear + normalise
-        // (:382-389).  One cascade per crop; a crop without a face yields no prediction (NaN logit, `None` upstream).
+        // (:382-389).  All crops of the call go through the cascade together; a crop without a face yields no
+        // prediction (NaN logit, `None` upstream).
         if ((rc = ensure(h, &h->face_batch, (size_t)n * 160 * 160 * 3))) return rc;
         std::vector<CropDesc> fd(n);
+        std::vector<MtImage> imgs(n);
         size_t off = 0;
         for (int i = 0; i < n; ++i) {
             const int x = xywh[4 * i], y = xywh[4 * i + 1], w = xywh[4 * i + 2], hgt = xywh[4 * i + 3];
             const uint8_t* img = apply_clahe ? (const uint8_t*)h->crop_buf.p + off
                                              : frame_dev + (frame_offs ? frame_offs[i] : 0) + (size_t)y * stride + (size_t)x * 3;
-            const size_t istride = apply_clahe ? (size_t)w * 3 : (size_t)stride;
+            imgs[i] = MtImage{img, hgt, w, apply_clahe ? (size_t)w * 3 : (size_t)stride};
             off += ((size_t)w * hgt * 3 + 255) & ~(size_t)255;        // as stage_crops lays the packed crops out
-            int found = 0;
-            if ((rc = mtcnn_align_device(h, img, hgt, w, istride, nullptr, &found, nullptr, nullptr, nullptr))) return rc;
-            uint8_t* slot = (uint8_t*)h->face_batch.p + (size_t)i * 160 * 160 * 3;
-            if (found) DFD_HIP_TRY(h, hipMemcpyAsync(slot, mtcnn_face_dev(h), 160 * 160 * 3, hipMemcpyDeviceToDevice, h->stream));
-            else DFD_HIP_TRY(h, hipMemsetAsync(slot, 0, 160 * 160 * 3, h->stream));
-            h->crop_valid[i] = (char)found;
             fd[i] = CropDesc{0, 0, 160, 160, 0, (size_t)i * 160 * 160 * 3};
         }
+        if ((rc = mtcnn_align_batch_device(h, imgs.data(), n, (uint8_t*)h->face_batch.p, nullptr, h->crop_valid.data(), nullptr,
+                                           nullptr, nullptr)))
+            return rc;
         DFD_HIP_TRY(h, hipMemcpyAsync(h->desc_buf.p, fd.data(), n * sizeof(CropDesc), hipMemcpyHostToDevice, h->stream));
         DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
         launch_crop_norm((const uint8_t*)h->face_batch.p, 160 * 3, nullptr, dd, n, h->in_nchw, false, h->stream);

@@ -6,9 +6,11 @@
 // of the library, as the package does it in numpy/torch glue.  Operation order and float32/double choices
 // follow the restatement in oracle/mtcnn_ref.py line by line.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <numeric>
 
+#include "b0_kernels.h"
 #include "dfd_common.h"
 #include "mtcnn_kernels.h"
 
@@ -16,6 +18,7 @@ namespace dfd {
 
 struct MtConv { const float *w, *b, *a; int co, ci, k; };
 struct MtDense { const float *w, *b, *a; int out, in; };
+struct MtGemmConv { const float *w, *b, *a; int co, ci, k; };       // [co][ky][kx][ci], channels padded to 32 / 64
 
 struct MtcnnState {
     bool ready = false;
@@ -24,7 +27,9 @@ struct MtcnnState {
     MtDense r4, r51, r52;
     MtConv o1, o2, o3, o4;
     MtDense o5, o61, o62, o63;
-    DevBuf in, a0, a1, prob, reg, win, coef, bnd, tmp, face;
+    MtConv r1p;                           // R-Net conv1 with 32 output channels (4 zero filters)
+    MtGemmConv r2g, r3g, o2g, o3g, o4g;
+    DevBuf in, a0, a1, z, prob, reg, win, coef, bnd, tmp, face, d_lv, d_items, d_pre;
 };
 
 void mtcnn_destroy(dfd_handle* h) {
@@ -60,6 +65,28 @@ MtDense mt_dense(dfd_handle* h, const std::string& q, int out, int in, const cha
     d.b = mt_tensor(h, "mtcnn." + q + ".b", out, ok);
     d.a = prelu ? mt_tensor(h, std::string("mtcnn.") + prelu + ".a", out, ok) : nullptr;
     return d;
+}
+
+MtGemmConv mt_gemm_conv(dfd_handle* h, const std::string& q, int co, int ci, int k, bool* ok) {
+    MtGemmConv c{};
+    c.co = co; c.ci = ci; c.k = k;
+    c.w = mt_tensor(h, "mtcnn." + q + ".wg", (size_t)co * ci * k * k, ok);
+    c.b = mt_tensor(h, "mtcnn." + q + ".bg", co, ok);
+    c.a = mt_tensor(h, "mtcnn." + q + ".ag", co, ok);
+    return c;
+}
+
+// valid k x k conv of `n` maps [ih][iw][ci] on the split-precision MFMA GEMM (fp32-exact products), then PReLU
+int gemm_conv_prelu(dfd_handle* h, const MtGemmConv& c, const float* x, float* y, int n, int ih, int iw) {
+    ConvGeom g;
+    g.H = ih; g.W = iw; g.Ho = ih - c.k + 1; g.Wo = iw - c.k + 1; g.Cin = c.ci; g.ksize = c.k; g.stride = 1; g.pad = 0; g.dil = 1;
+    const int K = c.k * c.k * c.ci;
+    const unsigned short* w3 = split_weights(h, c.w, c.co, K);
+    if (!w3) return DFD_ERR_HIP;
+    if (!launch_conv_gemm_split(x, w3, c.b, nullptr, y, n, g, c.co, ACT_NONE, false, h->stream))
+        return fail(h, DFD_ERR_STATE, "mtcnn: conv shape not supported by the GEMM kernel");
+    launch_mt_prelu(y, c.a, (long long)n * g.Ho * g.Wo * c.co, c.co, h->stream);
+    return DFD_OK;
 }
 
 struct Box { float x1, y1, x2, y2, score, r[4]; };
@@ -176,23 +203,26 @@ void pil_coeffs(int in_size, int out_size, std::vector<int>* coeff, std::vector<
     *ksize_out = ksize;
 }
 
+// The cascade for all crops of a step at once.  Stage 1 runs P-Net over every pyramid level of every crop in one
+// ragged launch per layer and downloads all maps together; stages 2 and 3 batch the candidate windows of all
+// crops; the host does the per-crop box logic in between.  Four stream synchronisations per step instead of
+// ~30 per crop.
 struct Cascade {
     dfd_handle* h;
     MtcnnState* S;
-    const uint8_t* img;      // device, BGR
-    int hh, ww;
-    size_t stride;
-    const char* tap_name;
+    const MtImage* imgs;
+    int n;
+    const char* tap_name;          // parity taps (crop 0 only)
     std::vector<float>* tap;
     int* tap_dims;
 
-    bool want(const std::string& n) const { return tap_name && n == tap_name; }
+    bool want(const std::string& nm) const { return tap_name && nm == tap_name; }
 
-    int upload_windows(const std::vector<MtWindow>& w) {
-        int rc = ensure(h, &S->win, w.size() * sizeof(MtWindow));
+    template <typename T>
+    int upload(DevBuf* buf, const std::vector<T>& v) {
+        int rc = ensure(h, buf, std::max<size_t>(v.size() * sizeof(T), 16));
         if (rc) return rc;
-        DFD_HIP_TRY(h, hipMemcpyAsync(S->win.p, w.data(), w.size() * sizeof(MtWindow), hipMemcpyHostToDevice, h->stream));
-        DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (!v.empty()) DFD_HIP_TRY(h, hipMemcpyAsync(buf->p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
         return DFD_OK;
     }
     int download(const void* dev, size_t floats, std::vector<float>* out) {
@@ -202,79 +232,6 @@ struct Cascade {
         DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
         return DFD_OK;
     }
-
-    // P-Net over one pyramid level: face-probability map [oh][ow] and regression map [oh][ow][4]
-    int pnet(int sh, int sw, std::vector<float>* prob, std::vector<float>* reg, int* oh, int* ow) {
-        hipStream_t s = h->stream;
-        int rc;
-        const std::vector<MtWindow> whole{MtWindow{0, 0, ww, hh}};
-        if ((rc = upload_windows(whole))) return rc;
-        const int c1h = sh - 2, c1w = sw - 2, ph = mt_pool_out(c1h, 2, 2), pw = mt_pool_out(c1w, 2, 2);
-        const int c2h = ph - 2, c2w = pw - 2, c3h = c2h - 2, c3w = c2w - 2;
-        *oh = c3h; *ow = c3w;
-        if (c3h <= 0 || c3w <= 0) { prob->clear(); reg->clear(); return DFD_OK; }
-        if ((rc = ensure(h, &S->in, (size_t)sh * sw * 3 * 4))) return rc;
-        if ((rc = ensure(h, &S->a0, (size_t)c1h * c1w * 32 * 4))) return rc;
-        if ((rc = ensure(h, &S->a1, (size_t)c1h * c1w * 32 * 4))) return rc;
-        if ((rc = ensure(h, &S->prob, (size_t)c3h * c3w * 4))) return rc;
-        if ((rc = ensure(h, &S->reg, (size_t)c3h * c3w * 4 * 4))) return rc;
-        float *in = (float*)S->in.p, *a0 = (float*)S->a0.p, *a1 = (float*)S->a1.p;
-        launch_mt_area_resize(img, stride, (const MtWindow*)S->win.p, 1, sh, sw, in, s);
-        launch_mt_conv(in, S->p1.w, S->p1.b, S->p1.a, a0, 1, sh, sw, 3, 10, 3, s);
-        launch_mt_maxpool(a0, a1, 1, c1h, c1w, 10, 2, 2, s);
-        launch_mt_conv(a1, S->p2.w, S->p2.b, S->p2.a, a0, 1, ph, pw, 10, 16, 3, s);
-        launch_mt_conv(a0, S->p3.w, S->p3.b, S->p3.a, a1, 1, c2h, c2w, 16, 32, 3, s);
-        launch_mt_conv(a1, S->p41.w, S->p41.b, nullptr, a0, 1, c3h, c3w, 32, 2, 1, s);
-        launch_mt_softmax_face(a0, (float*)S->prob.p, (long long)c3h * c3w, s);
-        launch_mt_conv(a1, S->p42.w, S->p42.b, nullptr, (float*)S->reg.p, 1, c3h, c3w, 32, 4, 1, s);
-        DFD_HIP_TRY(h, hipGetLastError());
-        if ((rc = download(S->prob.p, (size_t)c3h * c3w, prob))) return rc;
-        return download(S->reg.p, (size_t)c3h * c3w * 4, reg);
-    }
-
-    // R-Net (size 24) / O-Net (size 48) over `wins`: face probability [n], regression [n][4]
-    int refine(bool onet, const std::vector<MtWindow>& wins, std::vector<float>* prob, std::vector<float>* reg) {
-        hipStream_t s = h->stream;
-        const int n = (int)wins.size(), sz = onet ? 48 : 24;
-        int rc;
-        if ((rc = upload_windows(wins))) return rc;
-        const size_t big = (size_t)n * (sz - 2) * (sz - 2) * (onet ? 32 : 28) * 4;
-        if ((rc = ensure(h, &S->in, (size_t)n * sz * sz * 3 * 4))) return rc;
-        if ((rc = ensure(h, &S->a0, big))) return rc;
-        if ((rc = ensure(h, &S->a1, big))) return rc;
-        if ((rc = ensure(h, &S->prob, (size_t)n * 4))) return rc;
-        if ((rc = ensure(h, &S->reg, (size_t)n * 4 * 4))) return rc;
-        float *in = (float*)S->in.p, *a0 = (float*)S->a0.p, *a1 = (float*)S->a1.p;
-        launch_mt_area_resize(img, stride, (const MtWindow*)S->win.p, n, sz, sz, in, s);
-        if (!onet) {
-            launch_mt_conv(in, S->r1.w, S->r1.b, S->r1.a, a0, n, 24, 24, 3, 28, 3, s);       // 22
-            launch_mt_maxpool(a0, a1, n, 22, 22, 28, 3, 2, s);                                // 11
-            launch_mt_conv(a1, S->r2.w, S->r2.b, S->r2.a, a0, n, 11, 11, 28, 48, 3, s);     // 9
-            launch_mt_maxpool(a0, a1, n, 9, 9, 48, 3, 2, s);                                  // 4
-            launch_mt_conv(a1, S->r3.w, S->r3.b, S->r3.a, a0, n, 4, 4, 48, 64, 2, s);       // 3 -> [n][3][3][64]
-            launch_mt_dense(a0, S->r4.w, S->r4.b, S->r4.a, a1, n, 576, 128, s);
-            launch_mt_dense(a1, S->r51.w, S->r51.b, nullptr, a0, n, 128, 2, s);
-            launch_mt_softmax_face(a0, (float*)S->prob.p, n, s);
-            launch_mt_dense(a1, S->r52.w, S->r52.b, nullptr, (float*)S->reg.p, n, 128, 4, s);
-        } else {
-            launch_mt_conv(in, S->o1.w, S->o1.b, S->o1.a, a0, n, 48, 48, 3, 32, 3, s);       // 46
-            launch_mt_maxpool(a0, a1, n, 46, 46, 32, 3, 2, s);                                // 23
-            launch_mt_conv(a1, S->o2.w, S->o2.b, S->o2.a, a0, n, 23, 23, 32, 64, 3, s);     // 21
-            launch_mt_maxpool(a0, a1, n, 21, 21, 64, 3, 2, s);                                // 10
-            launch_mt_conv(a1, S->o3.w, S->o3.b, S->o3.a, a0, n, 10, 10, 64, 64, 3, s);     // 8
-            launch_mt_maxpool(a0, a1, n, 8, 8, 64, 2, 2, s);                                  // 4
-            launch_mt_conv(a1, S->o4.w, S->o4.b, S->o4.a, a0, n, 4, 4, 64, 128, 2, s);      // 3 -> [n][3][3][128]
-            launch_mt_dense(a0, S->o5.w, S->o5.b, S->o5.a, a1, n, 1152, 256, s);
-            launch_mt_dense(a1, S->o61.w, S->o61.b, nullptr, a0, n, 256, 2, s);
-            launch_mt_softmax_face(a0, (float*)S->prob.p, n, s);
-            launch_mt_dense(a1, S->o62.w, S->o62.b, nullptr, (float*)S->reg.p, n, 256, 4, s);
-            // dense6_3 (landmarks) does not influence the selected crop: not evaluated
-        }
-        DFD_HIP_TRY(h, hipGetLastError());
-        if ((rc = download(S->prob.p, n, prob))) return rc;
-        return download(S->reg.p, (size_t)n * 4, reg);
-    }
-
     void tap_boxes(const std::string& name, const std::vector<Box>& b) {
         if (!want(name)) return;
         tap->clear();
@@ -282,89 +239,251 @@ struct Cascade {
         tap_dims[0] = (int)b.size(); tap_dims[1] = 5; tap_dims[2] = 1;
     }
 
-    // detect_face for one image -> boxes after the three stages
-    int run(std::vector<Box>* out) {
+    struct Level { int crop; double scale; int sh, sw, oh, ow; long long cell_off; };
+
+    // ---- stage 1: P-Net over all pyramid levels of all crops -> per-crop candidate boxes (after regression + rerec)
+    int stage1(std::vector<std::vector<Box>>* out) {
+        hipStream_t s = h->stream;
         int rc;
-        // scale pyramid (double arithmetic, as the package's Python floats)
-        std::vector<double> scales;
-        {
-            const double m = 12.0 / 20.0;
+        std::vector<Level> levels;
+        std::vector<MtLevel> lv;
+        // per layer: items + running totals of output elements (arena offsets are the same running totals)
+        std::vector<MtItem> it_c1, it_p, it_c2, it_c3, it_z, it_r;
+        std::vector<long long> pre_in{0}, pre_c1{0}, pre_p{0}, pre_c2{0}, pre_c3{0}, pre_z{0}, pre_r{0};
+        long long cells = 0;
+        for (int c = 0; c < n; ++c) {
+            const int hh = imgs[c].h, ww = imgs[c].w;
+            const double m = 12.0 / 20.0;                         // scale pyramid in double, as the package's Python floats
             double minl = std::min(hh, ww) * m, scale_i = m;
-            while (minl >= 12) { scales.push_back(scale_i); scale_i *= 0.709; minl *= 0.709; }
+            while (minl >= 12) {
+                const int sh = (int)(hh * scale_i + 1), sw = (int)(ww * scale_i + 1);
+                const int c1h = sh - 2, c1w = sw - 2, ph = mt_pool_out(c1h, 2, 2), pw = mt_pool_out(c1w, 2, 2);
+                const int c2h = ph - 2, c2w = pw - 2, c3h = c2h - 2, c3w = c2w - 2;
+                levels.push_back(Level{c, scale_i, sh, sw, c3h, c3w, cells});
+                lv.push_back(MtLevel{imgs[c].src, (long long)imgs[c].stride, hh, ww, sh, sw, pre_in.back()});
+                it_c1.push_back(MtItem{pre_in.back(), pre_c1.back(), sh, sw});
+                it_p.push_back(MtItem{pre_c1.back(), pre_p.back(), c1h, c1w});
+                it_c2.push_back(MtItem{pre_p.back(), pre_c2.back(), ph, pw});
+                it_c3.push_back(MtItem{pre_c2.back(), pre_c3.back(), c2h, c2w});
+                it_z.push_back(MtItem{pre_c3.back(), pre_z.back(), c3h, c3w});
+                it_r.push_back(MtItem{pre_c3.back(), pre_r.back(), c3h, c3w});
+                pre_in.push_back(pre_in.back() + (long long)sh * sw * 3);
+                pre_c1.push_back(pre_c1.back() + (long long)c1h * c1w * 10);
+                pre_p.push_back(pre_p.back() + (long long)ph * pw * 10);
+                pre_c2.push_back(pre_c2.back() + (long long)c2h * c2w * 16);
+                pre_c3.push_back(pre_c3.back() + (long long)c3h * c3w * 32);
+                pre_z.push_back(pre_z.back() + (long long)c3h * c3w * 2);
+                pre_r.push_back(pre_r.back() + (long long)c3h * c3w * 4);
+                cells += (long long)c3h * c3w;
+                scale_i *= 0.709;
+                minl *= 0.709;
+            }
         }
-        std::vector<Box> all;
-        for (size_t si = 0; si < scales.size(); ++si) {
-            const double scale = scales[si];
-            const int sh = (int)(hh * scale + 1), sw = (int)(ww * scale + 1);
-            std::vector<float> prob, reg;
-            int oh = 0, ow = 0;
-            if ((rc = pnet(sh, sw, &prob, &reg, &oh, &ow))) return rc;
-            if (want("pnet.prob." + std::to_string(si))) { *tap = prob; tap_dims[0] = oh; tap_dims[1] = ow; tap_dims[2] = 1; }
-            if (want("pnet.reg." + std::to_string(si))) { *tap = reg; tap_dims[0] = oh; tap_dims[1] = ow; tap_dims[2] = 4; }
-            // generateBoundingBox: cells with prob >= 0.6 in (y, x) order; float32 arithmetic
+        out->assign(n, {});
+        const int nl = (int)levels.size();
+        std::vector<float> prob, reg;
+        if (nl) {
+            // descriptors: one upload each (pageable source: staged before the call returns)
+            if ((rc = upload(&S->d_lv, lv))) return rc;
+            std::vector<MtItem> items;
+            std::vector<long long> pres;
+            const std::vector<MtItem>* its[6] = {&it_c1, &it_p, &it_c2, &it_c3, &it_z, &it_r};
+            const std::vector<long long>* prs[7] = {&pre_in, &pre_c1, &pre_p, &pre_c2, &pre_c3, &pre_z, &pre_r};
+            for (auto* v : its) items.insert(items.end(), v->begin(), v->end());
+            for (auto* v : prs) pres.insert(pres.end(), v->begin(), v->end());
+            if ((rc = upload(&S->d_items, items))) return rc;
+            if ((rc = upload(&S->d_pre, pres))) return rc;
+            const MtItem* di = (const MtItem*)S->d_items.p;
+            const long long* dp = (const long long*)S->d_pre.p;
+            auto item_at = [&](int k) { return di + (size_t)k * nl; };
+            auto pre_at = [&](int k) { return dp + (size_t)k * (nl + 1); };
+            if ((rc = ensure(h, &S->in, pre_in.back() * 4))) return rc;
+            if ((rc = ensure(h, &S->a0, std::max(pre_c1.back(), pre_c2.back()) * 4))) return rc;
+            if ((rc = ensure(h, &S->a1, std::max(std::max(pre_p.back(), pre_c3.back()), (long long)4) * 4))) return rc;
+            if ((rc = ensure(h, &S->z, pre_z.back() * 4))) return rc;
+            if ((rc = ensure(h, &S->prob, cells * 4))) return rc;
+            if ((rc = ensure(h, &S->reg, pre_r.back() * 4))) return rc;
+            float *in = (float*)S->in.p, *a0 = (float*)S->a0.p, *a1 = (float*)S->a1.p;
+            launch_mt_area_resize_ragged((const MtLevel*)S->d_lv.p, pre_at(0), nl, pre_in.back(), in, s);
+            launch_mt_conv_ragged(in, S->p1.w, S->p1.b, S->p1.a, a0, item_at(0), pre_at(1), nl, pre_c1.back(), 3, 10, 3, s);
+            launch_mt_maxpool_ragged(a0, a1, item_at(1), pre_at(2), nl, pre_p.back(), 10, 2, 2, s);
+            launch_mt_conv_ragged(a1, S->p2.w, S->p2.b, S->p2.a, a0, item_at(2), pre_at(3), nl, pre_c2.back(), 10, 16, 3, s);
+            launch_mt_conv_ragged(a0, S->p3.w, S->p3.b, S->p3.a, a1, item_at(3), pre_at(4), nl, pre_c3.back(), 16, 32, 3, s);
+            launch_mt_conv_ragged(a1, S->p41.w, S->p41.b, nullptr, (float*)S->z.p, item_at(4), pre_at(5), nl, pre_z.back(), 32, 2, 1, s);
+            launch_mt_softmax_face((const float*)S->z.p, (float*)S->prob.p, cells, s);
+            launch_mt_conv_ragged(a1, S->p42.w, S->p42.b, nullptr, (float*)S->reg.p, item_at(5), pre_at(6), nl, pre_r.back(), 32, 4, 1, s);
+            DFD_HIP_TRY(h, hipGetLastError());
+            prob.resize(cells);
+            DFD_HIP_TRY(h, hipMemcpyAsync(prob.data(), S->prob.p, cells * 4, hipMemcpyDeviceToHost, s));
+            if ((rc = download(S->reg.p, (size_t)cells * 4, &reg))) return rc;
+        }
+        // host: generateBoundingBox per level, per-scale NMS, cross-scale NMS, regression, rerec - per crop
+        std::vector<std::vector<Box>> all(n);
+        int level_in_crop = 0, prev_crop = -1;
+        for (const Level& L : levels) {
+            level_in_crop = L.crop == prev_crop ? level_in_crop + 1 : 0;
+            prev_crop = L.crop;
+            const float* P = prob.data() + L.cell_off;
+            const float* R = reg.data() + L.cell_off * 4;
+            if (L.crop == 0) {
+                if (want("pnet.prob." + std::to_string(level_in_crop))) {
+                    tap->assign(P, P + (size_t)std::max(L.oh, 0) * std::max(L.ow, 0));
+                    tap_dims[0] = L.oh; tap_dims[1] = L.ow; tap_dims[2] = 1;
+                }
+                if (want("pnet.reg." + std::to_string(level_in_crop))) {
+                    tap->assign(R, R + (size_t)std::max(L.oh, 0) * std::max(L.ow, 0) * 4);
+                    tap_dims[0] = L.oh; tap_dims[1] = L.ow; tap_dims[2] = 4;
+                }
+            }
             std::vector<Box> bs;
-            const float fs = (float)scale;
-            for (int y = 0; y < oh; ++y)
-                for (int x = 0; x < ow; ++x) {
-                    const float p = prob[(size_t)y * ow + x];
-                    if (!(p >= 0.6f)) continue;
+            const float fs = (float)L.scale;
+            for (int y = 0; y < L.oh; ++y)
+                for (int x = 0; x < L.ow; ++x) {
+                    const float p = P[(size_t)y * L.ow + x];
+                    if (!(p >= 0.6f)) continue;                   // cells with prob >= thresholds[0], (y, x) order; float32
                     Box b{};
                     b.x1 = std::floor((2.f * (float)x + 1.f) / fs);
                     b.y1 = std::floor((2.f * (float)y + 1.f) / fs);
                     b.x2 = std::floor((2.f * (float)x + 12.f) / fs);
                     b.y2 = std::floor((2.f * (float)y + 12.f) / fs);
                     b.score = p;
-                    for (int r = 0; r < 4; ++r) b.r[r] = reg[((size_t)y * ow + x) * 4 + r];
+                    for (int r = 0; r < 4; ++r) b.r[r] = R[((size_t)y * L.ow + x) * 4 + r];
                     bs.push_back(b);
                 }
-            for (int i : nms_iou(bs, 0.5f)) all.push_back(bs[i]);
+            for (int i : nms_iou(bs, 0.5f)) all[L.crop].push_back(bs[i]);
         }
-        std::vector<Box> boxes;
-        for (int i : nms_iou(all, 0.7f)) {
-            Box b = all[i];
-            const float regw = b.x2 - b.x1, regh = b.y2 - b.y1;
-            const float x1 = b.x1 + b.r[0] * regw, y1 = b.y1 + b.r[1] * regh, x2 = b.x2 + b.r[2] * regw, y2 = b.y2 + b.r[3] * regh;
-            b.x1 = x1; b.y1 = y1; b.x2 = x2; b.y2 = y2;
-            rerec(b);
-            boxes.push_back(b);
-        }
-        tap_boxes("stage1", boxes);
-        // second and third stage
-        for (int stage = 2; stage <= 3 && !boxes.empty(); ++stage) {
-            std::vector<MtWindow> wins;
-            std::vector<Box> live;
-            for (const Box& b : boxes) {
-                MtWindow w;
-                if (window_of(b, ww, hh, &w)) { wins.push_back(w); live.push_back(b); }
+        for (int c = 0; c < n; ++c) {
+            for (int i : nms_iou(all[c], 0.7f)) {
+                Box b = all[c][i];
+                const float regw = b.x2 - b.x1, regh = b.y2 - b.y1;
+                const float x1 = b.x1 + b.r[0] * regw, y1 = b.y1 + b.r[1] * regh, x2 = b.x2 + b.r[2] * regw, y2 = b.y2 + b.r[3] * regh;
+                b.x1 = x1; b.y1 = y1; b.x2 = x2; b.y2 = y2;
+                rerec(b);
+                (*out)[c].push_back(b);
             }
-            boxes.clear();
-            if (!wins.empty()) {
-                std::vector<float> prob, reg;
-                if ((rc = refine(stage == 3, wins, &prob, &reg))) return rc;
-                if (want(stage == 2 ? "rnet.prob" : "onet.prob")) { *tap = prob; tap_dims[0] = (int)prob.size(); tap_dims[1] = 1; tap_dims[2] = 1; }
-                if (want(stage == 2 ? "rnet.reg" : "onet.reg")) { *tap = reg; tap_dims[0] = (int)prob.size(); tap_dims[1] = 4; tap_dims[2] = 1; }
-                const float thr = 0.7f;
-                std::vector<Box> pass;
-                for (size_t i = 0; i < live.size(); ++i) {
-                    if (!(prob[i] > thr)) continue;
-                    Box b = live[i];
-                    b.score = prob[i];
-                    for (int r = 0; r < 4; ++r) b.r[r] = reg[i * 4 + r];
-                    pass.push_back(b);
+        }
+        tap_boxes("stage1", (*out)[0]);
+        return DFD_OK;
+    }
+
+    // R-Net (24) / O-Net (48) over `wins` (at most kChunk per launch set): face probability [n], regression [n][4]
+    int refine(bool onet, const std::vector<MtSrcWindow>& wins, std::vector<float>* prob, std::vector<float>* reg) {
+        hipStream_t s = h->stream;
+        const int total = (int)wins.size(), sz = onet ? 48 : 24;
+        constexpr int kChunk = 4096;
+        prob->clear();
+        reg->clear();
+        int rc;
+        if ((rc = upload(&S->win, wins))) return rc;
+        for (int start = 0; start < total; start += kChunk) {
+            const int m = std::min(kChunk, total - start);
+            const MtSrcWindow* wd = (const MtSrcWindow*)S->win.p + start;
+            const size_t big = (size_t)m * (sz - 2) * (sz - 2) * 32 * 4;
+            if ((rc = ensure(h, &S->in, (size_t)m * sz * sz * 3 * 4))) return rc;
+            if ((rc = ensure(h, &S->a0, big))) return rc;
+            if ((rc = ensure(h, &S->a1, big))) return rc;
+            if ((rc = ensure(h, &S->prob, (size_t)m * 4))) return rc;
+            if ((rc = ensure(h, &S->reg, (size_t)m * 4 * 4))) return rc;
+            wd = (const MtSrcWindow*)S->win.p + start;      // (ensure never moves S->win)
+            float *in = (float*)S->in.p, *a0 = (float*)S->a0.p, *a1 = (float*)S->a1.p;
+            launch_mt_area_resize_multi(wd, m, sz, sz, in, s);
+            if (!onet) {
+                launch_mt_conv(in, S->r1p.w, S->r1p.b, S->r1p.a, a0, m, 24, 24, 3, 32, 3, s);      // 22, 32 ch (28 + 4 zero)
+                launch_mt_maxpool(a0, a1, m, 22, 22, 32, 3, 2, s);                                  // 11
+                if ((rc = gemm_conv_prelu(h, S->r2g, a1, a0, m, 11, 11))) return rc;                // 9, 64 ch (48 + 16 zero)
+                launch_mt_maxpool(a0, a1, m, 9, 9, 64, 3, 2, s);                                    // 4
+                if ((rc = gemm_conv_prelu(h, S->r3g, a1, a0, m, 4, 4))) return rc;                  // 3 -> [m][3][3][64]
+                launch_mt_dense(a0, S->r4.w, S->r4.b, S->r4.a, a1, m, 576, 128, s);
+                launch_mt_dense(a1, S->r51.w, S->r51.b, nullptr, a0, m, 128, 2, s);
+                launch_mt_softmax_face(a0, (float*)S->prob.p, m, s);
+                launch_mt_dense(a1, S->r52.w, S->r52.b, nullptr, (float*)S->reg.p, m, 128, 4, s);
+            } else {
+                launch_mt_conv(in, S->o1.w, S->o1.b, S->o1.a, a0, m, 48, 48, 3, 32, 3, s);         // 46
+                launch_mt_maxpool(a0, a1, m, 46, 46, 32, 3, 2, s);                                  // 23
+                if ((rc = gemm_conv_prelu(h, S->o2g, a1, a0, m, 23, 23))) return rc;                // 21
+                launch_mt_maxpool(a0, a1, m, 21, 21, 64, 3, 2, s);                                  // 10
+                if ((rc = gemm_conv_prelu(h, S->o3g, a1, a0, m, 10, 10))) return rc;                // 8
+                launch_mt_maxpool(a0, a1, m, 8, 8, 64, 2, 2, s);                                    // 4
+                if ((rc = gemm_conv_prelu(h, S->o4g, a1, a0, m, 4, 4))) return rc;                  // 3 -> [m][3][3][128]
+                launch_mt_dense(a0, S->o5.w, S->o5.b, S->o5.a, a1, m, 1152, 256, s);
+                launch_mt_dense(a1, S->o61.w, S->o61.b, nullptr, a0, m, 256, 2, s);
+                launch_mt_softmax_face(a0, (float*)S->prob.p, m, s);
+                launch_mt_dense(a1, S->o62.w, S->o62.b, nullptr, (float*)S->reg.p, m, 256, 4, s);
+                // dense6_3 (landmarks) does not influence the selected crop: not evaluated
+            }
+            DFD_HIP_TRY(h, hipGetLastError());
+            std::vector<float> p, r;
+            p.resize(m);
+            DFD_HIP_TRY(h, hipMemcpyAsync(p.data(), S->prob.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+            if ((rc = download(S->reg.p, (size_t)m * 4, &r))) return rc;
+            prob->insert(prob->end(), p.begin(), p.end());
+            reg->insert(reg->end(), r.begin(), r.end());
+        }
+        return DFD_OK;
+    }
+
+    // detect_face for all crops -> per-crop boxes after the three stages
+    int run(std::vector<std::vector<Box>>* out) {
+        int rc;
+        static const bool verbose = getenv("DFD_MT_VERBOSE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+        std::vector<std::vector<Box>> boxes;
+        if ((rc = stage1(&boxes))) return rc;
+        if (verbose) {
+            size_t tot = 0;
+            for (auto& b : boxes) tot += b.size();
+            fprintf(stderr, "[dfd] mtcnn %d crops: stage 1 -> %zu boxes, %.2f ms\n", n, tot, since());
+        }
+        for (int stage = 2; stage <= 3; ++stage) {
+            std::vector<MtSrcWindow> wins;
+            std::vector<std::vector<Box>> live(n);
+            for (int c = 0; c < n; ++c)
+                for (const Box& b : boxes[c]) {
+                    MtWindow w;
+                    if (!window_of(b, imgs[c].w, imgs[c].h, &w)) continue;
+                    wins.push_back(MtSrcWindow{imgs[c].src, (long long)imgs[c].stride, w.x, w.y, w.w, w.h});
+                    live[c].push_back(b);
                 }
+            std::vector<float> prob, reg;
+            if (!wins.empty() && (rc = refine(stage == 3, wins, &prob, &reg))) return rc;
+            size_t k = 0;
+            for (int c = 0; c < n; ++c) {
+                const size_t first = k;
+                std::vector<Box> pass;
+                for (const Box& lb : live[c]) {
+                    if (prob[k] > 0.7f) {                        // thresholds[1] = thresholds[2] = 0.7, strict
+                        Box b = lb;
+                        b.score = prob[k];
+                        for (int r = 0; r < 4; ++r) b.r[r] = reg[k * 4 + r];
+                        pass.push_back(b);
+                    }
+                    ++k;
+                }
+                if (c == 0 && !live[0].empty()) {
+                    if (want(stage == 2 ? "rnet.prob" : "onet.prob")) {
+                        tap->assign(prob.begin() + first, prob.begin() + k);
+                        tap_dims[0] = (int)(k - first); tap_dims[1] = 1; tap_dims[2] = 1;
+                    }
+                    if (want(stage == 2 ? "rnet.reg" : "onet.reg")) {
+                        tap->assign(reg.begin() + first * 4, reg.begin() + k * 4);
+                        tap_dims[0] = (int)(k - first); tap_dims[1] = 4; tap_dims[2] = 1;
+                    }
+                }
+                boxes[c].clear();
                 if (stage == 2) {
-                    for (int i : nms_iou(pass, 0.7f)) { Box b = pass[i]; bbreg(b); rerec(b); boxes.push_back(b); }
+                    for (int i : nms_iou(pass, 0.7f)) { Box b = pass[i]; bbreg(b); rerec(b); boxes[c].push_back(b); }
                 } else {
                     for (Box& b : pass) bbreg(b);
-                    for (int i : nms_min(pass, 0.7f)) boxes.push_back(pass[i]);
+                    for (int i : nms_min(pass, 0.7f)) boxes[c].push_back(pass[i]);
                 }
             }
-            tap_boxes(stage == 2 ? "stage2" : "stage3", boxes);
-        }
-        if (tap_name && tap_dims[0] < 0) {                     // a stage that was never reached is an empty list
-            const std::vector<Box> none;
-            tap_boxes("stage2", none);
-            tap_boxes("stage3", none);
+            tap_boxes(stage == 2 ? "stage2" : "stage3", boxes[0]);
+            if (verbose) {
+                size_t tot = 0;
+                for (auto& b : boxes) tot += b.size();
+                fprintf(stderr, "[dfd] mtcnn stage %d: %zu windows -> %zu boxes, %.2f ms so far\n", stage, wins.size(), tot, since());
+            }
         }
         *out = boxes;
         return DFD_OK;
@@ -397,72 +516,106 @@ int mtcnn_init(dfd_handle* h) {
     S->o61 = mt_dense(h, "onet.dense6_1", 2, 256, nullptr, &ok);
     S->o62 = mt_dense(h, "onet.dense6_2", 4, 256, nullptr, &ok);
     S->o63 = mt_dense(h, "onet.dense6_3", 10, 256, nullptr, &ok);
+    S->r1p.co = 32; S->r1p.ci = 3; S->r1p.k = 3;
+    S->r1p.w = mt_tensor(h, "mtcnn.rnet.conv1.wp", 3 * 3 * 3 * 32, &ok);
+    S->r1p.b = mt_tensor(h, "mtcnn.rnet.conv1.bp", 32, &ok);
+    S->r1p.a = mt_tensor(h, "mtcnn.rnet.conv1.ap", 32, &ok);
+    S->r2g = mt_gemm_conv(h, "rnet.conv2", 64, 32, 3, &ok);
+    S->r3g = mt_gemm_conv(h, "rnet.conv3", 64, 64, 2, &ok);
+    S->o2g = mt_gemm_conv(h, "onet.conv2", 64, 32, 3, &ok);
+    S->o3g = mt_gemm_conv(h, "onet.conv3", 64, 64, 3, &ok);
+    S->o4g = mt_gemm_conv(h, "onet.conv4", 128, 64, 2, &ok);
     if (!ok) return DFD_ERR_BLOB;
     S->ready = true;
     return DFD_OK;
 }
 
-// MTCNN.forward on a BGR image already in HBM: selected box + the 160x160 BGR u8 crop in S->face.
-// *found = 0: no face passed the cascade, or the selected box is degenerate (the package raises there and the
-// reference call site returns None).
+// MTCNN.forward on `n` BGR images already in HBM: per image the selected box, found flag, and the 160x160 BGR u8
+// crop written to faces_out + i * 160*160*3 (zero-filled when not found).  found = 0: no face passed the cascade,
+// or the selected box is degenerate (the package raises there and the reference call site returns None).
+int mtcnn_align_batch_device(dfd_handle* h, const MtImage* imgs, int n, uint8_t* faces_out, float* boxes_out, char* found,
+                             const char* tap_name, std::vector<float>* tap, int* tap_dims) {
+    MtcnnState* S = h->mtcnn;
+    if (!S || !S->ready) return fail(h, DFD_ERR_STATE, "the weights blob holds no MTCNN cascade");
+    for (int i = 0; i < n; ++i)
+        if (imgs[i].h <= 0 || imgs[i].w <= 0) return fail(h, DFD_ERR_ARG, "mtcnn: empty image");
+    Cascade c{h, S, imgs, n, tap_name, tap, tap_dims};
+    std::vector<std::vector<Box>> boxes;
+    int rc = c.run(&boxes);
+    if (rc) return rc;
+    hipStream_t s = h->stream;
+    // selection + extract_face geometry on the host; all resize coefficient tables in one upload
+    struct Job { int x1, y1, cw, ch, kx, ky; size_t cx, bx, cy, by, tmp; };
+    std::vector<Job> jobs(n);
+    std::vector<int> tables;
+    size_t tmp_bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        found[i] = 0;
+        if (boxes[i].empty()) continue;
+        // select_boxes(method="probability"): np.argsort(probs)[::-1][0] = the LAST of the ascending stable order
+        int best = 0;
+        for (int k = 1; k < (int)boxes[i].size(); ++k)
+            if (boxes[i][k].score >= boxes[i][best].score) best = k;
+        const Box& b = boxes[i][best];
+        if (boxes_out) { float* o = boxes_out + 5 * i; o[0] = b.x1; o[1] = b.y1; o[2] = b.x2; o[3] = b.y2; o[4] = b.score; }
+        // extract_face(margin 0): int() of the clipped float corners
+        const int x1 = (int)std::max(b.x1, 0.f), y1 = (int)std::max(b.y1, 0.f);
+        const int x2 = (int)std::min(b.x2, (float)imgs[i].w), y2 = (int)std::min(b.y2, (float)imgs[i].h);
+        if (x2 <= x1 || y2 <= y1) continue;
+        Job j{x1, y1, x2 - x1, y2 - y1, 0, 0, 0, 0, 0, 0, tmp_bytes};
+        std::vector<int> coeff, bounds;
+        if (j.cw != 160) {
+            pil_coeffs(j.cw, 160, &coeff, &bounds, &j.kx);
+            j.cx = tables.size(); tables.insert(tables.end(), coeff.begin(), coeff.end());
+            j.bx = tables.size(); tables.insert(tables.end(), bounds.begin(), bounds.end());
+            tmp_bytes += ((size_t)j.ch * 160 * 3 + 255) & ~(size_t)255;
+        }
+        if (j.ch != 160) {
+            pil_coeffs(j.ch, 160, &coeff, &bounds, &j.ky);
+            j.cy = tables.size(); tables.insert(tables.end(), coeff.begin(), coeff.end());
+            j.by = tables.size(); tables.insert(tables.end(), bounds.begin(), bounds.end());
+        }
+        jobs[i] = j;
+        found[i] = 1;
+    }
+    if ((rc = c.upload(&S->coef, tables))) return rc;
+    if ((rc = ensure(h, &S->tmp, std::max<size_t>(tmp_bytes, 16)))) return rc;
+    const int* T = (const int*)S->coef.p;
+    for (int i = 0; i < n; ++i) {
+        uint8_t* face = faces_out + (size_t)i * 160 * 160 * 3;
+        if (!found[i]) { DFD_HIP_TRY(h, hipMemsetAsync(face, 0, 160 * 160 * 3, s)); continue; }
+        const Job& j = jobs[i];
+        // crop.resize((160, 160), BILINEAR): horizontal pass into tmp [ch][160][3], vertical pass into the face slot
+        const uint8_t* src = imgs[i].src;
+        size_t sstride = imgs[i].stride;
+        int sx = j.x1, sy = j.y1;
+        if (j.cw != 160) {
+            uint8_t* dst = j.ch == 160 ? face : (uint8_t*)S->tmp.p + j.tmp;
+            launch_mt_pil_pass(src, sstride, sx, sy, j.cw, j.ch, T + j.cx, T + j.bx, j.kx, 160, 0, dst, s);
+            src = dst; sstride = 160 * 3; sx = 0; sy = 0;
+        }
+        if (j.ch != 160) launch_mt_pil_pass(src, sstride, sx, sy, 160, j.ch, T + j.cy, T + j.by, j.ky, 160, 1, face, s);
+        else if (j.cw == 160)                                // already 160 x 160: plain copy of the window
+            DFD_HIP_TRY(h, hipMemcpy2DAsync(face, 160 * 3, imgs[i].src + (size_t)j.y1 * imgs[i].stride + (size_t)j.x1 * 3,
+                                            imgs[i].stride, 160 * 3, 160, hipMemcpyDeviceToDevice, s));
+    }
+    DFD_HIP_TRY(h, hipGetLastError());
+    DFD_HIP_TRY(h, hipStreamSynchronize(s));          // `tables` (host) feeds the copy above
+    return DFD_OK;
+}
+
 int mtcnn_align_device(dfd_handle* h, const uint8_t* img_dev, int hh, int ww, size_t stride, float* box_out, int* found,
                        const char* tap_name, std::vector<float>* tap, int* tap_dims) {
     MtcnnState* S = h->mtcnn;
     if (!S || !S->ready) return fail(h, DFD_ERR_STATE, "the weights blob holds no MTCNN cascade");
-    if (hh <= 0 || ww <= 0) return fail(h, DFD_ERR_ARG, "mtcnn: empty image");
-    *found = 0;
-    Cascade c{h, S, img_dev, hh, ww, stride, tap_name, tap, tap_dims};
-    std::vector<Box> boxes;
-    int rc = c.run(&boxes);
+    int rc = ensure(h, &S->face, 160 * 160 * 3);
     if (rc) return rc;
-    if (boxes.empty()) return DFD_OK;
-    // select_boxes(method="probability"): np.argsort(probs)[::-1][0] = the LAST of the ascending stable order
-    int best = 0;
-    for (int i = 1; i < (int)boxes.size(); ++i)
-        if (boxes[i].score >= boxes[best].score) best = i;
-    const Box& b = boxes[best];
-    if (box_out) { box_out[0] = b.x1; box_out[1] = b.y1; box_out[2] = b.x2; box_out[3] = b.y2; box_out[4] = b.score; }
-    // extract_face(margin 0): int() of the clipped float corners
-    const int x1 = (int)std::max(b.x1, 0.f), y1 = (int)std::max(b.y1, 0.f);
-    const int x2 = (int)std::min(b.x2, (float)ww), y2 = (int)std::min(b.y2, (float)hh);
-    if (x2 <= x1 || y2 <= y1) return DFD_OK;
-    const int cw = x2 - x1, ch = y2 - y1;
-    if ((rc = ensure(h, &S->face, 160 * 160 * 3))) return rc;
-    hipStream_t s = h->stream;
-    // crop.resize((160, 160), BILINEAR): horizontal pass into tmp [ch][160][3], vertical pass into face
-    const uint8_t* src = img_dev;
-    size_t sstride = stride;
-    int sx = x1, sy = y1;
-    std::vector<int> coeff, bounds;
-    int ksize = 0;
-    if (cw != 160) {
-        pil_coeffs(cw, 160, &coeff, &bounds, &ksize);
-        if ((rc = ensure(h, &S->coef, coeff.size() * 4))) return rc;
-        if ((rc = ensure(h, &S->bnd, bounds.size() * 4))) return rc;
-        if ((rc = ensure(h, &S->tmp, (size_t)ch * 160 * 3))) return rc;
-        DFD_HIP_TRY(h, hipMemcpyAsync(S->coef.p, coeff.data(), coeff.size() * 4, hipMemcpyHostToDevice, s));
-        DFD_HIP_TRY(h, hipMemcpyAsync(S->bnd.p, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice, s));
-        const bool last = ch == 160;
-        launch_mt_pil_pass(src, sstride, sx, sy, cw, ch, (const int*)S->coef.p, (const int*)S->bnd.p, ksize, 160, 0,
-                           (uint8_t*)(last ? S->face.p : S->tmp.p), s);
-        DFD_HIP_TRY(h, hipStreamSynchronize(s));        // coeff/bounds are stack temporaries
-        src = (const uint8_t*)S->tmp.p; sstride = 160 * 3; sx = 0; sy = 0;
-    }
-    if (ch != 160) {
-        pil_coeffs(ch, 160, &coeff, &bounds, &ksize);
-        if ((rc = ensure(h, &S->coef, coeff.size() * 4))) return rc;
-        if ((rc = ensure(h, &S->bnd, bounds.size() * 4))) return rc;
-        DFD_HIP_TRY(h, hipMemcpyAsync(S->coef.p, coeff.data(), coeff.size() * 4, hipMemcpyHostToDevice, s));
-        DFD_HIP_TRY(h, hipMemcpyAsync(S->bnd.p, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice, s));
-        launch_mt_pil_pass(src, sstride, sx, sy, cw == 160 ? cw : 160, ch, (const int*)S->coef.p, (const int*)S->bnd.p, ksize,
-                           160, 1, (uint8_t*)S->face.p, s);
-        DFD_HIP_TRY(h, hipStreamSynchronize(s));
-    } else if (cw == 160) {                              // already 160 x 160: plain copy of the window
-        DFD_HIP_TRY(h, hipMemcpy2DAsync(S->face.p, 160 * 3, img_dev + (size_t)y1 * stride + (size_t)x1 * 3, stride, 160 * 3, 160,
-                                        hipMemcpyDeviceToDevice, s));
-    }
-    DFD_HIP_TRY(h, hipGetLastError());
-    *found = 1;
+    const MtImage img{img_dev, hh, ww, stride};
+    char f = 0;
+    float box[5] = {0, 0, 0, 0, 0};
+    if ((rc = mtcnn_align_batch_device(h, &img, 1, (uint8_t*)S->face.p, box, &f, tap_name, tap, tap_dims))) return rc;
+    if (box_out) memcpy(box_out, box, sizeof box);
+    *found = f;
     return DFD_OK;
 }
 

@@ -7,6 +7,11 @@
 namespace dfd {
 
 struct MtWindow { int x, y, w, h; };      // source window in pixels
+struct MtSrcWindow { const uint8_t* src; long long stride; int x, y, w, h; };     // ... of the image at `src`
+// one pyramid level of one crop: source image, output size, offset of its [oh][ow][3] block in the input arena
+struct MtLevel { const uint8_t* src; long long stride; int h, w, oh, ow; long long out_off; };
+// one image of a ragged layer launch: offsets (floats) into the input / output arenas, input size
+struct MtItem { long long in_off, out_off; int ih, iw; };
 
 // interpolate(mode="area") of `n` windows of a u8 BGR image to oh x ow, RGB order, (x - 127.5) / 128
 void launch_mt_area_resize(const uint8_t* src, size_t stride, const MtWindow* win_dev, int n, int oh, int ow, float* dst,
@@ -24,6 +29,17 @@ void launch_mt_softmax_face(const float* z, float* p, long long n, hipStream_t s
 // one pass of Pillow's 8-bit resize; coeff [out][ksize] int32 (22 fractional bits), bounds [out][2] = (first, count)
 void launch_mt_pil_pass(const uint8_t* src, size_t stride, int x0, int y0, int sw, int sh, const int* coeff_dev,
                         const int* bounds_dev, int ksize, int out, int vertical, uint8_t* dst, hipStream_t s);
+// ragged variants: `n` images of different sizes per launch; pre[n + 1] = running total of output elements
+void launch_mt_area_resize_ragged(const MtLevel* lv_dev, const long long* pre_dev, int n, long long total, float* dst,
+                                  hipStream_t s);
+void launch_mt_conv_ragged(const float* x, const float* w, const float* b, const float* slope, float* y,
+                           const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co, int k,
+                           hipStream_t s);
+void launch_mt_maxpool_ragged(const float* x, float* y, const MtItem* items_dev, const long long* pre_dev, int n, long long total,
+                              int c, int k, int st, hipStream_t s);
+void launch_mt_area_resize_multi(const MtSrcWindow* win_dev, int n, int oh, int ow, float* dst, hipStream_t s);
+// in-place PReLU over NHWC data with `c` channels
+void launch_mt_prelu(float* x, const float* slope, long long n, int c, hipStream_t s);
 void launch_mt_face_chw(const uint8_t* bgr, float* out, int hw, hipStream_t s);
 
 }  // namespace dfd

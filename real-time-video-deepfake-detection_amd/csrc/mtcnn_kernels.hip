@@ -179,4 +179,138 @@ void launch_mt_face_chw(const uint8_t* bgr, float* out, int hw, hipStream_t s) {
     hipLaunchKernelGGL(mt_face_chw_kernel, dim3((3 * hw + 255) / 256), dim3(256), 0, s, bgr, out, hw);
 }
 
+// ------------------------------------------------------------------------------------------------ ragged
+// Stage 1 runs P-Net over every pyramid level of every crop of a step: a few hundred small images of different
+// sizes.  One launch per layer covers them all: `items` describes each image (offsets into the layer's input and
+// output arenas, input size), `pre` is the running total of output elements; a thread finds its image by binary
+// search.  Arithmetic per element is exactly that of the single-image kernels above.
+__device__ __forceinline__ int mt_find(const long long* __restrict__ pre, int n, long long t) {
+    int lo = 0, hi = n;                     // pre[lo] <= t < pre[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pre[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void mt_area_resize_ragged_kernel(const MtLevel* __restrict__ lv,
+                                                                    const long long* __restrict__ pre, int n,
+                                                                    float* __restrict__ dst) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= pre[n]) return;
+    const int i = mt_find(pre, n, t);
+    const MtLevel L = lv[i];
+    const long long r = t - pre[i];
+    const int c = (int)(r % 3), ox = (int)((r / 3) % L.ow), oy = (int)(r / 3 / L.ow);
+    const int y0 = (int)(((long long)oy * L.h) / L.oh), y1 = (int)((((long long)oy + 1) * L.h + L.oh - 1) / L.oh);
+    const int x0 = (int)(((long long)ox * L.w) / L.ow), x1 = (int)((((long long)ox + 1) * L.w + L.ow - 1) / L.ow);
+    const uint8_t* p = L.src + (2 - c);
+    float sum = 0.f;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) sum += (float)p[(size_t)y * L.stride + (size_t)x * 3];
+    const float mean = sum / (float)((y1 - y0) * (x1 - x0));
+    dst[L.out_off + r] = (mean - 127.5f) * 0.0078125f;
+}
+
+void launch_mt_area_resize_ragged(const MtLevel* lv_dev, const long long* pre_dev, int n, long long total, float* dst,
+                                  hipStream_t s) {
+    if (total <= 0) return;
+    hipLaunchKernelGGL(mt_area_resize_ragged_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, lv_dev, pre_dev, n, dst);
+}
+
+__global__ __launch_bounds__(256) void mt_conv_ragged_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, const float* __restrict__ slope,
+                                                             float* __restrict__ y, const MtItem* __restrict__ items,
+                                                             const long long* __restrict__ pre, int n, int ci, int co, int k) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= pre[n]) return;
+    const int i = mt_find(pre, n, t);
+    const MtItem it = items[i];
+    const long long r = t - pre[i];
+    const int ow = it.iw - k + 1;
+    const int o = (int)(r % co), ox = (int)((r / co) % ow), oy = (int)(r / co / ow);
+    const float* xp = x + it.in_off + ((size_t)oy * it.iw + ox) * ci;
+    float acc = 0.f;
+    for (int c = 0; c < ci; ++c)
+        for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx)
+                acc = fmaf(xp[((size_t)ky * it.iw + kx) * ci + c], w[(((size_t)c * k + ky) * k + kx) * co + o], acc);
+    acc += b[o];
+    if (slope) acc = acc >= 0.f ? acc : acc * slope[o];
+    y[it.out_off + r] = acc;
+}
+
+void launch_mt_conv_ragged(const float* x, const float* w, const float* b, const float* slope, float* y,
+                           const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co, int k,
+                           hipStream_t s) {
+    if (total <= 0) return;
+    hipLaunchKernelGGL(mt_conv_ragged_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, b, slope, y, items_dev,
+                       pre_dev, n, ci, co, k);
+}
+
+__global__ __launch_bounds__(256) void mt_maxpool_ragged_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                const MtItem* __restrict__ items, const long long* __restrict__ pre,
+                                                                int n, int c, int k, int st) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= pre[n]) return;
+    const int i = mt_find(pre, n, t);
+    const MtItem it = items[i];
+    const long long r = t - pre[i];
+    int ow = (it.iw - k + st - 1) / st + 1;
+    if ((ow - 1) * st >= it.iw) --ow;
+    const int ch = (int)(r % c), ox = (int)((r / c) % ow), oy = (int)(r / c / ow);
+    float m = -INFINITY;
+    for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx) {
+            const int yy = oy * st + ky, xx = ox * st + kx;
+            if (yy < it.ih && xx < it.iw) m = fmaxf(m, x[it.in_off + ((size_t)yy * it.iw + xx) * c + ch]);
+        }
+    y[it.out_off + r] = m;
+}
+
+void launch_mt_maxpool_ragged(const float* x, float* y, const MtItem* items_dev, const long long* pre_dev, int n, long long total,
+                              int c, int k, int st, hipStream_t s) {
+    if (total <= 0) return;
+    hipLaunchKernelGGL(mt_maxpool_ragged_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, items_dev, pre_dev, n, c,
+                       k, st);
+}
+
+// windows that live in different images (the crops of a step): per-window source pointer and stride
+__global__ __launch_bounds__(256) void mt_area_resize_multi_kernel(const MtSrcWindow* __restrict__ win, int n, int oh, int ow,
+                                                                   float* __restrict__ dst) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)n * oh * ow * 3;
+    if (t >= total) return;
+    const int c = (int)(t % 3);
+    const int ox = (int)((t / 3) % ow), oy = (int)((t / 3 / ow) % oh), i = (int)(t / 3 / ow / oh);
+    const MtSrcWindow w = win[i];
+    const int y0 = (int)(((long long)oy * w.h) / oh), y1 = (int)((((long long)oy + 1) * w.h + oh - 1) / oh);
+    const int x0 = (int)(((long long)ox * w.w) / ow), x1 = (int)((((long long)ox + 1) * w.w + ow - 1) / ow);
+    const uint8_t* p = w.src + (size_t)w.y * w.stride + (size_t)w.x * 3 + (2 - c);
+    float sum = 0.f;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) sum += (float)p[(size_t)y * w.stride + (size_t)x * 3];
+    const float mean = sum / (float)((y1 - y0) * (x1 - x0));
+    dst[t] = (mean - 127.5f) * 0.0078125f;
+}
+
+void launch_mt_area_resize_multi(const MtSrcWindow* win_dev, int n, int oh, int ow, float* dst, hipStream_t s) {
+    const long long total = (long long)n * oh * ow * 3;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(mt_area_resize_multi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, win_dev, n, oh, ow, dst);
+}
+
+__global__ __launch_bounds__(256) void mt_prelu_kernel(float* __restrict__ x, const float* __restrict__ slope, long long n, int c) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const float v = x[t];
+    x[t] = v >= 0.f ? v : v * slope[t % c];
+}
+
+void launch_mt_prelu(float* x, const float* slope, long long n, int c, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(mt_prelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, slope, n, c);
+}
+
 }  // namespace dfd

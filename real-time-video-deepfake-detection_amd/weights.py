@@ -267,7 +267,7 @@ def seeded_mtcnn_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
     """
     rs = np.random.RandomState(seed + 2000)
     sd: Dict[str, np.ndarray] = {}
-    head_bias = {"pnet.conv4_1": (-1.1, 1.0), "rnet.dense5_1": (1.6, 1.5), "onet.dense6_1": (0.8, 1.5)}   # (mean, std) of the face-vs-background logit
+    head_bias = {"pnet.conv4_1": (-0.9, 1.0), "rnet.dense5_1": (2.4, 1.5), "onet.dense6_1": (0.8, 1.5)}   # (mean, std) of the face-vs-background logit
     for net in ("pnet", "rnet", "onet"):
         for name, co, ci, k in MTCNN_CONVS[net]:
             q = f"{net}.{name}"
@@ -334,7 +334,9 @@ def _calibrate_mtcnn_heads(sd: Dict[str, np.ndarray], rs, targets) -> None:
             size = {"pnet": 40, "rnet": 24, "onet": 48}[net]
             # image-like inputs: a per-sample colour offset and a smooth ramp under the pixel noise
             base = rs.randn(64, 3, 1, 1) * 0.3 + np.linspace(-0.3, 0.3, size).reshape(1, 1, 1, size) * rs.randn(64, 1, 1, 1)
-            x = torch.from_numpy((base + rs.randn(64, 3, size, size) * 0.15).astype(np.float32))
+            x = base + rs.randn(64, 3, size, size) * 0.15
+            x[32:] = (rs.randint(50, 200, (32, 3, size, size)) - 127.5) * 0.0078125      # and plain pixel noise (bench frames)
+            x = torch.from_numpy(x.astype(np.float32))
             feat = trunk(net, x)
             w = t[q + ".weight"].reshape(2, -1)
             d = feat @ (w[1] - w[0])
@@ -367,6 +369,30 @@ def pack_mtcnn_tensors(sd: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
             t[f"mtcnn.{net}.{name}.b"] = np.asarray(sd[f"{net}.{name}.bias"], np.float32)
         for name, c in MTCNN_PRELU[net]:
             t[f"mtcnn.{net}.{name}.a"] = np.asarray(sd[f"{net}.{name}.weight"], np.float32).reshape(c)
+
+    # The R-/O-Net convolutions behind the first one run on the MFMA implicit-GEMM kernel (C_in % 32 == 0):
+    # weights [co][ky][kx][ci] with channels zero-padded to 32 / 64 (R-Net: 28 -> 32, 48 -> 64; a padded channel
+    # is bias 0 -> PReLU(0) = 0 and meets zero weights downstream).
+    def pad_to(a, n, axis, fill=0.0):
+        padw = [(0, 0)] * a.ndim
+        padw[axis] = (0, n - a.shape[axis])
+        return np.pad(a, padw, constant_values=fill)
+
+    def gemm_conv(net, name, prelu, co_pad, ci_pad):
+        w = np.asarray(sd[f"{net}.{name}.weight"], np.float32).transpose(0, 2, 3, 1)          # [co][ky][kx][ci]
+        t[f"mtcnn.{net}.{name}.wg"] = np.ascontiguousarray(pad_to(pad_to(w, ci_pad, 3), co_pad, 0))
+        t[f"mtcnn.{net}.{name}.bg"] = pad_to(np.asarray(sd[f"{net}.{name}.bias"], np.float32), co_pad, 0)
+        t[f"mtcnn.{net}.{name}.ag"] = pad_to(np.asarray(sd[f"{net}.{prelu}.weight"], np.float32).reshape(-1), co_pad, 0)
+
+    w1 = t["mtcnn.rnet.conv1.w"]                                                              # [ci][ky][kx][28] -> 32
+    t["mtcnn.rnet.conv1.wp"] = np.ascontiguousarray(pad_to(w1, 32, 3))
+    t["mtcnn.rnet.conv1.bp"] = pad_to(t["mtcnn.rnet.conv1.b"], 32, 0)
+    t["mtcnn.rnet.conv1.ap"] = pad_to(t["mtcnn.rnet.prelu1.a"], 32, 0)
+    gemm_conv("rnet", "conv2", "prelu2", 64, 32)
+    gemm_conv("rnet", "conv3", "prelu3", 64, 64)
+    gemm_conv("onet", "conv2", "prelu2", 64, 32)
+    gemm_conv("onet", "conv3", "prelu3", 64, 64)
+    gemm_conv("onet", "conv4", "prelu4", 128, 64)
     return t
 
 
