@@ -234,7 +234,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (torch.manual_seed(1) randn crops, seeded random-init weights)",
         "config": {"workload": "configs[1]: batch=256 random 224x224 crops, EfficientNet-B0 fp32 inference",
-                   "batch_per_gpu": args.batch, "parallelism": f"frame-shard x{world}, no data-path collective"},
+                   "batch_per_gpu": args.batch, "parallelism": f"frame-shard x{world}, no data-path collective",
+                   "arithmetic": "fp32 storage and accumulation; 1x1-conv products are fp32-exact (each operand = exact sum "
+                                 "of three bf16 terms, six cross terms on the bf16 MFMA; the dropped terms are < 2^-24 "
+                                 "relative); DFD_SPLIT_GEMM=0 runs the same GEMMs on the fp32 MFMA instead"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "dfd::dw_kernel<...> / dfd::mbconv_kernel<...> (the 16 depthwise launches per step; blocks 1-5 compute their 1x1 expand inside the launch)",

@@ -684,12 +684,18 @@ static void s6_run(const float* X, const unsigned short* W3, const float* bias, 
                 if ((double)tiles / ((double)t.nblocks * bn_tiles) < 0.7) continue;      // mostly padding
                 if ((long long)t.mblocks * t.nblocks > (1 << 20)) continue;
                 s6_dispatch<CONV, GATE>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
-                hipEventRecord(e0, s);
-                for (int r = 0; r < 3; ++r)
-                    s6_dispatch<CONV, GATE>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
-                hipEventRecord(e1, s);
-                float ms = 0.f;
-                if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+                float ms = 1e30f;
+                bool ok = true;
+                for (int rep = 0; rep < 2 && ok; ++rep) {          // best of two groups of three: robust to a stray hiccup
+                    hipEventRecord(e0, s);
+                    for (int r = 0; r < 3; ++r)
+                        s6_dispatch<CONV, GATE>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
+                    hipEventRecord(e1, s);
+                    float m1 = 0.f;
+                    ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&m1, e0, e1) == hipSuccess;
+                    if (ok && m1 < ms) ms = m1;
+                }
+                if (!ok) continue;
                 if (getenv("DFD_S6_VERBOSE") && atoi(getenv("DFD_S6_VERBOSE")) > 1)
                     fprintf(stderr, "[dfd]   kind %d %dx%d mt=%d nt=%d: %.1f us\n", t.kind, t.wm, t.wn, t.mt, t.nt, ms * 1000.f / 3.f);
                 if (ms < best_ms) { best_ms = ms; tile = t; }
