@@ -63,7 +63,8 @@ int dfd_max_batch(const dfd_handle* h);
  *   "split_gemm" (default 1, env DFD_SPLIT_GEMM): 1x1 convs (N >= 16) and the detector's k x k convs run on
  *   the split-precision GEMM (each fp32 operand = exact sum of three bf16 terms, six products on the bf16
  *   MFMA, fp32 accumulate: fp32-dot-product accuracy); 0 = the fp32 MFMA kernel everywhere.
- *   "mtcnn" (default 1): align every crop with the MTCNN cascade when the blob carries one. */
+ *   "mtcnn" (default 1): align every crop with the MTCNN cascade when the blob carries one.
+ *   "profile_stride" (default 1): between dfd_b0_profile_begin/end only every k-th forward records events. */
 int dfd_set_option(dfd_handle* h, const char* name, int value);
 
 /* ---- device memory and stream plumbing (no reference counterpart) -------------- */
@@ -95,7 +96,7 @@ int dfd_b0_tap(dfd_handle* h, const float* nchw_dev, int n, const char* name,
 /* Per-launch timing with HIP events on the handle's stream.  Between begin and end every
  * dfd_classify_nchw_device call records an event after each kernel launch; end synchronises
  * and returns, per launch position, the elapsed milliseconds summed over the `steps`
- * forwards seen ("stem", "b<i>.exp", "b<i>.dw", "b<i>.se", "b<i>.proj", "head", "avgpool",
+ * instrumented forwards (every forward, or every "profile_stride"-th one) ("stem", "b<i>.exp", "b<i>.dw", "b<i>.se", "b<i>.proj", "head", "avgpool",
  * "mlp").  `names` receives pointers to static strings. */
 int dfd_b0_profile_begin(dfd_handle* h);
 int dfd_b0_profile_end(dfd_handle* h, float* ms_sum, const char** names, int max_layers,

@@ -122,6 +122,7 @@ int dfd_set_option(dfd_handle* h, const char* name, int value) {
     if (strcmp(name, "fuse_stem") == 0) { h->fuse_stem = value != 0; return DFD_OK; }
     if (strcmp(name, "split_gemm") == 0) { h->split_gemm = value != 0; return DFD_OK; }
     if (strcmp(name, "mtcnn") == 0) { h->use_mtcnn = value != 0; return DFD_OK; }
+    if (strcmp(name, "profile_stride") == 0) { h->prof_stride = value > 0 ? value : 1; return DFD_OK; }
     return fail(h, DFD_ERR_ARG, "unknown option '%s'", name);
 }
 
@@ -177,8 +178,11 @@ int dfd_classify_nchw_device(dfd_handle* h, const float* nchw_dev, int n, float*
     if (!h) return DFD_ERR_ARG;
     if (!nchw_dev || !logits_dev) return fail(h, DFD_ERR_ARG, "classify: null pointer");
     DFD_HIP_TRY(h, hipSetDevice(h->device));
-    if (h->prof.enabled) ++h->prof_steps;
-    return b0_forward(h, nchw_dev, n, logits_dev, nullptr, h->prof.enabled ? &h->prof : nullptr);
+    // between profile_begin and profile_end every prof_stride-th forward carries the per-launch events (an event
+    // after each of the ~63 launches costs 5 % of a batch-256 step: 3.85 vs 3.66 ms)
+    const bool sample = h->prof.enabled && (h->prof_seen++ % h->prof_stride == 0);
+    if (sample) ++h->prof_steps;
+    return b0_forward(h, nchw_dev, n, logits_dev, nullptr, sample ? &h->prof : nullptr);
 }
 
 int dfd_classify_nchw(dfd_handle* h, const float* nchw_host, int n, float* logits_host) {
@@ -231,6 +235,7 @@ int dfd_b0_profile_begin(dfd_handle* h) {
     h->prof.names.clear();
     h->prof.enabled = true;
     h->prof_steps = 0;
+    h->prof_seen = 0;
     return DFD_OK;
 }
 

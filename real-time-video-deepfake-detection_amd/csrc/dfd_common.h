@@ -100,7 +100,8 @@ struct dfd_handle {
     bool split_gemm = true;              // 1x1 / k x k convs on the bf16x3-split MFMA path (gemm_split.hip)
     std::map<const float*, unsigned short*> wsplit;   // fp32 weight tensor -> its three-plane bf16 split
     dfd::B0Prof prof;                    // layer events between profile_begin/end
-    int prof_steps = 0;
+    int prof_steps = 0;                  // forwards that carried events
+    int prof_seen = 0, prof_stride = 1;  // forwards since profile_begin; every prof_stride-th one is instrumented
     std::string err;
 };
 
