@@ -32,7 +32,8 @@ namespace dfd {
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));      // (HIP's uint4 struct does not always leave the stack)
 
-constexpr int S6_BK = 32;                 // K per LDS stage = K of one MFMA
+constexpr int S6_BK = 32;                 // K of one MFMA = one K-step
+constexpr int S6_KPAD = 64;               // weight planes are zero-padded in K to two K-steps (pw6 with KS = 2)
 #ifndef S6_XD
 #define S6_XD 3                           // pw6: K-steps of activation prefetch in flight (1 or 3)
 #endif
@@ -49,7 +50,7 @@ constexpr int S6_ROWB = 3 * 64;           // bytes per weight row per stage: 3 p
 // cycles measured).  No padding, so two buffers of the widest block are 48 KB: three blocks per CU.
 __host__ __device__ constexpr int s6_chunk_pos(int row, int c) { return (c + 6 * ((row >> 2) & 1)) % 12; }
 
-// W [N][K] fp32 -> three planes [Np][Kp] bf16, zero outside N x K (Kp = K rounded up to a stage, Np = s6_np(N)):
+// W [N][K] fp32 -> three planes [Np][Kp] bf16, zero outside N x K (Kp = K rounded up to 64, Np = s6_np(N)):
 // the GEMM's weight loads need neither clamps nor zero-fill selects.
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ W, __bf16* __restrict__ out,
                                                             int N, int K, int Np, int Kp) {
@@ -67,11 +68,11 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
 }
 
 size_t split_weights_count(int N, int K) {
-    return (size_t)s6_np(N) * ((K + S6_BK - 1) / S6_BK * S6_BK);
+    return (size_t)s6_np(N) * ((K + S6_KPAD - 1) / S6_KPAD * S6_KPAD);
 }
 
 void launch_split_weights(const float* W, unsigned short* out, int N, int K, hipStream_t s) {
-    const int Np = s6_np(N), Kp = (K + S6_BK - 1) / S6_BK * S6_BK;
+    const int Np = s6_np(N), Kp = (K + S6_KPAD - 1) / S6_KPAD * S6_KPAD;
     const size_t plane = (size_t)Np * Kp;
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, W,
                        reinterpret_cast<__bf16*>(out), N, K, Np, Kp);
@@ -133,7 +134,8 @@ __device__ __forceinline__ void s6_epilogue(const v4f (&acc)[MT][NT], const int 
     }
 }
 
-template <int NT, bool CONV, int MT, bool GATE>
+// KS = K-steps (MFMA K = 32 each) per LDS stage and barrier: 1, or 2 for half as many handoffs per K
+template <int NT, bool CONV, int MT, bool GATE, int KS>
 __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X,
                                                      const unsigned short* __restrict__ W3, int plane, int Kp,
                                                      const float* __restrict__ bias,
@@ -144,9 +146,9 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
                                                      ConvGeom cg, int res_first, unsigned xbytes, unsigned gbytes) {
     constexpr int BK = S6_BK;
     constexpr int BN = NT * 16, BM = 4 * MT * 16;
-    constexpr int CHUNKS = BN * 12;                       // 16-byte chunks per stage: row x plane x k-octet
+    constexpr int CHUNKS = BN * 12 * KS;                  // 16-byte chunks per stage: row x plane x k-octet
     constexpr int WLOADS = (CHUNKS + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char ws[2][BN * S6_ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char ws[2][KS][BN * S6_ROWB];
 
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int mblk = (idx / nblocks) * 8 + xcd, nblk = idx % nblocks;
@@ -192,28 +194,33 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W3), 0, 6 * plane, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GATE ? gate : X), 0, GATE ? gbytes : xbytes, 0x00020000);
+    // With KS = 2 a row's 4 * KS consecutive octets of one plane are 128 contiguous bytes = one cache line per 8
+    // lanes: the 64-byte pieces of a single K-step use half of every line they pull through the L1, and at small
+    // tiles the L1 (64 B/clk per CU, 3 * BN + 2 * BM line-cycles per K-step against 0.094 * BM * BN MFMA cycles)
+    // is what a K-step waits for.
     int wvo[WLOADS], wlds[WLOADS];
 #pragma unroll
     for (int t = 0; t < WLOADS; ++t) {
         const int e = tid + t * 256 < CHUNKS ? tid + t * 256 : CHUNKS - 1;
-        const int row = e / 12, rem = e - row * 12, pl = rem >> 2, c = rem & 3;
+        const int row = e / (12 * KS), rem = e - row * (12 * KS), pl = rem / (4 * KS), c = rem - pl * (4 * KS);
         wvo[t] = 2 * (pl * plane + (n0 + row) * Kp + 8 * c);
-        wlds[t] = row * S6_ROWB + s6_chunk_pos(row, pl * 4 + c) * 16;
+        wlds[t] = (c >> 2) * (BN * S6_ROWB) + row * S6_ROWB + s6_chunk_pos(row, pl * 4 + (c & 3)) * 16;
     }
 
     // Register rings: the activation stream comes from HBM / Infinity Cache (1-2 us under load, several
     // K-steps of MFMA work at these tile sizes) and is prefetched XD steps ahead; weights and gates are L2
     // hits and stay one step ahead.  The K loop is unrolled by the ring size U = XD + 1, so every ring slot is
     // a fixed register set and nothing is ever copied into place.
-    constexpr int XD = MT == 1 ? S6_XD : 1, U = XD + 1;      // the deep rings of MT = 2 do not fit 256 VGPRs
+    // (ring slots hold a whole stage; the deep rings of MT = 2 or KS = 2 do not fit 256 VGPRs)
+    constexpr int XD = MT == 1 && KS == 1 ? S6_XD : 1, U = XD + 1;
     static_assert(U % 2 == 0, "the LDS / gate ping-pong needs an even unroll");
-    constexpr int WD = MT == 1 ? S6_WD : 1;
+    constexpr int WD = MT == 1 && KS == 1 ? S6_WD : 1;
     static_assert(WD >= 1 && WD <= XD, "weight prefetch distance");
-    u4 wr[U][WLOADS];      // weights in flight: slot = K-step % U (WD slots live at a time)
-    v4f xr[U][MT][2];
-    v4f gr[2][MT][2];      // GATE: raw squeeze-excite gate fragments, multiplied in at use
-    bool okr[U][MT];       // CONV: tap inside the image (zero padding applied at use)
-    const int nk = (K + BK - 1) / BK;
+    u4 wr[U][WLOADS];      // weights in flight (a whole stage): slot = stage % U (WD slots live at a time)
+    v4f xr[U][KS][MT][2];
+    v4f gr[2][KS][MT][2];  // GATE: raw squeeze-excite gate fragments, multiplied in at use
+    bool okr[U][KS][MT];   // CONV: tap inside the image (zero padding applied at use)
+    const int nk = (K + BK - 1) / BK, nst = (nk + KS - 1) / KS;      // K-steps, stages
     // X / gate rows are not padded: in the last K-step of a K that is not a multiple of 32, lanes past the row
     // end re-read its last 8 values instead (they meet zero weights)
     int xvo[MT], xvo_last[MT], gvo[MT], gvo_last[MT];
@@ -229,9 +236,9 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
     auto ld = [&](const __amdgpu_buffer_rsrc_t& r, int vo, int so) {
         return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
     };
-    auto load_w = [&](int kstep, u4 (&w)[WLOADS]) {
+    auto load_w = [&](int st, u4 (&w)[WLOADS]) {
 #pragma unroll
-        for (int t = 0; t < WLOADS; ++t) w[t] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[t], 2 * kstep * BK, 0);
+        for (int t = 0; t < WLOADS; ++t) w[t] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[t], 2 * st * KS * BK, 0);
     };
     auto load_g = [&](int kstep, v4f (&g)[MT][2]) {
         if constexpr (GATE) {
@@ -269,13 +276,13 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
             }
         }
     };
-    auto store_w = [&](const u4 (&w)[WLOADS], int buf) {
+    auto store_w = [&](const u4 (&w)[WLOADS], unsigned char* dst) {
 #pragma unroll
-        for (int t = 0; t < WLOADS; ++t) *reinterpret_cast<u4*>(&ws[buf][wlds[t]]) = w[t];
+        for (int t = 0; t < WLOADS; ++t) *reinterpret_cast<u4*>(dst + wlds[t]) = w[t];
     };
 
     const int rd0 = s6_chunk_pos(j, q) * 16, rd1 = s6_chunk_pos(j, 4 + q) * 16, rd2 = s6_chunk_pos(j, 8 + q) * 16;
-    auto compute = [&](const v4f (&x)[MT][2], const v4f (&g)[MT][2], const bool (&okf)[MT], int buf) {
+    auto compute = [&](const v4f (&x)[MT][2], const v4f (&g)[MT][2], const bool (&okf)[MT], const unsigned char* wb) {
         bf8 xs[MT][3];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -286,13 +293,22 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
             }
             split8(lo, hi, xs[mt][0], xs[mt][1], xs[mt][2]);
         }
-        const unsigned char* wb = ws[buf];
+        // The fragments of tile nt + 1 are requested before the MFMAs of tile nt are issued (two register sets,
+        // order pinned): reading them right before use, as hipcc schedules it on its own, leaves the LDS latency
+        // (~150 cycles) exposed NT times per K-step - as long as the MFMAs themselves at one wave per SIMD.
+        bf8 wf[2][3];
+        auto read_w = [&](int nt, bf8 (&f)[3]) {
+            const unsigned char* wp = wb + (nt * 16 + j) * S6_ROWB;       // (nt * 16 + j) >> 2 has the parity of j >> 2
+            f[0] = *reinterpret_cast<const bf8*>(wp + rd0);
+            f[1] = *reinterpret_cast<const bf8*>(wp + rd1);
+            f[2] = *reinterpret_cast<const bf8*>(wp + rd2);
+        };
+        read_w(0, wf[0]);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const unsigned char* wp = wb + (nt * 16 + j) * S6_ROWB;       // (nt * 16 + j) >> 2 has the parity of j >> 2
-            const bf8 w0 = *reinterpret_cast<const bf8*>(wp + rd0);
-            const bf8 w1 = *reinterpret_cast<const bf8*>(wp + rd1);
-            const bf8 w2 = *reinterpret_cast<const bf8*>(wp + rd2);
+            if (nt + 1 < NT) read_w(nt + 1, wf[(nt + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf8 w0 = wf[nt & 1][0], w1 = wf[nt & 1][1], w2 = wf[nt & 1][2];
             // smallest terms first; the MT accumulators alternate
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, xs[mt][0], acc[mt][nt], 0, 0, 0);
@@ -306,50 +322,64 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xs[mt][1], acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xs[mt][0], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // One pipelined step, ring slot u = kstep % U: issue the loads (gate of step + 1, weights of step + WD,
-    // activations of step + XD, clamped to the last step: the repeats are never consumed), compute the step,
-    // then hand the weights of step + 1 to the other LDS buffer.  Every operand needs more than one step to
-    // arrive (an L2 hit is ~1 us under this load, a step of MFMAs 0.3-0.6 us), hence the rings.
-    // The sched_barriers keep the loads at the top (a whole step to land) and their first consumers at the
-    // bottom; left alone, hipcc sinks the loads to the end of the step and waits for them at once.
-    auto step = [&](auto uc, int kstep) {
+    // One pipelined stage (KS K-steps), ring slot u = stage % U: issue the loads (gate of stage + 1, weights of
+    // stage + WD, activations of stage + XD, clamped to the last stage: the repeats are never consumed), compute
+    // the stage, then hand the weights of stage + 1 to the other LDS buffer.  Every operand needs more than one
+    // K-step to arrive (an L2 hit is ~1 us under this load, a K-step of MFMAs 0.3-0.6 us), hence the rings.
+    // A half-stage past the last K-step (odd step count, KS = 2) reads the zero padding of the weight planes
+    // (K padded to 64) against re-read activations.  The sched_barriers keep the loads at the top (a whole stage
+    // to land) and their first consumers at the bottom; left alone, hipcc sinks the loads to the end of the
+    // stage and waits for them at once.
+    auto stage = [&](auto uc, int st) {
         constexpr int u = decltype(uc)::value;
-        const int k1 = kstep + 1 < nk ? kstep + 1 : nk - 1, kw = kstep + WD < nk ? kstep + WD : nk - 1,
-                  kd = kstep + XD < nk ? kstep + XD : nk - 1;
-        load_g(k1, gr[(u + 1) & 1]);
-        load_w(kw, wr[(u + WD) % U]);
-        load_x(kd, xr[(u + XD) % U], okr[(u + XD) % U]);
+        const int s1 = st + 1 < nst ? st + 1 : nst - 1, sw = st + WD < nst ? st + WD : nst - 1,
+                  sd = st + XD < nst ? st + XD : nst - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kg = s1 * KS + ks, kx = sd * KS + ks;
+            load_g(kg < nk ? kg : nk - 1, gr[(u + 1) & 1][ks]);
+            if (ks == 0) load_w(sw, wr[(u + WD) % U]);
+            load_x(kx < nk ? kx : nk - 1, xr[(u + XD) % U][ks], okr[(u + XD) % U][ks]);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        compute(xr[u], gr[u & 1], okr[u], u & 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) compute(xr[u][ks], gr[u & 1][ks], okr[u][ks], ws[u & 1][ks]);
         __builtin_amdgcn_sched_barrier(0);
-        store_w(wr[(u + 1) % U], (u + 1) & 1);
+        store_w(wr[(u + 1) % U], ws[(u + 1) & 1][0]);
         __syncthreads();
     };
 
     load_w(0, wr[0]);
-    load_g(0, gr[0]);
 #pragma unroll
-    for (int d = 1; d < WD; ++d) load_w(d < nk ? d : nk - 1, wr[d]);
+    for (int ks = 0; ks < KS; ++ks) load_g(ks < nk ? ks : nk - 1, gr[0][ks]);
 #pragma unroll
-    for (int d = 0; d < XD; ++d) load_x(d < nk ? d : nk - 1, xr[d], okr[d]);
-    store_w(wr[0], 0);
+    for (int d = 1; d < WD; ++d) load_w(d < nst ? d : nst - 1, wr[d]);
+#pragma unroll
+    for (int d = 0; d < XD; ++d)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kx = (d < nst ? d : nst - 1) * KS + ks;
+            load_x(kx < nk ? kx : nk - 1, xr[d][ks], okr[d][ks]);
+        }
+    store_w(wr[0], ws[0][0]);
     __syncthreads();
     int kt = 0;
-    for (; kt + U <= nk; kt += U) {
-        step(std::integral_constant<int, 0>{}, kt);
-        step(std::integral_constant<int, 1>{}, kt + 1);
+    for (; kt + U <= nst; kt += U) {
+        stage(std::integral_constant<int, 0>{}, kt);
+        stage(std::integral_constant<int, 1>{}, kt + 1);
         if constexpr (U == 4) {
-            step(std::integral_constant<int, 2>{}, kt + 2);
-            step(std::integral_constant<int, 3>{}, kt + 3);
+            stage(std::integral_constant<int, 2>{}, kt + 2);
+            stage(std::integral_constant<int, 3>{}, kt + 3);
         }
     }
-    // remainder (kt is a multiple of U here, so slot u = step - kt)
-    if (kt < nk) step(std::integral_constant<int, 0>{}, kt);
+    // remainder (kt is a multiple of U here, so slot u = stage - kt)
+    if (kt < nst) stage(std::integral_constant<int, 0>{}, kt);
     if constexpr (U == 4) {
-        if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
-        if (kt + 2 < nk) step(std::integral_constant<int, 2>{}, kt + 2);
+        if (kt + 1 < nst) stage(std::integral_constant<int, 1>{}, kt + 1);
+        if (kt + 2 < nst) stage(std::integral_constant<int, 2>{}, kt + 2);
     }
 
     s6_epilogue<MT, NT>(acc, m, n0 + 4 * q, bias, R, Y, M, N, act, res_first);
@@ -513,12 +543,19 @@ __global__ __launch_bounds__(256, 2) void pw7_kernel(const float* __restrict__ X
             xs[mt][1] = *reinterpret_cast<const bf8*>(xp + rd1);
             xs[mt][2] = *reinterpret_cast<const bf8*>(xp + rd2);
         }
+        bf8 wf[2][3];                         // next tile's weight fragments in flight during this tile's MFMAs (see pw6)
+        auto read_w = [&](int nt, bf8 (&f)[3]) {
+            const unsigned char* wp = ws[buf] + ((wn * NT + nt) * 16 + j) * S6_ROWB;
+            f[0] = *reinterpret_cast<const bf8*>(wp + rd0);
+            f[1] = *reinterpret_cast<const bf8*>(wp + rd1);
+            f[2] = *reinterpret_cast<const bf8*>(wp + rd2);
+        };
+        read_w(0, wf[0]);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const unsigned char* wp = ws[buf] + ((wn * NT + nt) * 16 + j) * S6_ROWB;
-            const bf8 w0 = *reinterpret_cast<const bf8*>(wp + rd0);
-            const bf8 w1 = *reinterpret_cast<const bf8*>(wp + rd1);
-            const bf8 w2 = *reinterpret_cast<const bf8*>(wp + rd2);
+            if (nt + 1 < NT) read_w(nt + 1, wf[(nt + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf8 w0 = wf[nt & 1][0], w1 = wf[nt & 1][1], w2 = wf[nt & 1][2];
             // the same six products in the same order as pw6: a result never depends on the kernel or tile chosen
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, xs[mt][0], acc[mt][nt], 0, 0, 0);
@@ -532,6 +569,7 @@ __global__ __launch_bounds__(256, 2) void pw7_kernel(const float* __restrict__ X
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xs[mt][1], acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xs[mt][0], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // step kstep, ring slot u = kstep & 1: loads for step + 2 (into the slots whose contents went to LDS at the
@@ -571,12 +609,12 @@ __global__ __launch_bounds__(256, 2) void pw7_kernel(const float* __restrict__ X
 }
 
 // kind 0: pw6 (block = 4 waves x MT*16 rows, NT*16 columns); kind 1: pw7 (WM x WN waves of MT x NT tiles)
-struct S6Tile { int kind, wm, wn, mt, nt, mblocks, nblocks; };
-static S6Tile make_tile(int M, int N, int kind, int wm, int wn, int mt, int nt) {
+struct S6Tile { int kind, wm, wn, mt, nt, ks, mblocks, nblocks; };      // ks: K-steps per stage (pw6)
+static S6Tile make_tile(int M, int N, int kind, int wm, int wn, int mt, int nt, int ks = 1) {
     const int bm = wm * mt * 16, bn = wn * nt * 16;
-    return S6Tile{kind, wm, wn, mt, nt, (M + bm - 1) / bm, (N + bn - 1) / bn};
+    return S6Tile{kind, wm, wn, mt, nt, ks, (M + bm - 1) / bm, (N + bn - 1) / bn};
 }
-static S6Tile make_tile6(int M, int N, int mt, int nt) { return make_tile(M, N, 0, 4, 1, mt, nt); }
+static S6Tile make_tile6(int M, int N, int mt, int nt, int ks = 1) { return make_tile(M, N, 0, 4, 1, mt, nt, ks); }
 
 // Heuristic tile (used when measuring is switched off): the biggest per-wave pw6 tile that still fills the chip.
 static S6Tile pick_tile6(int M, int N) {
@@ -607,7 +645,7 @@ static void s6_dispatch(const S6Tile& t, const float* X, const unsigned short* W
                         const float* gate, const float* R, float* Y, int M, int K, int N, int HW, int act,
                         const ConvGeom& g, int res_first, hipStream_t s) {
     const int grid = ((t.mblocks + 7) / 8) * 8 * t.nblocks;
-    const int Kp = (K + S6_BK - 1) / S6_BK * S6_BK, plane = s6_np(N) * Kp;
+    const int Kp = (K + S6_KPAD - 1) / S6_KPAD * S6_KPAD, plane = s6_np(N) * Kp;
     const unsigned xbytes = CONV ? (unsigned)((size_t)(M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin * 4) : (unsigned)((size_t)M * K * 4);
     const unsigned gbytes = GATE ? (unsigned)((size_t)(M / HW) * K * 4) : 0u;
     if (t.kind == 1) {
@@ -621,16 +659,18 @@ static void s6_dispatch(const S6Tile& t, const float* X, const unsigned short* W
 #undef DFD_S7_CASE
         return;
     }
-#define DFD_S6_CASE(NTV)                                                                                          \
-    case NTV:                                                                                                     \
-        if (t.mt == 2)                                                                                            \
-            hipLaunchKernelGGL((pw6_kernel<NTV, CONV, 2, GATE>), dim3(grid), dim3(256), 0, s, X, W3, plane, Kp, bias, \
-                               gate, R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes); \
-        else                                                                                                      \
-            hipLaunchKernelGGL((pw6_kernel<NTV, CONV, 1, GATE>), dim3(grid), dim3(256), 0, s, X, W3, plane, Kp, bias, \
-                               gate, R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes); \
+#define DFD_S6_LAUNCH(NTV, MTV, KSV)                                                                                 \
+    hipLaunchKernelGGL((pw6_kernel<NTV, CONV, MTV, GATE, KSV>), dim3(grid), dim3(256), 0, s, X, W3, plane, Kp, bias, gate, \
+                       R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes)
+#define DFD_S6_CASE(NTV)                                        \
+    case NTV:                                                   \
+        if (t.mt == 2 && t.ks == 2) DFD_S6_LAUNCH(NTV, 2, 2);   \
+        else if (t.mt == 2) DFD_S6_LAUNCH(NTV, 2, 1);           \
+        else if (t.ks == 2) DFD_S6_LAUNCH(NTV, 1, 2);           \
+        else DFD_S6_LAUNCH(NTV, 1, 1);                          \
         break;
     switch (t.nt) { DFD_S6_NT_CASES(DFD_S6_CASE) }
+#undef DFD_S6_LAUNCH
 #undef DFD_S6_CASE
 }
 
@@ -673,8 +713,9 @@ static void s6_run(const float* X, const unsigned short* W3, const float* bias, 
         if (tune && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
             const int tiles = (N + 15) / 16;
             std::vector<S6Tile> cands;
-            for (int mt = 1; mt <= 2; ++mt)
-                for (int nt = 1; nt <= 8 && nt <= tiles; ++nt) cands.push_back(make_tile6(M, N, mt, nt));
+            for (int ks = 1; ks <= (K > 32 ? 2 : 1); ++ks)
+                for (int mt = 1; mt <= 2; ++mt)
+                    for (int nt = 1; nt <= 8 && nt <= tiles; ++nt) cands.push_back(make_tile6(M, N, mt, nt, ks));
 #define DFD_S7_CAND(WMV, WNV, MTV, NTV) cands.push_back(make_tile(M, N, 1, WMV, WNV, MTV, NTV));
             DFD_S7_CONFIGS(DFD_S7_CAND)
 #undef DFD_S7_CAND
@@ -697,19 +738,19 @@ static void s6_run(const float* X, const unsigned short* W3, const float* bias, 
                 }
                 if (!ok) continue;
                 if (getenv("DFD_S6_VERBOSE") && atoi(getenv("DFD_S6_VERBOSE")) > 1)
-                    fprintf(stderr, "[dfd]   kind %d %dx%d mt=%d nt=%d: %.1f us\n", t.kind, t.wm, t.wn, t.mt, t.nt, ms * 1000.f / 3.f);
+                    fprintf(stderr, "[dfd]   kind %d %dx%d mt=%d nt=%d ks=%d: %.1f us\n", t.kind, t.wm, t.wn, t.mt, t.nt, t.ks, ms * 1000.f / 3.f);
                 if (ms < best_ms) { best_ms = ms; tile = t; }
             }
             hipEventDestroy(e0);
             hipEventDestroy(e1);
             if (getenv("DFD_S6_VERBOSE"))
-                fprintf(stderr, "[dfd] split gemm M=%d K=%d N=%d mode=%d -> kind %d %dx%d mt=%d nt=%d (%.1f us)\n", M, K, N,
-                        key.mode, tile.kind, tile.wm, tile.wn, tile.mt, tile.nt, best_ms * 1000.f / 3.f);
+                fprintf(stderr, "[dfd] split gemm M=%d K=%d N=%d mode=%d -> kind %d %dx%d mt=%d nt=%d ks=%d (%.1f us)\n", M, K, N,
+                        key.mode, tile.kind, tile.wm, tile.wn, tile.mt, tile.nt, tile.ks, best_ms * 1000.f / 3.f);
         }
         std::lock_guard<std::mutex> lk(g_tiles_mu);
         g_tiles[key] = tile;
     }
-    tile = make_tile(M, N, tile.kind, tile.wm, tile.wn, tile.mt, tile.nt);      // block counts for this call's M
+    tile = make_tile(M, N, tile.kind, tile.wm, tile.wn, tile.mt, tile.nt, tile.ks);      // block counts for this call's M
     s6_dispatch<CONV, GATE>(tile, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
 }
 
