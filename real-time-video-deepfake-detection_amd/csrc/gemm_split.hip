@@ -29,6 +29,27 @@
 
 namespace dfd {
 
+#ifdef S6_TRACE
+// cycle trace of one wave (build with EXTRA=-DS6_TRACE; profiles/micro/s6_trace.py reads it): s_memtime at fixed
+// points of the first stages of block S6_TRACE_BLOCK of the launch with K == S6_TRACE_K and N == S6_TRACE_N
+#ifndef S6_TRACE_K
+#define S6_TRACE_K 1152
+#endif
+#ifndef S6_TRACE_N
+#define S6_TRACE_N 192
+#endif
+__device__ long long g_s6_trace[1024];
+#define S6_TP(id)                                                                                          \
+    do {                                                                                                   \
+        if (K == S6_TRACE_K && N == S6_TRACE_N && blockIdx.x == 8 && threadIdx.x == 0 && tp < 1000) {      \
+            g_s6_trace[tp++] = (long long)(id);                                                            \
+            g_s6_trace[tp++] = (long long)__builtin_amdgcn_s_memtime();                                    \
+        }                                                                                                  \
+    } while (0)
+#else
+#define S6_TP(id) do { } while (0)
+#endif
+
 typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));      // (HIP's uint4 struct does not always leave the stack)
 
@@ -135,8 +156,17 @@ __device__ __forceinline__ void s6_epilogue(const v4f (&acc)[MT][NT], const int 
 }
 
 // KS = K-steps (MFMA K = 32 each) per LDS stage and barrier: 1, or 2 for half as many handoffs per K
-template <int NT, bool CONV, int MT, bool GATE, int KS>
-__global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X,
+// PIPE (KS = 1 only): the split of the NEXT K-step's activations is issued between the MFMAs of the current one
+// (sched_group_barrier pattern 1 MFMA : 2 VALU) instead of in front of them.  The s_memtime trace of the plain
+// pipeline (profiles/micro/s6_trace.py) shows a wave spending load issue + split VALU + MFMAs back to back
+// (400 + 500 + 1150 cycles per two K-steps at MT = 1, NT = 6): with 1.5 waves per SIMD nothing else fills the
+// MFMA pipe while a wave converts.
+// NW = waves per block (4 or 8): the block's weight tile is pulled through L2 -> L1 -> LDS once per block and
+// K-step, so rows per block (NW * MT * 16) set the L2 read traffic for the weights, (M / rows) * N * K * 6 bytes -
+// 260 MB for M = 12544, N = 192, K = 1152 at 64 rows, against 58 MB of activations: every inner-loop variant of
+// that layer lands on the same 45-55 us, which is that traffic.  Eight waves share the tile among twice the rows.
+template <int NT, bool CONV, int MT, bool GATE, int KS, bool PIPE = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void pw6_kernel(const float* __restrict__ X,
                                                      const unsigned short* __restrict__ W3, int plane, int Kp,
                                                      const float* __restrict__ bias,
                                                      const float* __restrict__ gate,
@@ -145,9 +175,9 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
                                                      int HW, int act, int mblocks, int nblocks,
                                                      ConvGeom cg, int res_first, unsigned xbytes, unsigned gbytes) {
     constexpr int BK = S6_BK;
-    constexpr int BN = NT * 16, BM = 4 * MT * 16;
+    constexpr int BN = NT * 16, BM = NW * MT * 16, NTHR = NW * 64;
     constexpr int CHUNKS = BN * 12 * KS;                  // 16-byte chunks per stage: row x plane x k-octet
-    constexpr int WLOADS = (CHUNKS + 255) / 256;
+    constexpr int WLOADS = (CHUNKS + NTHR - 1) / NTHR;
     __shared__ __attribute__((aligned(16))) unsigned char ws[2][KS][BN * S6_ROWB];
 
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -157,6 +187,9 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 15, q = lane >> 4;
     const int n0 = nblk * BN;
+#ifdef S6_TRACE
+    int tp = 0;
+#endif
 
     int m[MT];
     size_t gbase[MT];
@@ -201,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
     int wvo[WLOADS], wlds[WLOADS];
 #pragma unroll
     for (int t = 0; t < WLOADS; ++t) {
-        const int e = tid + t * 256 < CHUNKS ? tid + t * 256 : CHUNKS - 1;
+        const int e = tid + t * NTHR < CHUNKS ? tid + t * NTHR : CHUNKS - 1;
         const int row = e / (12 * KS), rem = e - row * (12 * KS), pl = rem / (4 * KS), c = rem - pl * (4 * KS);
         wvo[t] = 2 * (pl * plane + (n0 + row) * Kp + 8 * c);
         wlds[t] = (c >> 2) * (BN * S6_ROWB) + row * S6_ROWB + s6_chunk_pos(row, pl * 4 + (c & 3)) * 16;
@@ -212,9 +245,9 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
     // hits and stay one step ahead.  The K loop is unrolled by the ring size U = XD + 1, so every ring slot is
     // a fixed register set and nothing is ever copied into place.
     // (ring slots hold a whole stage; the deep rings of MT = 2 or KS = 2 do not fit 256 VGPRs)
-    constexpr int XD = MT == 1 && KS == 1 ? S6_XD : 1, U = XD + 1;
+    constexpr int XD = MT == 1 && KS == 1 && !PIPE ? S6_XD : 1, U = XD + 1;
     static_assert(U % 2 == 0, "the LDS / gate ping-pong needs an even unroll");
-    constexpr int WD = MT == 1 && KS == 1 ? S6_WD : 1;
+    constexpr int WD = MT == 1 && KS == 1 && !PIPE ? S6_WD : 1;
     static_assert(WD >= 1 && WD <= XD, "weight prefetch distance");
     u4 wr[U][WLOADS];      // weights in flight (a whole stage): slot = stage % U (WD slots live at a time)
     v4f xr[U][KS][MT][2];
@@ -282,8 +315,7 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
     };
 
     const int rd0 = s6_chunk_pos(j, q) * 16, rd1 = s6_chunk_pos(j, 4 + q) * 16, rd2 = s6_chunk_pos(j, 8 + q) * 16;
-    auto compute = [&](const v4f (&x)[MT][2], const v4f (&g)[MT][2], const bool (&okf)[MT], const unsigned char* wb) {
-        bf8 xs[MT][3];
+    auto split_x = [&](const v4f (&x)[MT][2], const v4f (&g)[MT][2], const bool (&okf)[MT], bf8 (&xs)[MT][3]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             v4f lo = x[mt][0], hi = x[mt][1];
@@ -293,6 +325,25 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
             }
             split8(lo, hi, xs[mt][0], xs[mt][1], xs[mt][2]);
         }
+    };
+    auto mfma_tile = [&](const bf8 (&xs)[MT][3], const bf8 (&f)[3], int nt, bool interleave) {
+        const bf8 w0 = f[0], w1 = f[1], w2 = f[2];
+        const bf8* wsel[6] = {&w2, &w1, &w0, &w1, &w0, &w0};      // smallest terms first
+        const int xsel[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int p6 = 0; p6 < 6; ++p6)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*wsel[p6], xs[mt][xsel[p6]], acc[mt][nt], 0, 0, 0);
+                if (interleave) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA ...
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // ... then two VALU in its shadow
+                }
+            }
+    };
+    auto compute = [&](const v4f (&x)[MT][2], const v4f (&g)[MT][2], const bool (&okf)[MT], const unsigned char* wb) {
+        bf8 xs[MT][3];
+        split_x(x, g, okf, xs);
         // The fragments of tile nt + 1 are requested before the MFMAs of tile nt are issued (two register sets,
         // order pinned): reading them right before use, as hipcc schedules it on its own, leaves the LDS latency
         // (~150 cycles) exposed NT times per K-step - as long as the MFMAs themselves at one wave per SIMD.
@@ -308,20 +359,7 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
         for (int nt = 0; nt < NT; ++nt) {
             if (nt + 1 < NT) read_w(nt + 1, wf[(nt + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            const bf8 w0 = wf[nt & 1][0], w1 = wf[nt & 1][1], w2 = wf[nt & 1][2];
-            // smallest terms first; the MT accumulators alternate
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, xs[mt][0], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xs[mt][1], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xs[mt][2], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xs[mt][0], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xs[mt][1], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xs[mt][0], acc[mt][nt], 0, 0, 0);
+            mfma_tile(xs, wf[nt & 1], nt, false);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -335,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
     // stage and waits for them at once.
     auto stage = [&](auto uc, int st) {
         constexpr int u = decltype(uc)::value;
+        S6_TP(1);
         const int s1 = st + 1 < nst ? st + 1 : nst - 1, sw = st + WD < nst ? st + WD : nst - 1,
                   sd = st + XD < nst ? st + XD : nst - 1;
 #pragma unroll
@@ -345,13 +384,75 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
             load_x(kx < nk ? kx : nk - 1, xr[(u + XD) % U][ks], okr[(u + XD) % U][ks]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        S6_TP(2);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) compute(xr[u][ks], gr[u & 1][ks], okr[u][ks], ws[u & 1][ks]);
         __builtin_amdgcn_sched_barrier(0);
+        S6_TP(3);
         store_w(wr[(u + 1) % U], ws[(u + 1) & 1][0]);
+        S6_TP(4);
         __syncthreads();
+        S6_TP(5);
     };
 
+    if constexpr (PIPE) {
+        static_assert(!PIPE || KS == 1, "PIPE is built for one K-step per stage");
+        // slot u = step & 1.  At step s: raw X / gate of step s + 2 and the weights of step s + 2 are requested into
+        // slot u (its previous contents, step s, were split / stored during step s - 1); X(s + 1) in slot u ^ 1 is
+        // split into xs[u ^ 1] between the MFMAs of step s, which read xs[u] and LDS buffer u; the weights of
+        // step s + 1 go to LDS buffer u ^ 1 at the bottom.
+        bf8 xs[2][MT][3];
+        auto pstep = [&](auto uc, int st) {
+            constexpr int u = decltype(uc)::value;
+            const int s2 = st + 2 < nk ? st + 2 : nk - 1;
+            load_w(s2, wr[u]);
+            load_g(s2, gr[u][0]);
+            load_x(s2, xr[u][0], okr[u][0]);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* wb = ws[u][0];
+            bf8 wf[2][3];
+            auto read_w = [&](int nt, bf8 (&f)[3]) {
+                const unsigned char* wp = wb + (nt * 16 + j) * S6_ROWB;
+                f[0] = *reinterpret_cast<const bf8*>(wp + rd0);
+                f[1] = *reinterpret_cast<const bf8*>(wp + rd1);
+                f[2] = *reinterpret_cast<const bf8*>(wp + rd2);
+            };
+            read_w(0, wf[0]);
+            split_x(xr[u ^ 1][0], gr[u ^ 1][0], okr[u ^ 1][0], xs[u ^ 1]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);              // first fragments
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);              // conversions while they arrive
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt + 1 < NT) {
+                    read_w(nt + 1, wf[(nt + 1) & 1]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                }
+                mfma_tile(xs[u], wf[nt & 1], nt, true);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            store_w(wr[u ^ 1], ws[u ^ 1][0]);
+            __syncthreads();
+        };
+        load_w(0, wr[0]);
+        load_g(0, gr[0][0]);
+        load_x(0, xr[0][0], okr[0][0]);
+        const int one = nk > 1 ? 1 : 0;
+        load_w(one, wr[1]);
+        load_g(one, gr[1][0]);
+        load_x(one, xr[1][0], okr[1][0]);
+        store_w(wr[0], ws[0][0]);
+        split_x(xr[0][0], gr[0][0], okr[0][0], xs[0]);
+        __syncthreads();
+        int ps = 0;
+        for (; ps + 2 <= nk; ps += 2) {
+            pstep(std::integral_constant<int, 0>{}, ps);
+            pstep(std::integral_constant<int, 1>{}, ps + 1);
+        }
+        if (ps < nk) pstep(std::integral_constant<int, 0>{}, ps);
+        s6_epilogue<MT, NT>(acc, m, n0 + 4 * q, bias, R, Y, M, N, act, res_first);
+        return;
+    }
+    S6_TP(0);
     load_w(0, wr[0]);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) load_g(ks < nk ? ks : nk - 1, gr[0][ks]);
@@ -382,7 +483,12 @@ __global__ __launch_bounds__(256, 2) void pw6_kernel(const float* __restrict__ X
         if (kt + 2 < nst) stage(std::integral_constant<int, 2>{}, kt + 2);
     }
 
+    S6_TP(8);
     s6_epilogue<MT, NT>(acc, m, n0 + 4 * q, bias, R, Y, M, N, act, res_first);
+    S6_TP(9);
+#ifdef S6_TRACE
+    if (K == S6_TRACE_K && N == S6_TRACE_N && blockIdx.x == 8 && threadIdx.x == 0) g_s6_trace[1023] = tp;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -609,7 +715,7 @@ __global__ __launch_bounds__(256, 2) void pw7_kernel(const float* __restrict__ X
 }
 
 // kind 0: pw6 (block = 4 waves x MT*16 rows, NT*16 columns); kind 1: pw7 (WM x WN waves of MT x NT tiles)
-struct S6Tile { int kind, wm, wn, mt, nt, ks, mblocks, nblocks; };      // ks: K-steps per stage (pw6)
+struct S6Tile { int kind, wm, wn, mt, nt, ks, mblocks, nblocks; };      // ks: K-steps per stage (pw6); 3 = PIPE variant
 static S6Tile make_tile(int M, int N, int kind, int wm, int wn, int mt, int nt, int ks = 1) {
     const int bm = wm * mt * 16, bn = wn * nt * 16;
     return S6Tile{kind, wm, wn, mt, nt, ks, (M + bm - 1) / bm, (N + bn - 1) / bn};
@@ -662,15 +768,33 @@ static void s6_dispatch(const S6Tile& t, const float* X, const unsigned short* W
 #define DFD_S6_LAUNCH(NTV, MTV, KSV)                                                                                 \
     hipLaunchKernelGGL((pw6_kernel<NTV, CONV, MTV, GATE, KSV>), dim3(grid), dim3(256), 0, s, X, W3, plane, Kp, bias, gate, \
                        R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes)
+#define DFD_S6_LAUNCHP(NTV, MTV)                                                                                     \
+    hipLaunchKernelGGL((pw6_kernel<NTV, CONV, MTV, GATE, 1, true>), dim3(grid), dim3(256), 0, s, X, W3, plane, Kp, bias, gate, \
+                       R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes)
+#ifdef DFD_S6_PIPE
+#define DFD_S6_PIPE_CASES(NTV)                              \
+    else if (t.ks == 3 && t.mt == 2) DFD_S6_LAUNCHP(NTV, 2); \
+    else if (t.ks == 3) DFD_S6_LAUNCHP(NTV, 1);
+#else
+#define DFD_S6_PIPE_CASES(NTV)
+#endif
+#define DFD_S6_LAUNCH8(NTV, KSV)                                                                                     \
+    hipLaunchKernelGGL((pw6_kernel<NTV, CONV, 1, GATE, KSV, false, 8>), dim3(grid), dim3(512), 0, s, X, W3, plane, Kp, bias, \
+                       gate, R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes)
 #define DFD_S6_CASE(NTV)                                        \
     case NTV:                                                   \
-        if (t.mt == 2 && t.ks == 2) DFD_S6_LAUNCH(NTV, 2, 2);   \
+        if (t.wm == 8 && t.ks == 2) DFD_S6_LAUNCH8(NTV, 2);     \
+        else if (t.wm == 8) DFD_S6_LAUNCH8(NTV, 1);             \
+        DFD_S6_PIPE_CASES(NTV)                                  \
+        else if (t.mt == 2 && t.ks == 2) DFD_S6_LAUNCH(NTV, 2, 2);   \
         else if (t.mt == 2) DFD_S6_LAUNCH(NTV, 2, 1);           \
         else if (t.ks == 2) DFD_S6_LAUNCH(NTV, 1, 2);           \
         else DFD_S6_LAUNCH(NTV, 1, 1);                          \
         break;
     switch (t.nt) { DFD_S6_NT_CASES(DFD_S6_CASE) }
 #undef DFD_S6_LAUNCH
+#undef DFD_S6_LAUNCHP
+#undef DFD_S6_LAUNCH8
 #undef DFD_S6_CASE
 }
 
@@ -713,9 +837,13 @@ static void s6_run(const float* X, const unsigned short* W3, const float* bias, 
         if (tune && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
             const int tiles = (N + 15) / 16;
             std::vector<S6Tile> cands;
+            // (ks = 3, the PIPE variant, is not offered: measured within 1 % of ks = 1 on every B0 shape, so its 48
+            // instances are not built either - DFD_S6_PIPE=1 at compile time brings them back)
             for (int ks = 1; ks <= (K > 32 ? 2 : 1); ++ks)
                 for (int mt = 1; mt <= 2; ++mt)
                     for (int nt = 1; nt <= 8 && nt <= tiles; ++nt) cands.push_back(make_tile6(M, N, mt, nt, ks));
+            for (int ks = 1; ks <= (K > 32 ? 2 : 1); ++ks)              // eight waves per block (MT = 1)
+                for (int nt = 2; nt <= 8 && nt <= tiles; ++nt) cands.push_back(make_tile(M, N, 0, 8, 1, 1, nt, ks));
 #define DFD_S7_CAND(WMV, WNV, MTV, NTV) cands.push_back(make_tile(M, N, 1, WMV, WNV, MTV, NTV));
             DFD_S7_CONFIGS(DFD_S7_CAND)
 #undef DFD_S7_CAND
@@ -771,5 +899,11 @@ bool launch_conv_gemm_split(const float* X, const unsigned short* W3, const floa
     s6_run<true, false>(X, W3, bias, nullptr, R, Y, M, K, Cout, 1, act, g, res_first ? 1 : 0, s);
     return true;
 }
+
+#ifdef S6_TRACE
+extern "C" int dfd_debug_s6_trace(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s6_trace), (size_t)n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 }  // namespace dfd
