@@ -20,6 +20,26 @@
 
 namespace dfd {
 
+#ifdef MB_TRACE
+// cycle trace of one thread of one mbconv block (build with EXTRA=-DMB_TRACE; profiles/micro/mb_trace.py)
+__device__ long long g_mb_trace[256];
+#define MB_TP(id)                                                                                             \
+    do {                                                                                                      \
+        if (H == MB_TRACE_H && blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0 && mtp < 250) {           \
+            g_mb_trace[mtp++] = (long long)(id);                                                              \
+            g_mb_trace[mtp++] = (long long)__builtin_amdgcn_s_memtime();                                      \
+        }                                                                                                     \
+    } while (0)
+#ifndef MB_TRACE_H
+#define MB_TRACE_H 56
+#endif
+extern "C" int dfd_debug_mb_trace(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mb_trace), (size_t)n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+#else
+#define MB_TP(id) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------ stem
 // One thread = one output pixel x 4 output channels; 8 consecutive lanes share a pixel, so
 // the 27 input taps are wave-broadcast loads and the 128-byte NHWC output row is one
@@ -485,6 +505,10 @@ __global__ __launch_bounds__(256) void mbconv_kernel(const float* __restrict__ X
     const int t = blockIdx.x % tiles_sp, group = blockIdx.x / tiles_sp;
     const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
     const int iy0 = ty0 * S - pad_lo, ix0 = tx0 * S - pad_lo;
+#ifdef MB_TRACE
+    int mtp = 0;
+#endif
+    MB_TP(0);
 
     // B operand for all of this wave's pixel tiles: lane (pixel j, k-quad q); loaded once
     const float* xb = X + (size_t)n * H * H * Cin;
@@ -505,7 +529,9 @@ __global__ __launch_bounds__(256) void mbconv_kernel(const float* __restrict__ X
 
     for (int sub = 0; sub < NSUB; ++sub) {
         const int c0 = (group * NSUB + sub) * CB;
+        MB_TP(1);
         if (sub > 0) __syncthreads();                            // previous chunk done with tile/wl/red
+        MB_TP(2);
         for (int i = tid; i < K * K * CG; i += 256)
             wl[i] = ldg4(Wt + (size_t)(i / CG) * C + c0 + 4 * (i % CG));
         const v4f bv = ldg4(bias + c0 + 4 * (tid % CG));
@@ -521,6 +547,7 @@ __global__ __launch_bounds__(256) void mbconv_kernel(const float* __restrict__ X
                 wf[nt][kk] = k < Cin ? v : (v4f){0.f, 0.f, 0.f, 0.f};
             }
         }
+        MB_TP(3);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int mt = wave + 4 * it;
@@ -545,9 +572,15 @@ __global__ __launch_bounds__(256) void mbconv_kernel(const float* __restrict__ X
                 }
             }
         }
+        MB_TP(4);
         __syncthreads();
+        MB_TP(5);
         dw_compute<K, S, CB, TH, TW, RP>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
+        MB_TP(6);
     }
+#ifdef MB_TRACE
+    if (H == MB_TRACE_H && blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
+#endif
 }
 
 // Stem + block-0 depthwise in ONE kernel.  Block = image x 8x16 output tile x all 32 channels.  The
