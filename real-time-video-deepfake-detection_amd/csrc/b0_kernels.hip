@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const float*
 // fragments of all its pixels are loaded ONCE, up front (one batch of loads in flight), and reused
 // for every chunk.  Price: the halo's expand FLOPs are recomputed (1.1-1.65x).
 template <int K, int S, int CB, int TH, int TW, int RP, int KC, int NSUB>
-__global__ __launch_bounds__(256) void mbconv_kernel(const float* __restrict__ X,
+__global__ __launch_bounds__(256, 3) void mbconv_kernel(const float* __restrict__ X,
                                                      const float* __restrict__ We,
                                                      const float* __restrict__ be,
                                                      const float* __restrict__ Wt,
