@@ -463,14 +463,27 @@ __global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const float*
         wl[i] = ldg4(Wt + (size_t)(i / CG) * C + c0 + 4 * (i % CG));
     const int iy0 = ty0 * S - pad_lo, ix0 = tx0 * S - pad_lo;
     const float* xb = X + (size_t)n * H * H * C + c0;
-#pragma unroll 4
-    for (int i = tid; i < IH * IW * CG; i += 256) {
+    // Halo tile -> LDS.  Every load is unconditional (address clamped into the image, VALUE masked) and all of a
+    // thread's loads are issued before the first LDS store: a load under `if (inside)` makes hipcc branch and
+    // wait per element - the s_memtime trace of the fused stem kernel showed 57 % of a block's time in ten
+    // serialized round trips of exactly this loop shape.  Threads past the last element repeat it (same value,
+    // same address), so the stores are unconditional too.
+    constexpr int NEL = IH * IW * CG, NLD = (NEL + 255) / 256;
+    v4f stg[NLD];
+    bool stg_ok[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + k * 256 < NEL ? tid + k * 256 : NEL - 1;
         const int cg = i % CG, pix = i / CG;
         const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
-        v4f v = (v4f){0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H)
-            v = ldg4(xb + ((size_t)iy * H + ix) * C + 4 * cg);
-        tile[i] = v;
+        const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
+        stg[k] = ldg4(xb + ((size_t)(inside ? iy : 0) * H + (inside ? ix : 0)) * C + 4 * cg);
+        stg_ok[k] = inside;
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + k * 256 < NEL ? tid + k * 256 : NEL - 1;
+        tile[i] = stg_ok[k] ? stg[k] : (v4f){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     dw_compute<K, S, CB, TH, TW, RP>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
@@ -609,12 +622,24 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
     // stem pixel (sy, sx) = (ty0 - 1 + py, tx0 - 1 + px) reads input rows 2*sy .. 2*sy+2 (TF-SAME: pad high only)
     const int r0 = 2 * (ty0 - 1), c0 = 2 * (tx0 - 1);
     const float* xb = x + (size_t)n * 3 * 224 * 224;
-    for (int i = tid; i < 3 * PH * PW; i += 256) {
+    // input patch -> LDS: unconditional clamped loads, all in flight before the first store (see dw_kernel)
+    constexpr int NPE = 3 * PH * PW, NPL = (NPE + 255) / 256;
+    float pv[NPL];
+    bool pok[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int i = tid + k * 256 < NPE ? tid + k * 256 : NPE - 1;
         const int ci = i / (PH * PW), r = (i / PW) % PH, c = i % PW;
         const int iy = r0 + r, ix = c0 + c;
-        float v = 0.f;
-        if ((unsigned)iy < 224u && (unsigned)ix < 224u) v = xb[(size_t)ci * 224 * 224 + iy * 224 + ix];
-        patch[(ci * PH + r) * PWP + c] = v;
+        const bool inside = (unsigned)iy < 224u && (unsigned)ix < 224u;
+        pv[k] = xb[(size_t)ci * 224 * 224 + (inside ? iy : 0) * 224 + (inside ? ix : 0)];
+        pok[k] = inside;
+    }
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int i = tid + k * 256 < NPE ? tid + k * 256 : NPE - 1;
+        const int ci = i / (PH * PW), r = (i / PW) % PH, c = i % PW;
+        patch[(ci * PH + r) * PWP + c] = pok[k] ? pv[k] : 0.f;
     }
     __syncthreads();
     const int cg = tid & 7;
