@@ -114,11 +114,44 @@ __device__ __forceinline__ void split8(const v4f lo, const v4f hi, bf8& s0, bf8&
     }
 }
 
-// epilogue shared by both kernels: the lane holds Y[m[mt]][n .. n+3] for n = nbase + 16 * nt
+// epilogue shared by both kernels: the lane holds Y[m[mt]][n .. n+3] for n = nbase + 16 * nt.
+// When N is a multiple of 4 (every layer of B0 and of the detector) the bias and residual fragments are requested
+// up front, unconditionally (clamped indices): under the per-tile `continue`s below hipcc issued them one by one,
+// each behind its own wait - the s_memtime trace showed 9,000 cycles of epilogue for MT x NT = 6 residual loads.
 template <int MT, int NT>
 __device__ __forceinline__ void s6_epilogue(const v4f (&acc)[MT][NT], const int (&m)[MT], int nbase,
                                             const float* __restrict__ bias, const float* __restrict__ R,
                                             float* __restrict__ Y, int M, int N, int act, int res_first) {
+    if ((N & 3) == 0) {                                  // uniform
+        v4f bv[NT], rv[MT][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nbase + nt * 16;
+            const int nc = n < N ? n : 0;
+            bv[nt] = ldg4(bias + nc);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int mc = m[mt] < M ? m[mt] : M - 1;
+                rv[mt][nt] = R ? ldg4(R + (size_t)mc * N + nc) : (v4f){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nbase + nt * 16;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                v4f v = acc[mt][nt] + bv[nt];
+                if (res_first) v += rv[mt][nt];
+                if (act == ACT_SWISH) v = swish4(v);
+                else if (act == ACT_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                if (!res_first) v += rv[mt][nt];
+                if (n < N && m[mt] < M) stg4(Y + (size_t)m[mt] * N + n, v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = nbase + nt * 16;
