@@ -406,14 +406,9 @@ __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* 
                 for (int p = 0; p < RP; ++p) acc[p] += in[p * S + kx] * w;
             }
         };
-        if constexpr (K == 5) {
-            // rolled: one kernel row (5 weight vectors) live at a time instead of all 25
+        // rolled: one kernel row (K weight vectors) live at a time instead of all K * K
 #pragma unroll 1
-            for (int ky = 0; ky < K; ++ky) tap_row(ky);
-        } else {
-#pragma unroll
-            for (int ky = 0; ky < K; ++ky) tap_row(ky);
-        }
+        for (int ky = 0; ky < K; ++ky) tap_row(ky);
         const int gy = ty0 + oy;
 #pragma unroll
         for (int p = 0; p < RP; ++p) {
