@@ -535,27 +535,39 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const float* __restrict_
         }
     }
 
-    for (int sub = 0; sub < NSUB; ++sub) {
+    // Per-chunk weights (depthwise taps, biases, the chunk's expand rows) are requested one chunk ahead into
+    // registers: loaded at the top of their own chunk they cost an exposed L2 round trip per chunk (600-1600 of
+    // ~10k cycles in the s_memtime trace).  All loads unconditional (clamped), see dw_kernel.
+    static_assert(K * K * CG <= 256, "one depthwise weight vector per thread");
+    struct ChunkW { v4f wl, bv, wf[NTB][KC], bex[NTB]; };
+    auto load_chunk = [&](int sub, ChunkW& w) {
         const int c0 = (group * NSUB + sub) * CB;
-        MB_TP(1);
-        if (sub > 0) __syncthreads();                            // previous chunk done with tile/wl/red
-        MB_TP(2);
-        for (int i = tid; i < K * K * CG; i += 256)
-            wl[i] = ldg4(Wt + (size_t)(i / CG) * C + c0 + 4 * (i % CG));
-        const v4f bv = ldg4(bias + c0 + 4 * (tid % CG));
-        // A operand: this chunk's expand weights, lane (channel j, k-quad q)
-        v4f wf[NTB][KC], bex[NTB];
+        const int i = tid < K * K * CG ? tid : 0;
+        w.wl = ldg4(Wt + (size_t)(i / CG) * C + c0 + 4 * (i % CG));
+        w.bv = ldg4(bias + c0 + 4 * (tid % CG));
 #pragma unroll
         for (int nt = 0; nt < NTB; ++nt) {
-            bex[nt] = ldg4(be + c0 + nt * 16 + 4 * q);
+            w.bex[nt] = ldg4(be + c0 + nt * 16 + 4 * q);
 #pragma unroll
             for (int kk = 0; kk < KC; ++kk) {
                 const int k = kk * 16 + 4 * q;
                 const v4f v = ldg4(We + (size_t)(c0 + nt * 16 + j) * Cin + (k < Cin ? k : 0));
-                wf[nt][kk] = k < Cin ? v : (v4f){0.f, 0.f, 0.f, 0.f};
+                w.wf[nt][kk] = k < Cin ? v : (v4f){0.f, 0.f, 0.f, 0.f};
             }
         }
-        MB_TP(3);
+    };
+    ChunkW cw[2];
+    load_chunk(0, cw[0]);
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const int c0 = (group * NSUB + sub) * CB;
+        ChunkW& cur = cw[sub & 1];
+        if (sub > 0) __syncthreads();                            // previous chunk done with tile/wl/red
+        if (tid < K * K * CG) wl[tid] = cur.wl;
+        load_chunk(sub + 1 < NSUB ? sub + 1 : NSUB - 1, cw[(sub + 1) & 1]);      // lands during this chunk
+        const v4f bv = cur.bv;
+        v4f (&wf)[NTB][KC] = cur.wf;
+        v4f (&bex)[NTB] = cur.bex;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int mt = wave + 4 * it;
