@@ -562,12 +562,15 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const float* __restrict_
     for (int sub = 0; sub < NSUB; ++sub) {
         const int c0 = (group * NSUB + sub) * CB;
         ChunkW& cur = cw[sub & 1];
+        MB_TP(1);
         if (sub > 0) __syncthreads();                            // previous chunk done with tile/wl/red
+        MB_TP(2);
         if (tid < K * K * CG) wl[tid] = cur.wl;
         load_chunk(sub + 1 < NSUB ? sub + 1 : NSUB - 1, cw[(sub + 1) & 1]);      // lands during this chunk
         const v4f bv = cur.bv;
         v4f (&wf)[NTB][KC] = cur.wf;
         v4f (&bex)[NTB] = cur.bex;
+        MB_TP(3);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int mt = wave + 4 * it;
@@ -620,11 +623,20 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
     __shared__ v4f wl[K * K * CG];
     __shared__ v4f red[4 * CG];
     __shared__ float patch[3 * PH * PWP];
-    __shared__ float ws[27 * 32];
+    __shared__ __attribute__((aligned(16))) float ws[27 * 32];
     const int tid = threadIdx.x, n = blockIdx.y, t = blockIdx.x;
     const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
-    for (int i = tid; i < 27 * 32; i += 256) ws[i] = ws_g[i];
-    for (int i = tid; i < K * K * CG; i += 256) wl[i] = ldg4(Wt + (size_t)(i / CG) * 32 + 4 * (i % CG));
+#ifdef MB_TRACE
+    int mtp = 0;
+    const int H = 224;
+#endif
+    MB_TP(0);
+    // weights: one 16-byte load per thread each (216 + 72 vectors), requested together with the patch below -
+    // the element-wise copy loops were four more serialized round trips in front of the patch loads
+    static_assert(27 * 32 / 4 <= 256 && K * K * CG <= 256, "one vector per thread");
+    const v4f ws_v = ldg4(ws_g + 4 * (tid < 216 ? tid : 215));
+    const int wi = tid < K * K * CG ? tid : 0;
+    const v4f wl_v = ldg4(Wt + (size_t)(wi / CG) * 32 + 4 * (wi % CG));
     const v4f bv = ldg4(bias + 4 * (tid % CG));
     // stem pixel (sy, sx) = (ty0 - 1 + py, tx0 - 1 + px) reads input rows 2*sy .. 2*sy+2 (TF-SAME: pad high only)
     const int r0 = 2 * (ty0 - 1), c0 = 2 * (tx0 - 1);
@@ -648,7 +660,11 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
         const int ci = i / (PH * PW), r = (i / PW) % PH, c = i % PW;
         patch[(ci * PH + r) * PWP + c] = pok[k] ? pv[k] : 0.f;
     }
+    if (tid < 216) *reinterpret_cast<v4f*>(&ws[4 * tid]) = ws_v;
+    if (tid < K * K * CG) wl[tid] = wl_v;
+    MB_TP(1);
     __syncthreads();
+    MB_TP(2);
     const int cg = tid & 7;
     const v4f bsv = ldg4(bs + 4 * cg);
     // thread = 4 output channels x 6 of the 180 halo pixels; taps outermost so each weight vector is read
@@ -675,6 +691,7 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
 #pragma unroll
                 for (int i = 0; i < NPX; ++i) acc[i] += pp[poff[i]] * w;
             }
+    MB_TP(3);
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
         const int p = (tid >> 3) + 32 * i;
@@ -689,8 +706,14 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
                 stg4(stem_out + (((size_t)n * 112 + sy) * 112 + sx) * 32 + 4 * cg, v);
         }
     }
+    MB_TP(4);
     __syncthreads();
+    MB_TP(5);
     dw_compute<K, S, CB, TH, TW, RP>(tile, wl, red, bv, Y, P, n, 112, 32, 0, ty0, tx0, t, tiles_sp);
+    MB_TP(6);
+#ifdef MB_TRACE
+    if (blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
+#endif
 }
 
 void launch_stem_dw(const float* x, const float* ws, const float* bs, const float* Wd, const float* bd, float* Y,
