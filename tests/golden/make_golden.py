@@ -17,7 +17,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import frames as F  # noqa: E402
 import rtdfd_amd  # noqa: E402
-from oracle import b0_ref, ssd_ref  # noqa: E402
+from oracle import b0_ref, mtcnn_ref, ssd_ref  # noqa: E402
+from tests import mt_images  # noqa: E402
 from oracle.forensics_ref import ForensicsRef  # noqa: E402
 
 
@@ -62,7 +63,19 @@ def main():
         det[name] = {"n_rows": len(rows), "top_scores": [r[0] for r in rows[:5]],
                      "boxes": ssd_ref.postprocess(rows, f.shape[0], f.shape[1], 0.5)}
     json.dump({"weights_seed": 0, "frames": det}, open(os.path.join(HERE, "ssd_boxes.json"), "w"), indent=1)
-    print("wrote b0_logits.json forensic_scores.json ssd_boxes.json")
+
+    mt = W.to_torch(W.seeded_mtcnn_state_dict(0))
+    cases = []
+    for (h, w, seed), img in zip(mt_images.CASES, mt_images.images()):
+        taps = {}
+        face = mtcnn_ref.mtcnn_forward(mt, img, taps)
+        cases.append({"image": f"mt_images.textured({h}, {w}, {seed})",
+                      "rows": [len(taps[k]) for k in ("stage1", "stage2", "stage3")],
+                      "selected": None if face is None else [float(v) for v in taps["selected"]],
+                      "face_sum": None if face is None else int(face.sum()),
+                      "face_corner": None if face is None else [int(v) for v in face[:, 0, :4].ravel()]})
+    json.dump({"weights_seed": 0, "cases": cases}, open(os.path.join(HERE, "mtcnn_faces.json"), "w"), indent=1)
+    print("wrote b0_logits.json forensic_scores.json ssd_boxes.json mtcnn_faces.json")
 
 
 if __name__ == "__main__":

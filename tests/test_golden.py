@@ -21,6 +21,7 @@ spec.loader.exec_module(mg)
 B0 = json.load(open(os.path.join(G, "b0_logits.json")))
 FOR = json.load(open(os.path.join(G, "forensic_scores.json")))
 SSD = json.load(open(os.path.join(G, "ssd_boxes.json")))
+MT = json.load(open(os.path.join(G, "mtcnn_faces.json")))
 
 
 def test_oracle_reproduces_b0_golden(pkg, seeded_sd):
@@ -65,3 +66,36 @@ def test_hip_hits_forensic_golden(b0_handle, name):
 def test_hip_hits_ssd_golden(b0_handle, name):
     got = b0_handle.detect_faces(mg.SSD_FRAMES[name](), 0.5)
     assert [list(b) for b in got] == SSD["frames"][name]["boxes"]
+
+
+def _mt_case(i):
+    from tests import mt_images
+
+    return mt_images.images()[i], MT["cases"][i]
+
+
+@pytest.mark.parametrize("i", range(len(MT["cases"])))
+def test_oracle_reproduces_mtcnn_golden(pkg, mtcnn_sd, i):
+    from oracle import mtcnn_ref
+
+    img, want = _mt_case(i)
+    taps = {}
+    face = mtcnn_ref.mtcnn_forward(pkg.weights.to_torch(mtcnn_sd), img, taps)
+    assert [len(taps[k]) for k in ("stage1", "stage2", "stage3")] == want["rows"]
+    assert (face is None) == (want["selected"] is None)
+    if face is not None:
+        assert np.abs(np.array(want["selected"]) - taps["selected"]).max() <= 1e-2
+        assert int(face.sum()) == want["face_sum"] and [int(v) for v in face[:, 0, :4].ravel()] == want["face_corner"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(MT["cases"])))
+def test_hip_hits_mtcnn_golden(mt_handle, i):
+    img, want = _mt_case(i)
+    bgr = np.ascontiguousarray(img[..., ::-1])
+    assert [mt_handle.mtcnn_tap(bgr, k).shape[0] for k in ("stage1", "stage2", "stage3")] == want["rows"]
+    face, box = mt_handle.mtcnn_align(bgr)
+    assert (face is None) == (want["selected"] is None)
+    if face is not None:
+        assert np.abs(np.array(want["selected"]) - box).max() <= 1e-2
+        assert int(face.sum()) == want["face_sum"] and [int(v) for v in face[:, 0, :4].ravel()] == want["face_corner"]
