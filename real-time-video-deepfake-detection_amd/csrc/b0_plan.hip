@@ -274,8 +274,8 @@ int b0_forward(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* t
     mk.mark("avgpool");
     if ((rc = tap_out(h, tap, "feat", h->feat, (size_t)n * 1280))) return rc;
     if (!logits_dev) return DFD_OK;   // extract_features stops here
-    launch_pointwise(h->feat, P.fc1_w, P.fc1_b, nullptr, nullptr, h->fc1, n, 1280, 512, 1, ACT_RELU, s);
-    launch_pointwise(h->fc1, P.fc2_w, P.fc2_b, nullptr, nullptr, h->fc2, n, 512, 256, 1, ACT_RELU, s);
+    if ((rc = pointwise(h, h->feat, P.fc1_w, P.fc1_b, nullptr, nullptr, h->fc1, n, 1280, 512, 1, ACT_RELU))) return rc;
+    if ((rc = pointwise(h, h->fc1, P.fc2_w, P.fc2_b, nullptr, nullptr, h->fc2, n, 512, 256, 1, ACT_RELU))) return rc;
     launch_pointwise(h->fc2, P.fc3_w, P.fc3_b, nullptr, nullptr, logits_dev, n, 256, 1, 1, ACT_NONE, s);
     mk.mark("mlp");
     if ((rc = tap_out(h, tap, "logit", logits_dev, (size_t)n))) return rc;
