@@ -366,6 +366,22 @@ bool launch_conv_gemm(const float* X, const float* W, const float* bias, const f
 // the image: TF-SAME padding), weights too.  Thread = (channel quad, strip of RP outputs
 // along W); per kernel row it pulls the (RP-1)S+K input vectors of the strip into
 // registers once and reuses them across the K taps.
+// LDS tile layout shared by the three producers (halo staging, fused expand, fused stem) and dw_compute: pixel p,
+// channel quad c -> 16-byte unit p * CG + (c ^ swz(p)).  The MFMA expand hands a lane (pixel = lane & 15, quad
+// = lane >> 4): 8 consecutive lanes of a ds_write_b128 are 8 consecutive pixels of ONE quad, which in the plain
+// p * CG + c layout is the same bank group 8 times (CG = 8) or 4 times (CG = 4) - 67 % / 41-51 % of all LDS
+// cycles of those kernels were conflict cycles, on an LDS that was busy 50-77 % of the time.  XOR-ing the quad
+// with low pixel bits spreads them over all banks; within a pixel it is a permutation, so producers that write
+// quad-fastest and the reads (one pixel per lane quad-group) keep their bank pattern.
+// Measured: it pays where the writes were 8-way conflicted (CG = 8 fused kernel, block 1: 0.263 -> 0.250 ms); at
+// CG = 4 and in the kernels whose producers were conflict-free anyway the per-tap index arithmetic of the reads
+// (no more base + immediate offsets) costs more than the conflicts did (+8 %), so SWZ is on for that one only.
+template <int CG, bool SWZ>
+__device__ __forceinline__ int tile_unit(int p, int c) {
+    if constexpr (SWZ && CG >= 8) return p * CG + (c ^ (p & 7));
+    else return p * CG + c;
+}
+
 template <int K, int S, int CB, int TH, int TW>
 struct DwShape {
     static constexpr int CG = CB / 4;
@@ -375,7 +391,7 @@ struct DwShape {
 // depthwise conv of the LDS tile + folded BN + swish + store + per-tile SE partial sums.
 // Ends with a barrier-protected write of P; callers that reuse tile/wl/red afterwards must
 // __syncthreads() first.
-template <int K, int S, int CB, int TH, int TW, int RP>
+template <int K, int S, int CB, int TH, int TW, int RP, bool SWZ = false>
 __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* red,
                                            const v4f bv, float* __restrict__ Y,
                                            float* __restrict__ P, int n, int Ho, int C, int c0, int ty0,
@@ -395,10 +411,10 @@ __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* 
 #pragma unroll
         for (int p = 0; p < RP; ++p) acc[p] = bv;
         auto tap_row = [&](int ky) {
-            const v4f* row = &tile[((oy * S + ky) * IW + ox0 * S) * CG + cg];
+            const int p0 = (oy * S + ky) * IW + ox0 * S;
             v4f in[NIN];
 #pragma unroll
-            for (int i = 0; i < NIN; ++i) in[i] = row[i * CG];
+            for (int i = 0; i < NIN; ++i) in[i] = tile[tile_unit<CG, SWZ>(p0 + i, cg)];
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
                 const v4f w = wl[(ky * K + kx) * CG + cg];
@@ -591,14 +607,14 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const float* __restrict_
                 if (p < NP) {
 #pragma unroll
                     for (int nt = 0; nt < NTB; ++nt)
-                        tile[p * CG + nt * 4 + q] = inside ? swish4(acc[nt] + bex[nt]) : (v4f){0.f, 0.f, 0.f, 0.f};
+                        tile[tile_unit<CG, (CG >= 8)>(p, nt * 4 + q)] = inside ? swish4(acc[nt] + bex[nt]) : (v4f){0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
         MB_TP(4);
         __syncthreads();
         MB_TP(5);
-        dw_compute<K, S, CB, TH, TW, RP>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
+        dw_compute<K, S, CB, TH, TW, RP, (CG >= 8)>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
         MB_TP(6);
     }
 #ifdef MB_TRACE
