@@ -66,6 +66,24 @@ int dfd_max_batch(const dfd_handle* h);
  *   "mtcnn" (default 1): align every crop with the MTCNN cascade when the blob carries one.
  *   "profile_stride" (default 1): between dfd_b0_profile_begin/end only every k-th forward records events. */
 int dfd_set_option(dfd_handle* h, const char* name, int value);
+/*   "gemm_tile" (default -1): >= 0 forces split-GEMM instance number value % (candidates of the shape) for every
+ *   1x1 / k x k conv - parity tests walk 0 .. dfd_gemm_tile_count()-1 and require identical bits; -1 = the
+ *   handle's tile table (measured by dfd_warmup, heuristic for shapes it has not seen). */
+int dfd_gemm_tile_count(void);
+
+/* One untimed pass over the classifier at batch `n_crops` (0 = skip; <= max_batch) and the detector at
+ * `n_frames` frames (0 = skip) on synthetic data.  Sizes workspaces, splits the weights and MEASURES the
+ * split-GEMM tile of every layer shape at those batch sizes (the only entry point that synchronises for
+ * tuning; the "_device" entry points never do - a shape that was not warmed up runs a heuristic tile, with
+ * the same result bits).  Call once per (n_crops, n_frames) you intend to serve; DFD_S6_TUNE=0 in the
+ * environment skips the measurement. */
+int dfd_warmup(dfd_handle* h, int n_crops, int n_frames);
+
+/* Host-only arithmetic of the split GEMM's 32-bit addressing guard: how many of `rows` rows of `row_bytes`
+ * bytes one kernel launch may cover (a multiple of rows_per_image, whole `rows` when everything fits below
+ * 2^31 bytes, -1 when a single image does not).  Batches above that are issued as several launches, so every
+ * max_batch dfd_create accepts is addressable.  No GPU needed. */
+long long dfd_gemm_chunk_rows(long long rows, long long row_bytes, long long rows_per_image);
 
 /* ---- device memory and stream plumbing (no reference counterpart) -------------- */
 int dfd_device_alloc(dfd_handle* h, size_t bytes, void** dptr);

@@ -34,6 +34,9 @@ SIGNATURES = {
     "dfd_last_error": (C.c_char_p, [C.c_void_p]),
     "dfd_max_batch": (C.c_int, [C.c_void_p]),
     "dfd_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "dfd_gemm_tile_count": (C.c_int, []),
+    "dfd_warmup": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "dfd_gemm_chunk_rows": (C.c_longlong, [C.c_longlong, C.c_longlong, C.c_longlong]),
     "dfd_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "dfd_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dfd_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -168,6 +171,10 @@ class Handle:
 
     def set_option(self, name: str, value: int):
         self._check(self._lib.dfd_set_option(self._p, name.encode(), int(value)))
+
+    def warmup(self, n_crops: int = 0, n_frames: int = 0):
+        """Measure the split-GEMM tiles for these batch sizes (synchronises; serving calls never do)."""
+        self._check(self._lib.dfd_warmup(self._p, int(n_crops), int(n_frames)))
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)

@@ -39,10 +39,23 @@ bool launch_conv_gemm(const float* X, const float* W, const float* bias, const f
 size_t split_weights_count(int N, int K);
 void launch_split_weights(const float* W, unsigned short* out, int N, int K, hipStream_t s);
 bool split_gemm_supports(int K, int N);
-void launch_pointwise_split(const float* X, const unsigned short* W3, const float* bias, const float* gate,
+// `tab` is the handle's tile table (null: heuristic tile, nothing remembered).  A shape the table has no
+// measurement for runs the heuristic tile unless the table is in tuning mode (dfd_warmup), where every
+// candidate is timed on the caller's operands - the only place these launchers synchronise.  Calls whose
+// activations span 2^31 bytes or more are issued as several launches over whole images (32-bit buffer offsets
+// inside the kernels); false = shape not supported.
+struct S6Table;
+S6Table* s6_table_create();
+void s6_table_destroy(S6Table* t);
+void s6_table_set_force(S6Table* t, int idx);      // >= 0: run candidate idx (mod count) everywhere; -1: normal
+void s6_table_set_tuning(S6Table* t, bool on);
+int s6_table_measured(const S6Table* t);           // shapes with a measured tile
+int s6_max_candidates();                           // upper bound of the candidate count over all shapes
+long long s6_chunk_rows(long long M, long long row_bytes, long long HW);
+bool launch_pointwise_split(S6Table* tab, const float* X, const unsigned short* W3, const float* bias, const float* gate,
                             const float* R, float* Y, int M, int K, int N, int HW, int act, hipStream_t s);
-bool launch_conv_gemm_split(const float* X, const unsigned short* W3, const float* bias, const float* R, float* Y,
-                            int n_img, const ConvGeom& g, int Cout, int act, bool res_first, hipStream_t s);
+bool launch_conv_gemm_split(S6Table* tab, const float* X, const unsigned short* W3, const float* bias, const float* R,
+                            float* Y, int n_img, const ConvGeom& g, int Cout, int act, bool res_first, hipStream_t s);
 
 // depthwise kxk conv (k in {3,5}, stride in {1,2}, TF-SAME pad) + folded BN + swish, and
 // per-tile channel sums for the squeeze-excite pool: P[n][tile][c].  Returns the tile count

@@ -156,7 +156,8 @@ int pointwise(dfd_handle* h, const float* X, const float* W, const float* bias, 
     if (h->split_gemm && N >= 16 && split_gemm_supports(K, N)) {       // never on M: batch-invariant results
         const unsigned short* w3 = split_weights(h, W, N, K);
         if (!w3) return DFD_ERR_HIP;
-        launch_pointwise_split(X, w3, bias, gate, R, Y, M, K, N, HW, act, h->stream);
+        if (!launch_pointwise_split(h->gemm, X, w3, bias, gate, R, Y, M, K, N, HW, act, h->stream))
+            return fail(h, DFD_ERR_CAPACITY, "1x1 conv M=%d K=%d: one image exceeds the 2^31-byte addressing of the split GEMM", M, K);
     } else {
         launch_pointwise(X, W, bias, gate, R, Y, M, K, N, HW, act, h->stream);
     }

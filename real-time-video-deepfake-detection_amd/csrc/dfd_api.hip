@@ -14,6 +14,15 @@ int dev_alloc(dfd_handle* h, size_t bytes, float** out) {
     return DFD_OK;
 }
 
+// deterministic pseudo-random crops for dfd_warmup (roughly the range of normalised pixels)
+__global__ __launch_bounds__(256) void fill_pattern_kernel(float* __restrict__ x, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t v = (uint32_t)i * 2654435761u;
+    v ^= v >> 15; v *= 2246822519u; v ^= v >> 13;
+    x[i] = ((float)(v >> 8) * (1.0f / 16777216.0f) - 0.5f) * 4.0f;
+}
+
 int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, int max_batch) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -29,6 +38,8 @@ int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, in
     if (const char* e = getenv("DFD_FUSE_EXPAND")) h->fuse_expand = atoi(e) != 0;
     if (const char* e = getenv("DFD_FUSE_STEM")) h->fuse_stem = atoi(e) != 0;
     if (const char* e = getenv("DFD_SPLIT_GEMM")) h->split_gemm = atoi(e) != 0;
+    h->gemm = s6_table_create();
+    if (!h->gemm) return fail(h, DFD_ERR_ARG, "out of host memory");
     DFD_HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     DFD_HIP_TRY(h, hipEventCreate(&h->ev0));
     DFD_HIP_TRY(h, hipEventCreate(&h->ev1));
@@ -79,6 +90,8 @@ void destroy_impl(dfd_handle* h) {
     ssd_destroy(h);
     mtcnn_destroy(h);
     freq_destroy(h);
+    s6_table_destroy(h->gemm);
+    h->gemm = nullptr;
     for (void* p : h->owned)
         if (p) hipFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -122,8 +135,34 @@ int dfd_set_option(dfd_handle* h, const char* name, int value) {
     if (strcmp(name, "fuse_stem") == 0) { h->fuse_stem = value != 0; return DFD_OK; }
     if (strcmp(name, "split_gemm") == 0) { h->split_gemm = value != 0; return DFD_OK; }
     if (strcmp(name, "mtcnn") == 0) { h->use_mtcnn = value != 0; return DFD_OK; }
+    if (strcmp(name, "gemm_tile") == 0) { s6_table_set_force(h->gemm, value); return DFD_OK; }
     if (strcmp(name, "profile_stride") == 0) { h->prof_stride = value > 0 ? value : 1; return DFD_OK; }
     return fail(h, DFD_ERR_ARG, "unknown option '%s'", name);
+}
+
+int dfd_warmup(dfd_handle* h, int n_crops, int n_frames) {
+    if (!h) return DFD_ERR_ARG;
+    if (n_crops < 0 || n_crops > h->max_batch || n_frames < 0)
+        return fail(h, DFD_ERR_ARG, "warmup: n_crops outside 0..%d or n_frames negative", h->max_batch);
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    s6_table_set_tuning(h->gemm, true);
+    int rc = DFD_OK;
+    if (n_crops > 0) {
+        const size_t cnt = (size_t)n_crops * 3 * 224 * 224;
+        hipLaunchKernelGGL(fill_pattern_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->in_nchw, cnt);
+        rc = b0_forward(h, h->in_nchw, n_crops, h->logits, nullptr, nullptr);
+    }
+    if (rc == DFD_OK && n_frames > 0) rc = ssd_warmup(h, n_frames);
+    s6_table_set_tuning(h->gemm, false);
+    if (rc) return rc;
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DFD_OK;
+}
+
+int dfd_gemm_tile_count(void) { return s6_max_candidates(); }
+
+long long dfd_gemm_chunk_rows(long long rows, long long row_bytes, long long rows_per_image) {
+    return s6_chunk_rows(rows, row_bytes, rows_per_image);
 }
 
 int dfd_device_alloc(dfd_handle* h, size_t bytes, void** dptr) {

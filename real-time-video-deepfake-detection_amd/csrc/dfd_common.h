@@ -23,6 +23,8 @@ void freq_destroy(dfd_handle* h);
 struct SsdState;        // ssd_api.hip
 int ssd_init(dfd_handle* h);
 void ssd_destroy(dfd_handle* h);
+int ssd_warmup(dfd_handle* h, int n_frames);   // detector forward on n synthetic 300x300 inputs (tile measurement)
+struct S6Table;         // gemm_split.hip: measured split-GEMM tiles of this handle
 struct MtcnnState;      // mtcnn_api.hip
 int mtcnn_init(dfd_handle* h);
 void mtcnn_destroy(dfd_handle* h);
@@ -99,6 +101,7 @@ struct dfd_handle {
     bool fuse_expand = true;             // MBConv blocks 1-5: expand conv computed inside the depthwise kernel
     bool split_gemm = true;              // 1x1 / k x k convs on the bf16x3-split MFMA path (gemm_split.hip)
     std::map<const float*, unsigned short*> wsplit;   // fp32 weight tensor -> its three-plane bf16 split
+    dfd::S6Table* gemm = nullptr;        // split-GEMM tile per shape (measured by dfd_warmup, heuristic otherwise)
     dfd::B0Prof prof;                    // layer events between profile_begin/end
     int prof_steps = 0;                  // forwards that carried events
     int prof_seen = 0, prof_stride = 1;  // forwards since profile_begin; every prof_stride-th one is instrumented

@@ -22,7 +22,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
-#include <mutex>
+#include <algorithm>
+#include <new>
 #include <tuple>
 #include <type_traits>
 #include <vector>
@@ -198,8 +199,9 @@ __device__ __forceinline__ void s6_epilogue(const v4f (&acc)[MT][NT], const int 
 // K-step, so rows per block (NW * MT * 16) set the L2 read traffic for the weights, (M / rows) * N * K * 6 bytes -
 // 260 MB for M = 12544, N = 192, K = 1152 at 64 rows, against 58 MB of activations: every inner-loop variant of
 // that layer lands on the same 45-55 us, which is that traffic.  Eight waves share the tile among twice the rows.
+// (launch bound: two blocks per CU where the LDS tile allows it - 2 x KS x NT x 3 KB of 160 KB - else one)
 template <int NT, bool CONV, int MT, bool GATE, int KS, bool PIPE = false, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void pw6_kernel(const float* __restrict__ X,
+__global__ __launch_bounds__(NW * 64, (NW == 4 && 2 * KS * NT * 16 * S6_ROWB <= 80 * 1024) ? 2 : 1) void pw6_kernel(const float* __restrict__ X,
                                                      const unsigned short* __restrict__ W3, int plane, int Kp,
                                                      const float* __restrict__ bias,
                                                      const float* __restrict__ gate,
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void pw6_kernel(const flo
 // The raw activations are prefetched two K-steps ahead (register ring of two, the K loop is unrolled by two),
 // the weights one step ahead.
 template <int WM, int WN, int MT, int NT, bool CONV, bool GATE>
-__global__ __launch_bounds__(256, 2) void pw7_kernel(const float* __restrict__ X,
+__global__ __launch_bounds__(256, (2 * (WM * MT + WN * NT) * 16 * S6_ROWB <= 80 * 1024) ? 2 : 1) void pw7_kernel(const float* __restrict__ X,
                                                      const unsigned short* __restrict__ W3, int plane, int Kp,
                                                      const float* __restrict__ bias,
                                                      const float* __restrict__ gate,
@@ -747,15 +749,15 @@ __global__ __launch_bounds__(256, 2) void pw7_kernel(const float* __restrict__ X
     s6_epilogue<MT, NT>(acc, m, n0 + wn * NT * 16 + 4 * q, bias, R, Y, M, N, act, res_first);
 }
 
-// kind 0: pw6 (block = 4 waves x MT*16 rows, NT*16 columns); kind 1: pw7 (WM x WN waves of MT x NT tiles)
-struct S6Tile { int kind, wm, wn, mt, nt, ks, mblocks, nblocks; };      // ks: K-steps per stage (pw6); 3 = PIPE variant
+// kind 0: pw6 (block = NW waves x MT*16 rows, NT*16 columns; wm = NW); kind 1: pw7 (WM x WN waves of MT x NT tiles)
+struct S6Tile { int kind, wm, wn, mt, nt, ks, mblocks, nblocks; bool measured; };      // ks: K-steps per stage (pw6)
 static S6Tile make_tile(int M, int N, int kind, int wm, int wn, int mt, int nt, int ks = 1) {
     const int bm = wm * mt * 16, bn = wn * nt * 16;
-    return S6Tile{kind, wm, wn, mt, nt, ks, (M + bm - 1) / bm, (N + bn - 1) / bn};
+    return S6Tile{kind, wm, wn, mt, nt, ks, (M + bm - 1) / bm, (N + bn - 1) / bn, false};
 }
 static S6Tile make_tile6(int M, int N, int mt, int nt, int ks = 1) { return make_tile(M, N, 0, 4, 1, mt, nt, ks); }
 
-// Heuristic tile (used when measuring is switched off): the biggest per-wave pw6 tile that still fills the chip.
+// Heuristic tile (shapes nobody warmed up): the biggest per-wave pw6 tile that still fills the chip.
 static S6Tile pick_tile6(int M, int N) {
     const int tiles = (N + 15) / 16;
     S6Tile best = make_tile6(M, N, 1, 1);
@@ -779,14 +781,39 @@ static S6Tile pick_tile6(int M, int N) {
     OP(2, 2, 1, 2) OP(2, 2, 1, 3) OP(2, 2, 1, 4) OP(2, 2, 1, 6) OP(2, 2, 2, 2) OP(2, 2, 2, 3)     \
     OP(2, 2, 2, 4) OP(2, 2, 2, 6) OP(2, 2, 4, 2) OP(2, 2, 4, 3)
 
+// Every instance the library can launch for a shape, in a fixed order (what the tuner measures and what
+// dfd_set_option(h, "gemm_tile", i) indexes): pw6 with 4 waves (KS x MT x NT), pw6 with 8 waves (KS x NT), pw7.
+static std::vector<S6Tile> s6_candidates(int M, int K, int N) {
+    const int tiles = (N + 15) / 16;
+    std::vector<S6Tile> raw, out;
+    for (int ks = 1; ks <= (K > 32 ? 2 : 1); ++ks)
+        for (int mt = 1; mt <= 2; ++mt)
+            for (int nt = 1; nt <= 8 && nt <= tiles; ++nt) raw.push_back(make_tile6(M, N, mt, nt, ks));
+    for (int ks = 1; ks <= (K > 32 ? 2 : 1); ++ks)              // eight waves per block (MT = 1)
+        for (int nt = 2; nt <= 8 && nt <= tiles; ++nt) raw.push_back(make_tile(M, N, 0, 8, 1, 1, nt, ks));
+#define DFD_S7_CAND(WMV, WNV, MTV, NTV) raw.push_back(make_tile(M, N, 1, WMV, WNV, MTV, NTV));
+    DFD_S7_CONFIGS(DFD_S7_CAND)
+#undef DFD_S7_CAND
+    for (const S6Tile& t : raw) {
+        const int bn_tiles = t.kind == 0 ? t.nt : t.wn * t.nt;
+        if ((double)tiles / ((double)t.nblocks * bn_tiles) < 0.7) continue;      // mostly padding
+        if ((long long)t.mblocks * t.nblocks > (1 << 20)) continue;
+        out.push_back(t);
+    }
+    if (out.empty()) out.push_back(make_tile6(M, N, 1, 1));
+    return out;
+}
+
 template <bool CONV, bool GATE>
 static void s6_dispatch(const S6Tile& t, const float* X, const unsigned short* W3, const float* bias,
                         const float* gate, const float* R, float* Y, int M, int K, int N, int HW, int act,
                         const ConvGeom& g, int res_first, hipStream_t s) {
     const int grid = ((t.mblocks + 7) / 8) * 8 * t.nblocks;
     const int Kp = (K + S6_KPAD - 1) / S6_KPAD * S6_KPAD, plane = s6_np(N) * Kp;
+    // the caller (s6_run) keeps every call below 2^31 bytes of activations: the kernels address X / gate with
+    // 32-bit buffer offsets
     const unsigned xbytes = CONV ? (unsigned)((size_t)(M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin * 4) : (unsigned)((size_t)M * K * 4);
-    const unsigned gbytes = GATE ? (unsigned)((size_t)(M / HW) * K * 4) : 0u;
+    const unsigned gbytes = GATE ? (unsigned)((size_t)((M + HW - 1) / HW) * K * 4) : 0u;
     if (t.kind == 1) {
 #define DFD_S7_CASE(WMV, WNV, MTV, NTV)                                                                              \
     if (t.wm == WMV && t.wn == WNV && t.mt == MTV && t.nt == NTV) {                                                  \
@@ -801,16 +828,6 @@ static void s6_dispatch(const S6Tile& t, const float* X, const unsigned short* W
 #define DFD_S6_LAUNCH(NTV, MTV, KSV)                                                                                 \
     hipLaunchKernelGGL((pw6_kernel<NTV, CONV, MTV, GATE, KSV>), dim3(grid), dim3(256), 0, s, X, W3, plane, Kp, bias, gate, \
                        R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes)
-#define DFD_S6_LAUNCHP(NTV, MTV)                                                                                     \
-    hipLaunchKernelGGL((pw6_kernel<NTV, CONV, MTV, GATE, 1, true>), dim3(grid), dim3(256), 0, s, X, W3, plane, Kp, bias, gate, \
-                       R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes)
-#ifdef DFD_S6_PIPE
-#define DFD_S6_PIPE_CASES(NTV)                              \
-    else if (t.ks == 3 && t.mt == 2) DFD_S6_LAUNCHP(NTV, 2); \
-    else if (t.ks == 3) DFD_S6_LAUNCHP(NTV, 1);
-#else
-#define DFD_S6_PIPE_CASES(NTV)
-#endif
 #define DFD_S6_LAUNCH8(NTV, KSV)                                                                                     \
     hipLaunchKernelGGL((pw6_kernel<NTV, CONV, 1, GATE, KSV, false, 8>), dim3(grid), dim3(512), 0, s, X, W3, plane, Kp, bias, \
                        gate, R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes)
@@ -818,7 +835,6 @@ static void s6_dispatch(const S6Tile& t, const float* X, const unsigned short* W
     case NTV:                                                   \
         if (t.wm == 8 && t.ks == 2) DFD_S6_LAUNCH8(NTV, 2);     \
         else if (t.wm == 8) DFD_S6_LAUNCH8(NTV, 1);             \
-        DFD_S6_PIPE_CASES(NTV)                                  \
         else if (t.mt == 2 && t.ks == 2) DFD_S6_LAUNCH(NTV, 2, 2);   \
         else if (t.mt == 2) DFD_S6_LAUNCH(NTV, 2, 1);           \
         else if (t.ks == 2) DFD_S6_LAUNCH(NTV, 1, 2);           \
@@ -826,110 +842,149 @@ static void s6_dispatch(const S6Tile& t, const float* X, const unsigned short* W
         break;
     switch (t.nt) { DFD_S6_NT_CASES(DFD_S6_CASE) }
 #undef DFD_S6_LAUNCH
-#undef DFD_S6_LAUNCHP
 #undef DFD_S6_LAUNCH8
 #undef DFD_S6_CASE
 }
 
 // The best tile depends on how the block count quantises into rounds of resident blocks (8 XCDs x 32 CUs x
-// 2-6 blocks, by VGPRs and LDS of the instance), on K (prologue/epilogue share) and on the L2 re-reads of X:
-// measured rather than modelled.  The first call with a new (M, K, N, mode) times every tile on the caller's
-// own operands (the kernel is idempotent: Y never aliases X or R) and keeps the fastest; every tile computes
-// each output with the same MFMA sequence, so the choice never changes a result bit.  DFD_S6_TUNE=0: heuristic.
+// 1-6 blocks, by VGPRs and LDS of the instance), on K (prologue/epilogue share) and on the L2 re-reads of X:
+// measured rather than modelled - but only inside dfd_warmup (table->tuning), which is allowed to synchronise.
+// Everywhere else a shape that was never warmed up runs the heuristic tile and nothing blocks.  Every tile
+// computes each output with the same MFMA sequence, so the choice never changes a result bit
+// (tests/test_gemm_tiles_gpu.py walks every candidate through dfd_set_option(h, "gemm_tile", i)).
 struct S6Key {
     int M, K, N, mode;
     bool operator<(const S6Key& o) const {
         return std::tie(M, K, N, mode) < std::tie(o.M, o.K, o.N, o.mode);
     }
 };
-static std::map<S6Key, S6Tile> g_tiles;
-static std::mutex g_tiles_mu;
+struct S6Table {
+    std::map<S6Key, S6Tile> tiles;
+    int force = -1;          // >= 0: candidate index (mod the shape's candidate count) for every call
+    bool tuning = false;     // measure unseen shapes (synchronises the stream): dfd_warmup only
+};
+
+S6Table* s6_table_create() { return new (std::nothrow) S6Table(); }
+void s6_table_destroy(S6Table* t) { delete t; }
+void s6_table_set_force(S6Table* t, int idx) { if (t) t->force = idx; }
+void s6_table_set_tuning(S6Table* t, bool on) { if (t) t->tuning = on; }
+int s6_table_measured(const S6Table* t) {
+    int n = 0;
+    if (t) for (const auto& kv : t->tiles) n += kv.second.measured ? 1 : 0;
+    return n;
+}
+int s6_max_candidates() { return (int)s6_candidates(1 << 20, 1152, 1280).size(); }
+
+// Rows of one kernel call: activations (and gates) are addressed with 32-bit byte offsets and sized with a
+// 32-bit num_records, so a call never spans 2^31 bytes of X.  Chunks are whole images (HW rows) so that the
+// gate index m / HW and the convolution's image index stay relative to the chunk base.
+long long s6_chunk_rows(long long M, long long row_bytes, long long HW) {
+    const long long lim = (1ll << 31) - 1;
+    if (HW <= 0) HW = 1;
+    if (M * row_bytes <= lim) return M;
+    long long imgs = lim / (row_bytes * HW);
+    if (imgs < 1) return -1;                                   // one image alone is too large (never for B0 / SSD)
+    return imgs * HW;
+}
 
 template <bool CONV, bool GATE>
-static void s6_run(const float* X, const unsigned short* W3, const float* bias, const float* gate, const float* R,
-                   float* Y, int M, int K, int N, int HW, int act, const ConvGeom& g, int res_first, hipStream_t s) {
-    static const bool tune = !(getenv("DFD_S6_TUNE") && atoi(getenv("DFD_S6_TUNE")) == 0);
-    // M in 8 buckets per octave: data-dependent row counts (the MTCNN candidate windows) share a measurement
-    int mkey = M;
-    if (M > 64) {
-        int sh = 0;
-        while ((M >> sh) > 15) ++sh;
-        mkey = ((M + (1 << sh) - 1) >> sh) << sh;
-    }
-    const S6Key key{mkey, K, N, (CONV ? 1 : 0) | (GATE ? 2 : 0) | (CONV ? (g.ksize << 8) | (g.stride << 4) : 0)};
-    S6Tile tile;
-    bool have = false;
-    {
-        std::lock_guard<std::mutex> lk(g_tiles_mu);
-        auto it = g_tiles.find(key);
-        if (it != g_tiles.end()) { tile = it->second; have = true; }
-    }
-    if (!have) {
-        tile = pick_tile6(M, N);
-        hipEvent_t e0, e1;
-        if (tune && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-            const int tiles = (N + 15) / 16;
-            std::vector<S6Tile> cands;
-            // (ks = 3, the PIPE variant, is not offered: measured within 1 % of ks = 1 on every B0 shape, so its 48
-            // instances are not built either - DFD_S6_PIPE=1 at compile time brings them back)
-            for (int ks = 1; ks <= (K > 32 ? 2 : 1); ++ks)
-                for (int mt = 1; mt <= 2; ++mt)
-                    for (int nt = 1; nt <= 8 && nt <= tiles; ++nt) cands.push_back(make_tile6(M, N, mt, nt, ks));
-            for (int ks = 1; ks <= (K > 32 ? 2 : 1); ++ks)              // eight waves per block (MT = 1)
-                for (int nt = 2; nt <= 8 && nt <= tiles; ++nt) cands.push_back(make_tile(M, N, 0, 8, 1, 1, nt, ks));
-#define DFD_S7_CAND(WMV, WNV, MTV, NTV) cands.push_back(make_tile(M, N, 1, WMV, WNV, MTV, NTV));
-            DFD_S7_CONFIGS(DFD_S7_CAND)
-#undef DFD_S7_CAND
-            float best_ms = 1e30f;
-            for (const S6Tile& t : cands) {
-                const int bn_tiles = t.kind == 0 ? t.nt : t.wn * t.nt;
-                if ((double)tiles / ((double)t.nblocks * bn_tiles) < 0.7) continue;      // mostly padding
-                if ((long long)t.mblocks * t.nblocks > (1 << 20)) continue;
+static void s6_measure(const std::vector<S6Tile>& cands, S6Tile* tile, const S6Key& key, const float* X,
+                       const unsigned short* W3, const float* bias, const float* gate, const float* R, float* Y, int M,
+                       int K, int N, int HW, int act, const ConvGeom& g, int res_first, hipStream_t s) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return;
+    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return; }
+    float best_ms = 1e30f;
+    for (const S6Tile& t : cands) {
+        s6_dispatch<CONV, GATE>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
+        float ms = 1e30f;
+        bool ok = true;
+        for (int rep = 0; rep < 2 && ok; ++rep) {          // best of two groups of three: robust to a stray hiccup
+            hipEventRecord(e0, s);
+            for (int r = 0; r < 3; ++r)
                 s6_dispatch<CONV, GATE>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
-                float ms = 1e30f;
-                bool ok = true;
-                for (int rep = 0; rep < 2 && ok; ++rep) {          // best of two groups of three: robust to a stray hiccup
-                    hipEventRecord(e0, s);
-                    for (int r = 0; r < 3; ++r)
-                        s6_dispatch<CONV, GATE>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
-                    hipEventRecord(e1, s);
-                    float m1 = 0.f;
-                    ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&m1, e0, e1) == hipSuccess;
-                    if (ok && m1 < ms) ms = m1;
-                }
-                if (!ok) continue;
-                if (getenv("DFD_S6_VERBOSE") && atoi(getenv("DFD_S6_VERBOSE")) > 1)
-                    fprintf(stderr, "[dfd]   kind %d %dx%d mt=%d nt=%d ks=%d: %.1f us\n", t.kind, t.wm, t.wn, t.mt, t.nt, t.ks, ms * 1000.f / 3.f);
-                if (ms < best_ms) { best_ms = ms; tile = t; }
-            }
-            hipEventDestroy(e0);
-            hipEventDestroy(e1);
-            if (getenv("DFD_S6_VERBOSE"))
-                fprintf(stderr, "[dfd] split gemm M=%d K=%d N=%d mode=%d -> kind %d %dx%d mt=%d nt=%d ks=%d (%.1f us)\n", M, K, N,
-                        key.mode, tile.kind, tile.wm, tile.wn, tile.mt, tile.nt, tile.ks, best_ms * 1000.f / 3.f);
+            hipEventRecord(e1, s);
+            float m1 = 0.f;
+            ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&m1, e0, e1) == hipSuccess;
+            if (ok && m1 < ms) ms = m1;
         }
-        std::lock_guard<std::mutex> lk(g_tiles_mu);
-        g_tiles[key] = tile;
+        if (!ok) continue;
+        if (getenv("DFD_S6_VERBOSE") && atoi(getenv("DFD_S6_VERBOSE")) > 1)
+            fprintf(stderr, "[dfd]   kind %d %dx%d mt=%d nt=%d ks=%d: %.1f us\n", t.kind, t.wm, t.wn, t.mt, t.nt, t.ks, ms * 1000.f / 3.f);
+        if (ms < best_ms) { best_ms = ms; *tile = t; tile->measured = true; }
     }
-    tile = make_tile(M, N, tile.kind, tile.wm, tile.wn, tile.mt, tile.nt, tile.ks);      // block counts for this call's M
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (getenv("DFD_S6_VERBOSE"))
+        fprintf(stderr, "[dfd] split gemm M=%d K=%d N=%d mode=%d -> kind %d %dx%d mt=%d nt=%d ks=%d (%.1f us)\n", M, K, N,
+                key.mode, tile->kind, tile->wm, tile->wn, tile->mt, tile->nt, tile->ks, best_ms * 1000.f / 3.f);
+}
+
+template <bool CONV, bool GATE>
+static void s6_run_one(S6Table* tab, const float* X, const unsigned short* W3, const float* bias, const float* gate,
+                       const float* R, float* Y, int M, int K, int N, int HW, int act, const ConvGeom& g, int res_first,
+                       hipStream_t s) {
+    static const bool tune_env = !(getenv("DFD_S6_TUNE") && atoi(getenv("DFD_S6_TUNE")) == 0);
+    S6Tile tile;
+    if (tab && tab->force >= 0) {
+        const std::vector<S6Tile> cands = s6_candidates(M, K, N);
+        tile = cands[(size_t)tab->force % cands.size()];
+    } else {
+        // M in 8 buckets per octave: data-dependent row counts (the MTCNN candidate windows) share an entry
+        int mkey = M;
+        if (M > 64) {
+            int sh = 0;
+            while ((M >> sh) > 15) ++sh;
+            mkey = ((M + (1 << sh) - 1) >> sh) << sh;
+        }
+        const S6Key key{mkey, K, N, (CONV ? 1 : 0) | (GATE ? 2 : 0) | (CONV ? (g.ksize << 8) | (g.stride << 4) : 0)};
+        const bool tuning = tab && tab->tuning && tune_env;
+        auto it = tab ? tab->tiles.find(key) : std::map<S6Key, S6Tile>::iterator();
+        if (tab && it != tab->tiles.end() && (it->second.measured || !tuning)) {
+            tile = it->second;
+        } else {
+            tile = pick_tile6(M, N);
+            if (tuning) s6_measure<CONV, GATE>(s6_candidates(M, K, N), &tile, key, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
+            if (tab) tab->tiles[key] = tile;
+        }
+        tile = make_tile(M, N, tile.kind, tile.wm, tile.wn, tile.mt, tile.nt, tile.ks);      // block counts for this call's M
+    }
     s6_dispatch<CONV, GATE>(tile, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
 }
 
 bool split_gemm_supports(int K, int N) { return K % 8 == 0 && K >= 16 && split_weights_count(N, K) * 6 < (1ull << 31); }
 
-void launch_pointwise_split(const float* X, const unsigned short* W3, const float* bias, const float* gate,
+bool launch_pointwise_split(S6Table* tab, const float* X, const unsigned short* W3, const float* bias, const float* gate,
                             const float* R, float* Y, int M, int K, int N, int HW, int act, hipStream_t s) {
     const ConvGeom none{};
-    if (gate) s6_run<false, true>(X, W3, bias, gate, R, Y, M, K, N, HW, act, none, 0, s);
-    else s6_run<false, false>(X, W3, bias, nullptr, R, Y, M, K, N, HW, act, none, 0, s);
+    if (HW <= 0) HW = 1;
+    const long long chunk = s6_chunk_rows(M, (long long)K * 4, gate ? HW : 1);
+    if (chunk <= 0) return false;
+    for (long long m0 = 0; m0 < M; m0 += chunk) {
+        const int mc = (int)std::min<long long>(chunk, M - m0);
+        const float* xc = X + (size_t)m0 * K;
+        const float* rc = R ? R + (size_t)m0 * N : nullptr;
+        float* yc = Y + (size_t)m0 * N;
+        if (gate) s6_run_one<false, true>(tab, xc, W3, bias, gate + (size_t)(m0 / HW) * K, rc, yc, mc, K, N, HW, act, none, 0, s);
+        else s6_run_one<false, false>(tab, xc, W3, bias, nullptr, rc, yc, mc, K, N, HW, act, none, 0, s);
+    }
+    return true;
 }
 
-bool launch_conv_gemm_split(const float* X, const unsigned short* W3, const float* bias, const float* R, float* Y,
-                            int n_img, const ConvGeom& g, int Cout, int act, bool res_first, hipStream_t s) {
+bool launch_conv_gemm_split(S6Table* tab, const float* X, const unsigned short* W3, const float* bias, const float* R,
+                            float* Y, int n_img, const ConvGeom& g, int Cout, int act, bool res_first, hipStream_t s) {
     if (g.Cin % S6_BK != 0) return false;                  // a K stage must not straddle two taps
-    const int M = n_img * g.Ho * g.Wo, K = g.ksize * g.ksize * g.Cin;
+    const int K = g.ksize * g.ksize * g.Cin;
     if (!split_gemm_supports(K, Cout)) return false;
-    s6_run<true, false>(X, W3, bias, nullptr, R, Y, M, K, Cout, 1, act, g, res_first ? 1 : 0, s);
+    const long long in_img = (long long)g.H * g.W * g.Cin * 4, out_rows = (long long)g.Ho * g.Wo;
+    const long long imgs = s6_chunk_rows(n_img, in_img, 1);        // "rows" = images of in_img bytes
+    if (imgs <= 0) return false;
+    for (long long i0 = 0; i0 < n_img; i0 += imgs) {
+        const int ni = (int)std::min<long long>(imgs, n_img - i0);
+        s6_run_one<true, false>(tab, X + (size_t)i0 * g.H * g.W * g.Cin, W3, bias, nullptr,
+                                R ? R + (size_t)i0 * out_rows * Cout : nullptr, Y + (size_t)i0 * out_rows * Cout,
+                                (int)(ni * out_rows), K, Cout, 1, act, g, res_first ? 1 : 0, s);
+    }
     return true;
 }
 

@@ -90,7 +90,7 @@ static bool conv_gemm(dfd_handle* h, const float* X, const float* W, const float
     const int K = g.ksize * g.ksize * g.Cin;
     if (h->split_gemm && g.Cin % 32 == 0 && split_gemm_supports(K, Cout)) {
         const unsigned short* w3 = split_weights(h, W, Cout, K);
-        if (w3 && launch_conv_gemm_split(X, w3, bias, R, Y, n, g, Cout, act, res_first, h->stream)) return true;
+        if (w3 && launch_conv_gemm_split(h->gemm, X, w3, bias, R, Y, n, g, Cout, act, res_first, h->stream)) return true;
     }
     return launch_conv_gemm(X, W, bias, R, Y, n, g, Cout, act, res_first, h->stream);
 }
@@ -271,6 +271,21 @@ int ssd_forward(dfd_handle* h, const uint8_t* in300, int n, const char* tap_name
     }
     DFD_HIP_TRY(h, hipGetLastError());
     return DFD_OK;
+}
+
+// dfd_warmup: the detector's layer shapes at batch n, on a byte pattern (sizes the workspace, splits the weights and
+// - with the tile table in tuning mode - measures the GEMM tiles)
+int ssd_warmup(dfd_handle* h, int n) {
+    if (!h->ssd || !h->ssd->ready || n <= 0) return DFD_OK;
+    int rc;
+    const size_t bytes = (size_t)n * SSD_IN * SSD_IN * 3;
+    if ((rc = ensure(h, &h->ssd->in_u8, bytes))) return rc;
+    std::vector<uint8_t> pat(bytes);
+    uint32_t st = 12345u;
+    for (size_t i = 0; i < bytes; ++i) { st = st * 1664525u + 1013904223u; pat[i] = (uint8_t)(50 + ((st >> 24) * 150 >> 8)); }
+    DFD_HIP_TRY(h, hipMemcpyAsync(h->ssd->in_u8.p, pat.data(), bytes, hipMemcpyHostToDevice, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return ssd_forward(h, (const uint8_t*)h->ssd->in_u8.p, n, nullptr, nullptr, 0, nullptr);
 }
 
 // reference face_detection.py:84-105 on one image's DetectionOutput rows
