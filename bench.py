@@ -144,6 +144,104 @@ def e2e_mtcnn(frames, boxes, K):
     return out
 
 
+def stream_frame(base, t):
+    """frame t of a synthetic 1080p stream: the stream's base frame with a band that scrolls 4 px per frame and a
+    patch whose brightness follows t - cheap to make, deterministic in (base, t), frame-to-frame mean |diff| ~ 1"""
+    f = base.copy()
+    y0 = (37 * t) % (base.shape[0] - 256)
+    f[y0:y0 + 256] = np.roll(base[y0:y0 + 256], 4 * (t + 1), axis=1)
+    f[64:192, 64:192] = np.clip(base[64:192, 64:192].astype(np.int16) + ((t * 7) % 23) - 11, 0, 255).astype(np.uint8)
+    return f
+
+
+def config5_streams(h, rank, world, dist, local_rank, waves=6, n_streams=8, verify_frames=12):
+    """BASELINE.json configs[4] / SURVEY 8(d) Config 5: 8 seeded 1080p streams (seeds 100-107), frame t of every
+    stream on rank t % G (weak scaling: 8 frames per GPU per wave), per wave ONE all-gather of 80-byte records
+    (dfd_vote_allgather = ncclAllGather over RCCL through the C ABI; torch.distributed as a fallback) inside the
+    timed loop, then every rank replays temporal forensic signal + votes in frame order.  After the timed loop rank 0
+    recomputes the single-GPU sequence for a prefix of the frames and requires identical verdict sequences."""
+    import torch
+
+    from rtdfd_amd import streams as S
+
+    Hh, Ww = 1080, 1920
+    bases = [np.random.default_rng(100 + s).integers(50, 200, (Hh, Ww, 3), dtype=np.uint8) for s in range(n_streams)]
+    transport, note = "rccl", None
+    try:
+        cid = [h.comm_unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(cid, src=0)
+        h.comm_init(cid[0], rank, world)
+    except Exception as e:                                       # noqa: BLE001 - any failure -> documented fallback
+        transport, note = ("torch" if world > 1 else "local"), f"dfd_comm_init failed: {e}"
+    sh = S.ShardedStreams(h, n_streams, rank, world, transport=transport)
+
+    def batch(t):
+        cur = [stream_frame(bases[s], t) for s in range(n_streams)]
+        prev = [stream_frame(bases[s], t - 1) for s in range(n_streams)] if t > 0 else []
+        return np.stack(cur + prev), [(s, t, t > 0) for s in range(n_streams)]
+
+    # resident in HBM before the timed region: this rank's frames (and their predecessors) for every wave
+    staged = []
+    for w in range(waves):
+        arr, items = batch(sh.frame_of(w))
+        staged.append((h.alloc(arr.nbytes).upload(arr), items))
+    # untimed warm-up on a throw-away driver (workspace growth, first-use costs), incl. one collective
+    warm = S.ShardedStreams(h, n_streams, rank, world, transport=transport)
+    warm.finish_wave(warm.local_records(staged[0][0].ptr, Hh, Ww, staged[0][1]))
+    h.sync()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    seq = {s: [] for s in range(n_streams)}
+    t0 = time.perf_counter()
+    for fd, items in staged:
+        out = sh.finish_wave(sh.local_records(fd.ptr, Hh, Ww, items))       # collective inside the timed loop
+        for s, rows in out.items():
+            seq[s] += [(r['frame'], r['confidence_level'], r['fake_probability']) for r in rows]
+    h.sync()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    for fd, _ in staged:
+        fd.free()
+    frames = waves * world * n_streams
+    res = {"workload": f"{n_streams} seeded 1080p streams (seeds 100-107), frame t on rank t % {world}; per wave: SSD detect + "
+                       "faces[0] -> CLAHE -> 224 -> B0, six forensic signals (temporal from recomputed gray(t-1)), one "
+                       "all-gather of 80-byte records, replay of temporal score + votes on every rank",
+           "frames_per_s": round(frames / dt, 1), "ms_per_wave": round(dt / waves * 1e3, 3), "waves": waves,
+           "frames_per_wave_per_gpu": n_streams, "transport": transport,
+           "collective": "dfd_vote_allgather (ncclAllGather, RCCL)" if transport == "rccl" else transport,
+           "record_bytes": S.RECORD_FLOATS * 8, "bytes_gathered_per_wave": S.RECORD_FLOATS * 8 * n_streams * world}
+    if note:
+        res["transport_note"] = note
+    # verdict-sequence equality with the single-GPU sequence (rank 0, untimed, a prefix of the frames)
+    if rank == 0:
+        nver = min(verify_frames, waves * world)
+        one = S.ShardedStreams(h, n_streams, 0, 1, transport="local")
+        truth = {s: [] for s in range(n_streams)}
+        for t in range(nver):
+            arr, items = batch(t)
+            fd = h.alloc(arr.nbytes).upload(arr)
+            for s, rows in one.finish_wave(one.local_records(fd.ptr, Hh, Ww, items)).items():
+                truth[s] += [(r['frame'], r['confidence_level'], r['fake_probability']) for r in rows]
+            fd.free()
+        same = all(seq[s][:nver] == truth[s] for s in range(n_streams))
+        res["verdicts_equal_single_gpu"] = bool(same)
+        res["verified_frames_per_stream"] = nver
+        res["verdicts_stream0"] = [lv for _, lv, _ in seq[0]]
+        if not same:
+            raise SystemExit("config5: sharded verdict sequence differs from the single-GPU sequence")
+    if transport == "rccl":
+        h.comm_destroy()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +251,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
     ap.add_argument("--no-e2e", action="store_true", help="skip the 1080p end-to-end extra (configs[2]/[3])")
+    ap.add_argument("--no-streams", action="store_true", help="skip the frame-sharded 8-stream extra (configs[4])")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -264,6 +363,26 @@ def main():
     }
     if not args.no_e2e:
         out["e2e"] = e2e_frames(h, rank, dist, local_rank)
+    if not args.no_streams:
+        # the extra must never cost the main line: if the collective set-up wedges, rank 0 prints what it has
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["config5"] = {"error": "timed out after 240 s (collective set-up?)"}
+                print(json.dumps(out), flush=True)
+            os._exit(0 if rank == 0 else 1)
+
+        guard = threading.Timer(240.0, bail)
+        guard.daemon = True
+        guard.start()
+        try:
+            out["config5"] = config5_streams(h, rank, world, dist, local_rank)
+        except SystemExit:
+            raise
+        except Exception as e:                                   # noqa: BLE001
+            out["config5"] = {"error": f"{type(e).__name__}: {e}"}
+        guard.cancel()
     if rank == 0:
         if args.layers:
             agg = {}

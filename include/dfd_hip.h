@@ -237,6 +237,33 @@ int dfd_analyze_batch_device(dfd_handle* h, const uint8_t* frames_dev, int n, in
                              int apply_clahe, int with_forensics, int32_t* xywh_out, int* n_faces_out,
                              float* logits_out, double* forensic_prob_out);
 
+/* ---- frame-sharded streams (BASELINE.json configs[4]) ------------------------------
+ * With frame t of a stream on rank t % G, the only state that crosses frames is the vote window (reference
+ * deepfake_detection.py:111-118) and the analyzer's temporal signal (reference frame_analysis.py:349-389: the
+ * previous gray frame and the last 30 mean differences).  A rank therefore computes, for each of its frames,
+ * the five stateless signals and the mean absolute gray difference against the frame's predecessor (which it
+ * also holds: recomputed, not communicated), all ranks exchange fixed-size records with ONE all-gather per wave,
+ * and every rank replays temporal score, weighted sum and vote in frame order (host: streams.py).
+ *
+ * dfd_forensic_signals_device: n packed BGR frames resident in HBM; prev_index[f] = index (inside this batch) of
+ * frame f's predecessor or -1.  scores5_out [n][5] = frequency, noise, ela, edge, color (all five computed;
+ * the caller drops noise/ela/color on "fast" frames); mean_diff_out [n] = mean |gray - gray_prev| or -1. */
+int dfd_forensic_signals_device(dfd_handle* h, const uint8_t* frames_dev, int n, int height, int width,
+                                const int32_t* prev_index, double* scores5_out, double* mean_diff_out);
+
+/* Vote exchange over RCCL (xGMI inside a node).  Rank 0 obtains an id (ncclGetUniqueId) and hands its
+ * DFD_COMM_ID_BYTES bytes to the other ranks by any host channel (file, socket, torch.distributed store); every
+ * rank then calls dfd_comm_init on its handle.  dfd_vote_allgather copies `bytes_per_rank` bytes of records
+ * to the device, runs ONE ncclAllGather on the handle's stream and returns all ranks' blocks, rank-major, in
+ * host memory (world * bytes_per_rank bytes): the collective named in SURVEY 8(b)/(e).  librccl is opened on
+ * first use (DFD_RCCL_LIB overrides the name); without it these three return DFD_ERR_STATE. */
+#define DFD_COMM_ID_BYTES 128
+int dfd_comm_unique_id(void* id_out);
+int dfd_comm_init(dfd_handle* h, const void* id, int rank, int world);
+int dfd_comm_destroy(dfd_handle* h);
+int dfd_comm_info(const dfd_handle* h, int* rank, int* world);      /* world = 0: no communicator */
+int dfd_vote_allgather(dfd_handle* h, const void* local_records, size_t bytes_per_rank, void* all_records_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,13 @@ SIGNATURES = {
     "dfd_forensics_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "dfd_forensics_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_int)]),
+    "dfd_forensic_signals_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
+    "dfd_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dfd_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "dfd_comm_destroy": (C.c_int, [C.c_void_p]),
+    "dfd_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dfd_vote_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dfd_b0_profile_begin": (C.c_int, [C.c_void_p]),
     "dfd_b0_profile_end": (C.c_int, [C.c_void_p, c_float_p, C.POINTER(C.c_char_p), C.c_int,
                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -361,6 +368,53 @@ class Handle:
         boxes = [[tuple(int(v) for v in xy[f, i]) for i in range(nf[f])] for f in range(n)]
         logits = [lg[f, : nf[f]].copy() for f in range(n)]
         return boxes, logits, (fp if with_forensics else None)
+
+    def forensic_signals_device(self, frames_dev: int, n: int, height: int, width: int, prev_index):
+        """-> (scores [n][5] = frequency, noise, ela, edge, color; mean_diff [n], -1 where prev_index < 0)"""
+        pi = np.ascontiguousarray(np.asarray(prev_index, np.int32).reshape(-1))
+        if pi.size != n:
+            raise ValueError("prev_index must have one entry per frame")
+        sc = np.empty((n, 5), np.float64)
+        md = np.empty(n, np.float64)
+        self._check(self._lib.dfd_forensic_signals_device(self._p, frames_dev, int(n), int(height), int(width), _ptr(pi),
+                                                          _ptr(sc), _ptr(md)))
+        return sc, md
+
+    # -- vote exchange over RCCL (C ABI)
+    COMM_ID_BYTES = 128
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        lib = load()
+        buf = (C.c_char * Handle.COMM_ID_BYTES)()
+        rc = lib.dfd_comm_unique_id(buf)
+        if rc != 0:
+            raise DfdError(rc, (lib.dfd_last_error(None) or b"dfd_comm_unique_id failed").decode())
+        return bytes(buf)
+
+    def comm_init(self, comm_id: bytes, rank: int, world: int):
+        if len(comm_id) != self.COMM_ID_BYTES:
+            raise ValueError("communicator id must be 128 bytes")
+        buf = (C.c_char * self.COMM_ID_BYTES).from_buffer_copy(comm_id)
+        self._check(self._lib.dfd_comm_init(self._p, buf, int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._check(self._lib.dfd_comm_destroy(self._p))
+
+    def comm_info(self):
+        r, w = C.c_int(), C.c_int()
+        self._check(self._lib.dfd_comm_info(self._p, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def vote_allgather(self, local: np.ndarray) -> np.ndarray:
+        """One ncclAllGather of this rank's record block -> (world, *local.shape), rank-major."""
+        a = np.ascontiguousarray(local)
+        _, world = self.comm_info()
+        if world <= 0:
+            raise DfdError(-5, "vote_allgather: no communicator (comm_init)")
+        out = np.empty((world,) + a.shape, a.dtype)
+        self._check(self._lib.dfd_vote_allgather(self._p, _ptr(a), a.nbytes, _ptr(out)))
+        return out
 
     @property
     def has_mtcnn(self) -> bool:

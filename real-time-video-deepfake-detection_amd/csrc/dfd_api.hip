@@ -86,6 +86,7 @@ void destroy_impl(dfd_handle* h) {
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    comm_destroy(h);
     forensic_destroy(h);
     ssd_destroy(h);
     mtcnn_destroy(h);

@@ -24,6 +24,8 @@ struct SsdState;        // ssd_api.hip
 int ssd_init(dfd_handle* h);
 void ssd_destroy(dfd_handle* h);
 int ssd_warmup(dfd_handle* h, int n_frames);   // detector forward on n synthetic 300x300 inputs (tile measurement)
+struct CommState;       // comm_api.hip: RCCL communicator of the vote exchange
+void comm_destroy(dfd_handle* h);
 struct S6Table;         // gemm_split.hip: measured split-GEMM tiles of this handle
 struct MtcnnState;      // mtcnn_api.hip
 int mtcnn_init(dfd_handle* h);
@@ -96,6 +98,7 @@ struct dfd_handle {
     dfd::FreqState* freq = nullptr;           // compute_frequency_features tables + scratch
     dfd::SsdState* ssd = nullptr;             // detector plan + workspace (null: blob has no detector)
     dfd::MtcnnState* mtcnn = nullptr;         // MTCNN cascade (null: blob has none)
+    dfd::CommState* comm = nullptr;           // vote exchange (null until dfd_comm_init)
     bool use_mtcnn = true;                    // classify paths align each crop with the cascade when the blob has one
     bool fuse_stem = true;               // stem conv computed inside block 0's depthwise kernel
     bool fuse_expand = true;             // MBConv blocks 1-5: expand conv computed inside the depthwise kernel

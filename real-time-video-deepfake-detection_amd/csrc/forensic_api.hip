@@ -24,6 +24,7 @@ struct ForensicState {
     ForensicBuffers buf{};
     float2* twiddle = nullptr;
     double* diff_part = nullptr;   // 256 partial sums
+    DevBuf pair_idx, pair_part;    // dfd_forensic_signals_device: predecessor indices, [n][256] partial sums
 };
 
 void forensic_destroy(dfd_handle* h) {
@@ -243,6 +244,47 @@ int dfd_forensics(dfd_handle* h, int stream_id, const uint8_t* bgr, int hh, int 
     if (rc) return rc;
     DFD_HIP_TRY(h, hipMemcpyAsync(h->frame_buf.p, bgr, (size_t)hh * stride, hipMemcpyHostToDevice, h->stream));
     return forensics_run(h, stream_id, (const uint8_t*)h->frame_buf.p, hh, ww, stride, full, scores_out, prob_out, stats_out);
+}
+
+int dfd_forensic_signals_device(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, const int32_t* prev_index,
+                                double* scores5_out, double* mean_diff_out) {
+    if (!h) return DFD_ERR_ARG;
+    if (!frames_dev || n <= 0 || hh <= 0 || ww <= 0 || !prev_index || !scores5_out || !mean_diff_out)
+        return fail(h, DFD_ERR_ARG, "forensic_signals: bad pointer or geometry");
+    for (int f = 0; f < n; ++f)
+        if (prev_index[f] >= n) return fail(h, DFD_ERR_ARG, "forensic_signals: prev_index[%d] = %d outside the batch", f, prev_index[f]);
+    if (!h->has_color) return fail(h, DFD_ERR_STATE, "forensics needs the colour tables (blob packed without luts)");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    int rc = state_init(h, n);
+    if (rc) return rc;
+    ForensicState& F = *h->forensic;
+    if ((rc = ensure(h, &F.pair_idx, (size_t)n * 4))) return rc;
+    if ((rc = ensure(h, &F.pair_part, (size_t)n * 256 * 8))) return rc;
+    const int stride = ww * 3;
+    DFD_HIP_TRY(h, hipMemcpyAsync(F.pair_idx.p, prev_index, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    launch_resize_bgr(frames_dev, n, hh, ww, stride, (size_t)hh * stride, F.buf.rs, 256, 256, h->stream);
+    launch_forensics(F.buf, n, true, h->color, F.twiddle, h->stream);
+    launch_absdiff_pairs(F.buf.gray, (const int*)F.pair_idx.p, (double*)F.pair_part.p, n, h->stream);
+    std::vector<double> st((size_t)n * FORENSIC_STATS), noise((size_t)n * 64), ela((size_t)n * 64), part((size_t)n * 256);
+    DFD_HIP_TRY(h, hipMemcpyAsync(st.data(), F.buf.stats, st.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipMemcpyAsync(noise.data(), F.buf.stats_noise, noise.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipMemcpyAsync(ela.data(), F.buf.stats_ela, ela.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipMemcpyAsync(part.data(), F.pair_part.p, part.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, hipGetLastError());
+    for (int f = 0; f < n; ++f) {
+        double sc[6], ex[10];
+        static_scores(&st[(size_t)f * FORENSIC_STATS], &noise[(size_t)f * 64], &ela[(size_t)f * 64], true, sc, ex);
+        for (int i = 0; i < 5; ++i) scores5_out[(size_t)f * 5 + i] = sc[i];
+        if (prev_index[f] < 0) {
+            mean_diff_out[f] = -1.0;
+        } else {
+            double sum = 0;                                      // the summation order of forensics_run
+            for (int i = 0; i < 256; ++i) sum += part[(size_t)f * 256 + i];
+            mean_diff_out[f] = sum / 65536.0;
+        }
+    }
+    return DFD_OK;
 }
 
 int dfd_forensics_reset(dfd_handle* h, int stream_id) {

@@ -492,6 +492,22 @@ void launch_forensics(const ForensicBuffers& B, int n, bool full, const ColorTab
     hipLaunchKernelGGL(stats_finalize_kernel, dim3((n + 63) / 64), dim3(64), 0, s, B, full ? 1 : 0, n);
 }
 
+// frame-sharded streams: frame f against frame prev_index[f] of the same batch (gray planes [n][65536]);
+// prev_index < 0 = no predecessor (partial sums 0).  part: [n][256].
+__global__ __launch_bounds__(256) void absdiff_pairs_kernel(const uint8_t* __restrict__ gray, const int* __restrict__ prev_index,
+                                                            double* __restrict__ part) {
+    __shared__ double red[4];
+    const int f = blockIdx.y, pf = prev_index[f];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int d = pf < 0 ? 0 : abs((int)gray[(size_t)f * FPIX + i] - (int)gray[(size_t)pf * FPIX + i]);
+    const double t = block_sum<256>((double)d, red);
+    if (threadIdx.x == 0) part[(size_t)f * 256 + blockIdx.x] = t;
+}
+
+void launch_absdiff_pairs(const uint8_t* gray, const int* prev_index, double* part, int n, hipStream_t s) {
+    hipLaunchKernelGGL(absdiff_pairs_kernel, dim3(256, n), dim3(256), 0, s, gray, prev_index, part);
+}
+
 void launch_absdiff(const uint8_t* gray, const uint8_t* prev, double* part, hipStream_t s) {
     hipLaunchKernelGGL(absdiff_kernel, dim3(256), dim3(256), 0, s, gray, prev, part);
 }

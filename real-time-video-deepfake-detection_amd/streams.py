@@ -1,0 +1,183 @@
+"""Frame-sharded streams: frame t of a stream on rank t % G, ONE all-gather of fixed-size records per wave,
+then every rank replays temporal forensic score, weighted sum and vote in frame order (BASELINE.json
+configs[4]).
+
+What crosses frames in the reference's /analyze flow (backend_server.py:147-233) is
+  * the analyzer's temporal signal: previous gray frame + the last 30 mean differences + its frame counter
+    (frame_analysis.py:349-389) and the full/fast schedule on the detector's frame counter
+    (deepfake_detection.py:509-512),
+  * the TemporalTracker (deepfake_detection.py:93-290).
+Everything else is a pure function of one frame.  A rank therefore computes per frame: the face
+probability of faces[0] (or none), the five stateless forensic scores and mean|gray(t) - gray(t-1)| - it holds
+frame t-1 too and recomputes its gray plane (64 KB) instead of receiving it - and ships them as one
+80-byte record.  `StreamReplica.replay` is the rest of the flow; fed the records of all ranks in frame order
+it performs exactly the arithmetic of the single-GPU stateful path (csrc/forensic_api.hip forensics_run +
+DeepfakeDetector.analyze_request), so every rank ends each wave with bit-identical vote state.
+
+Transports for the exchange: "rccl" = dfd_vote_allgather through the C ABI (ncclAllGather on the handle's
+stream), "torch" = torch.distributed.all_gather_into_tensor (gloo in the CPU tests), "local" = world size 1.
+"""
+from __future__ import annotations
+
+import math
+from collections import deque
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .tracker import TemporalTracker
+
+# record layout (float64 each)
+F_STREAM, F_FRAME, F_FACE_PROB, F_MEAN_DIFF, F_FREQ, F_NOISE, F_ELA, F_EDGE, F_COLOR, F_NFACES = range(10)
+RECORD_FLOATS = 10
+FULL_WEIGHTS = (0.25, 0.20, 0.20, 0.15, 0.10, 0.10)      # frequency, noise, ela, edge, color, temporal (:49-56)
+
+
+def _clip01(v: float) -> float:
+    return 0.0 if v < 0.0 else (1.0 if v > 1.0 else v)
+
+
+def _sigmoid32(logit) -> float:
+    x = np.float32(logit)
+    return float(np.float32(1.0) / (np.float32(1.0) + np.exp(-x, dtype=np.float32)))
+
+
+class StreamReplica:
+    """All cross-frame state of one /analyze stream; identical on every rank after each replayed record."""
+
+    def __init__(self, detection_threshold: float = 0.55, full_forensic_interval: int = 3):
+        self.tracker = TemporalTracker(window_size=60, high_confidence_threshold=0.6, voting_window=10,
+                                       detection_threshold=detection_threshold)
+        self.full_forensic_interval = full_forensic_interval
+        self.diffs: deque = deque(maxlen=30)          # frame_analysis.py:36
+        self.analyzer_frames = 0                      # FrameForensicAnalyzer.frame_count
+        self.frame_count = 0                          # DeepfakeDetector.frame_count
+        self.next_frame = 0
+
+    def forensic_probability(self, rec) -> float:
+        """temporal score + weighted sum for this frame (the host half of csrc/forensic_api.hip forensics_run)"""
+        full = self.frame_count % self.full_forensic_interval == 0     # before the counter moves (server order)
+        self.analyzer_frames += 1
+        temporal = 0.0
+        md = float(rec[F_MEAN_DIFF])
+        if md >= 0.0:                                                  # a predecessor exists
+            self.diffs.append(md)
+            if len(self.diffs) >= 5:
+                d = list(self.diffs)
+                m = 0.0
+                for v in d:
+                    m += v
+                m /= len(d)
+                q = 0.0
+                for v in d:
+                    q += (v - m) * (v - m)
+                cv = math.sqrt(q / len(d)) / (m + 1e-10)
+                s = 0.0
+                if cv > 1.5:
+                    s += 0.4
+                elif cv > 1.0:
+                    s += 0.2
+                if md < 0.3 and self.analyzer_frames > 10:
+                    s += 0.3
+                elif md < 0.8 and self.analyzer_frames > 10:
+                    s += 0.1
+                temporal = _clip01(s)
+        comb = 0.0
+        if full:
+            sc = (rec[F_FREQ], rec[F_NOISE], rec[F_ELA], rec[F_EDGE], rec[F_COLOR], temporal)
+            for v, w in zip(sc, FULL_WEIGHTS):
+                comb += float(v) * w
+        else:
+            comb += float(rec[F_FREQ]) * 0.45
+            comb += temporal * 0.25
+            comb += float(rec[F_EDGE]) * 0.30
+        return _clip01(comb)
+
+    def replay(self, rec) -> dict:
+        frame = int(rec[F_FRAME])
+        if frame != self.next_frame:
+            raise ValueError(f"records must arrive in frame order: got frame {frame}, expected {self.next_frame}")
+        self.next_frame += 1
+        fprob = self.forensic_probability(rec)
+        self.frame_count += 1
+        p = rec[F_FACE_PROB]
+        vote = fprob if np.isnan(p) else float(p)                     # backend_server.py:166,199
+        self.tracker.update(vote)
+        return {'frame': frame, 'analysis_mode': 'frame_only' if np.isnan(p) else 'face+frame',
+                'fake_probability': vote, 'frame_forensic_probability': fprob,
+                'confidence_level': self.tracker.get_confidence_level(), 'faces_detected': int(rec[F_NFACES])}
+
+
+def exchange(block: np.ndarray, transport: str = "local", handle=None, group=None) -> np.ndarray:
+    """(capacity, 10) float64 of this rank -> (world * capacity, 10) of all ranks, rank-major."""
+    block = np.ascontiguousarray(block, np.float64)
+    if transport == "local":
+        return block
+    if transport == "rccl":
+        return handle.vote_allgather(block).reshape(-1, RECORD_FLOATS)
+    if transport == "torch":
+        import torch
+        import torch.distributed as dist
+
+        world = dist.get_world_size(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        send = torch.from_numpy(block).to(dev)
+        recv = torch.empty((world * block.shape[0], RECORD_FLOATS), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        return recv.cpu().numpy()
+    raise ValueError(f"unknown transport {transport!r}")
+
+
+def replay_all(replicas: Sequence[StreamReplica], records: np.ndarray) -> Dict[int, List[dict]]:
+    """Feed gathered records (unused slots have stream < 0) to the replicas in (frame, stream) order."""
+    rows = [r for r in records if r[F_STREAM] >= 0]
+    rows.sort(key=lambda r: (r[F_FRAME], r[F_STREAM]))
+    out: Dict[int, List[dict]] = {}
+    for r in rows:
+        s = int(r[F_STREAM])
+        out.setdefault(s, []).append(replicas[s].replay(r))
+    return out
+
+
+class ShardedStreams:
+    """Per-rank driver.  A wave = one frame of every stream on every rank (frame index wave * G + rank)."""
+
+    def __init__(self, handle, n_streams: int, rank: int = 0, world: int = 1, transport: Optional[str] = None,
+                 detection_threshold: float = 0.55, group=None):
+        self.h, self.n_streams, self.rank, self.world, self.group = handle, n_streams, rank, world, group
+        self.transport = transport or ("local" if world == 1 else "torch")
+        self.replicas = [StreamReplica(detection_threshold) for _ in range(n_streams)]
+        self._calib_heur = None
+
+    def frame_of(self, wave: int) -> int:
+        return wave * self.world + self.rank
+
+    def local_records(self, frames_dev: int, height: int, width: int, items, conf_thr: float = 0.5) -> np.ndarray:
+        """items: [(stream, frame index, has_prev)] for the batch resident at frames_dev, laid out as all current
+        frames first, then the predecessors of those that have one, in the same order.  One detector + classifier
+        pass over the current frames (faces[0] per frame, as the server does) and one forensic pass."""
+        m = len(items)
+        prevs = [i for i, it in enumerate(items) if it[2]]
+        prev_index = np.full(m + len(prevs), -1, np.int32)
+        for k, i in enumerate(prevs):
+            prev_index[i] = m + k
+        boxes, logits, _ = self.h.analyze_batch_device(frames_dev, m, height, width, forced_boxes=None,
+                                                       confidence_threshold=conf_thr, max_faces=1, with_forensics=False)
+        scores, mdiff = self.h.forensic_signals_device(frames_dev, m + len(prevs), height, width, prev_index)
+        block = np.full((self.n_streams, RECORD_FLOATS), -1.0, np.float64)
+        if m > self.n_streams:
+            raise ValueError("more frames in a wave than record slots")
+        small = height < 30 or width < 30
+        for i, (stream, frame, _) in enumerate(items):
+            p = np.nan
+            if boxes[i] and not small:
+                x, y, w, h = boxes[i][0]
+                lg = logits[i][0]
+                if not np.isnan(lg):
+                    p = float(np.clip(_sigmoid32(lg) + (0.10 if (h < 80 or w < 80) else 0.0), 0, 1))   # :445-455,489-502
+            block[i] = (stream, frame, p, mdiff[i], *scores[i], len(boxes[i]))
+        return block
+
+    def finish_wave(self, block: np.ndarray) -> Dict[int, List[dict]]:
+        """collective: exchange + replay; identical return value on every rank"""
+        return replay_all(self.replicas, exchange(block, self.transport, self.h, self.group))

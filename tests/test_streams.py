@@ -1,0 +1,135 @@
+"""CPU: frame-sharded streams (streams.py).  (1) StreamReplica.replay - temporal forensic score, full/fast
+schedule, weighted sum, vote - against the oracle's stateful analyzer + tracker driven in the /analyze order;
+(2) world_size 2 and 3 over gloo: every rank ends with the verdict sequence of a single process, including the
+temporal forensic signal (gray(t-1) recomputed on the rank that owns frame t, mean differences exchanged)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import imgproc_ref as I
+from oracle.forensics_ref import ForensicsRef
+from oracle.tracker_ref import TrackerRef
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _frames(n, seed):
+    """256x256 frames with frame-to-frame differences that wander across the temporal thresholds"""
+    rs = np.random.RandomState(seed)
+    base = rs.randint(40, 220, (256, 256, 3)).astype(np.int16)
+    out = []
+    for t in range(n):
+        amp = (0, 1, 1, 0, 6, 0, 0, 12, 1, 0)[t % 10]
+        out.append(np.clip(base + rs.randint(-amp, amp + 1, base.shape), 0, 255).astype(np.uint8))
+        if t % 7 == 6:
+            base = np.roll(base, 3, axis=1)
+    return out
+
+
+def _record(S, stateless, frame, prev, stream, t, face_prob):
+    stateless.stats = {}
+    sc = [stateless.frequency(frame), stateless.noise(frame), stateless.ela(frame), stateless.edges(frame),
+          stateless.color(frame)]
+    md = -1.0
+    if prev is not None:
+        md = float(np.mean(np.abs(I.bgr2gray_u8(frame).astype(np.float32) - I.bgr2gray_u8(prev).astype(np.float32))))
+    return np.array([stream, t, face_prob, md, *sc, 0 if np.isnan(face_prob) else 1], np.float64)
+
+
+def test_replay_equals_oracle_server_flow(pkg):
+    S = pkg.streams
+    frames = _frames(16, 3)
+    rs = np.random.RandomState(9)
+    face = [np.nan if t % 3 else float(rs.rand()) for t in range(len(frames))]
+    ref_an, ref_tr, ref_count = ForensicsRef(), TrackerRef(detection_threshold=0.55), 0
+    rep = S.StreamReplica(detection_threshold=0.55)
+    stateless = ForensicsRef()
+    for t, f in enumerate(frames):
+        # oracle: backend_server.py:147-233 (forensics before the counter moves; vote on face prob else forensic)
+        res = ref_an.analyze(f) if ref_count % 3 == 0 else ref_an.analyze_fast(f)
+        ref_count += 1
+        want_vote = res['fake_probability'] if np.isnan(face[t]) else face[t]
+        ref_tr.update(want_vote)
+        got = rep.replay(_record(S, stateless, f, frames[t - 1] if t else None, 0, t, face[t]))
+        assert got['frame_forensic_probability'] == res['fake_probability'], t
+        assert got['fake_probability'] == want_vote
+        assert got['confidence_level'] == ref_tr.confidence_level()
+        assert rep.tracker.get_voting_stats() == ref_tr.voting_stats()
+    assert rep.analyzer_frames == ref_an.frame_count and len(rep.diffs) == len(ref_an.temporal_diffs)
+    with pytest.raises(ValueError):
+        rep.replay(_record(S, stateless, frames[0], None, 0, 99, np.nan))       # out of order is loud
+
+
+def _synthetic_records(n_streams, n_frames):
+    """what the GPU stage would produce: scores are multiples of 0.05, mean differences cross 0.3 / 0.8"""
+    rs = np.random.RandomState(77)
+    recs = {}
+    for s in range(n_streams):
+        for t in range(n_frames):
+            sc = rs.randint(0, 17, 5) * 0.05
+            md = -1.0 if t == 0 else float(rs.choice([0.0, 0.1, 0.5, 1.0, 4.0, 9.0]) * rs.rand())
+            p = np.nan if rs.rand() < 0.4 else float(rs.rand())
+            recs[(s, t)] = np.array([s, t, p, md, *sc, 0 if np.isnan(p) else 1], np.float64)
+    return recs
+
+
+def _worker(rank, world, port, n_streams, n_frames, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import rtdfd_amd
+
+    S = rtdfd_amd.streams
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    recs = _synthetic_records(n_streams, n_frames)
+    sh = S.ShardedStreams(None, n_streams, rank, world, transport="torch")
+    levels = []
+    waves = (n_frames + world - 1) // world
+    for w in range(waves):
+        t = sh.frame_of(w)
+        block = np.full((n_streams, S.RECORD_FLOATS), -1.0)
+        if t < n_frames:
+            for s in range(n_streams):
+                block[s] = recs[(s, t)]                    # this rank owns frame t of every stream
+        out = sh.finish_wave(block)
+        levels.append({s: [r['confidence_level'] for r in rows] for s, rows in out.items()})
+    q.put((rank, levels, [r.tracker.get_voting_stats() for r in sh.replicas],
+           [list(r.tracker.score_history) for r in sh.replicas], [list(r.diffs) for r in sh.replicas]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_streams_equal_single_process(pkg, world):
+    n_streams, n_frames = 3, 26
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_streams, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    S = pkg.streams
+    recs = _synthetic_records(n_streams, n_frames)
+    reps = [S.StreamReplica() for _ in range(n_streams)]
+    seq = {s: [reps[s].replay(recs[(s, t)])['confidence_level'] for t in range(n_frames)] for s in range(n_streams)}
+    for rank, levels, stats, hist, diffs in results:
+        flat = {s: [lv for wave in levels for lv in wave.get(s, [])] for s in range(n_streams)}
+        assert flat == seq, rank                                    # verdict sequence == single-process sequence
+        assert stats == [r.tracker.get_voting_stats() for r in reps]
+        assert hist == [list(r.tracker.score_history) for r in reps]          # bit-identical doubles
+        assert diffs == [list(r.diffs) for r in reps]
+    assert any(lv in ("FAKE", "REAL") for v in seq.values() for lv in v)

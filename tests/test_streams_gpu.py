@@ -1,0 +1,106 @@
+"""GPU: the frame-sharded stream driver (streams.ShardedStreams) on the device path.
+  * world 1: verdicts, probabilities and vote counts equal the stateful single-GPU /analyze flow
+    (DeepfakeDetector.analyze_request: dfd_analyze_frame with per-stream temporal state in the handle);
+  * two ranks emulated on the one GPU (each computes its own shard from frames t-1 and t; blocks concatenated the
+    way the all-gather returns them): every rank's sequence equals the world-1 sequence - in particular the
+    temporal forensic signal, whose gray(t-1) the owning rank recomputes;
+  * the RCCL transport through the C ABI (dfd_comm_* + dfd_vote_allgather) at world size 1."""
+import numpy as np
+import pytest
+
+import frames as F
+
+pytestmark = pytest.mark.gpu
+
+H, W = 480, 640
+
+
+def _stream(seed, n):
+    """slowly changing frames (temporal signal active), blank frames (no face -> forensic vote) mixed in"""
+    rs = np.random.RandomState(seed)
+    base = F.natural_like(H, W, seed=40 + seed).astype(np.int16)
+    out = []
+    for t in range(n):
+        if t % 5 == 4:
+            out.append(F.blank_frame(W, H))
+            continue
+        amp = (0, 1, 0, 4, 0, 9)[t % 6]
+        out.append(np.clip(base + rs.randint(-amp, amp + 1, base.shape), 0, 255).astype(np.uint8))
+    return out
+
+
+def _run_world(pkg, h, streams, world, transport="local"):
+    S = pkg.streams
+    n_streams, n_frames = len(streams), len(streams[0])
+    ranks = [S.ShardedStreams(h, n_streams, r, world, transport=transport if world == 1 else "local") for r in range(world)]
+    seq = [{s: [] for s in range(n_streams)} for _ in range(world)]
+    for wave in range((n_frames + world - 1) // world):
+        blocks = []
+        for sh in ranks:
+            t = sh.frame_of(wave)
+            block = np.full((n_streams, S.RECORD_FLOATS), -1.0)
+            if t < n_frames:
+                items = [(s, t, t > 0) for s in range(n_streams)]
+                batch = [streams[s][t] for s in range(n_streams)] + ([streams[s][t - 1] for s in range(n_streams)] if t > 0 else [])
+                arr = np.stack(batch)
+                fd = h.alloc(arr.nbytes).upload(arr)
+                block = sh.local_records(fd.ptr, H, W, items, conf_thr=0.5)
+                fd.free()
+            blocks.append(block)
+        gathered = np.concatenate(blocks)                      # rank-major, as ncclAllGather returns it
+        for r, sh in enumerate(ranks):
+            out = sh.finish_wave(blocks[0]) if world == 1 else S.replay_all(sh.replicas, gathered)
+            for s, rows in out.items():
+                seq[r][s] += rows
+    return ranks, seq
+
+
+def test_world1_equals_stateful_single_gpu_flow_and_two_ranks_equal_world1(pkg, b0_handle):
+    h = b0_handle
+    streams = [_stream(1, 14), _stream(2, 14)]
+    ranks1, seq1 = _run_world(pkg, h, streams, 1)
+    # the stateful per-frame API, one detector object per stream
+    for s, frames in enumerate(streams):
+        det = pkg.deepfake_detection.DeepfakeDetector(use_tta=False, num_tta_augmentations=1, detection_threshold=0.55, handle=h)
+        det.frame_analyzer.stream_id = 700 + s
+        h.forensics_reset(700 + s)
+        for t, f in enumerate(frames):
+            want = det.analyze_request(f)
+            got = seq1[0][s][t]
+            assert got['analysis_mode'] == want['analysis_mode'], (s, t)
+            assert got['frame_forensic_probability'] == want['frame_forensic_probability'], (s, t)
+            assert got['fake_probability'] == want['fake_probability'], (s, t)
+            assert got['confidence_level'] == want['confidence_level'], (s, t)
+        assert ranks1[0].replicas[s].tracker.get_voting_stats() == det.temporal_tracker.get_voting_stats()
+    modes = {r['analysis_mode'] for s in seq1[0].values() for r in s}
+    assert modes == {'face+frame', 'frame_only'}, "the stream exercises only one branch of the vote"
+    assert any(r['confidence_level'] in ('FAKE', 'REAL') for r in seq1[0][0])
+    # two ranks, frame t on rank t % 2
+    ranks2, seq2 = _run_world(pkg, h, streams, 2)
+    for r in range(2):
+        for s in range(len(streams)):
+            assert seq2[r][s] == seq1[0][s], (r, s)
+            assert list(ranks2[r].replicas[s].diffs) == list(ranks1[0].replicas[s].diffs)
+
+
+def test_rccl_transport_world1(pkg, b0_handle):
+    h = b0_handle
+    cid = h.comm_unique_id()
+    assert len(cid) == 128
+    h.comm_init(cid, 0, 1)
+    try:
+        assert h.comm_info() == (0, 1)
+        block = np.arange(30, dtype=np.float64).reshape(3, 10)
+        out = h.vote_allgather(block)
+        assert out.shape == (1, 3, 10) and np.array_equal(out[0], block)
+        streams = [_stream(5, 6)]
+        _, a = _run_world(pkg, h, streams, 1, transport="rccl")
+        _, b = _run_world(pkg, h, streams, 1, transport="local")
+        assert a == b
+        with pytest.raises(pkg._lib.DfdError):
+            h.comm_init(cid, 0, 1)                              # one communicator per handle
+    finally:
+        h.comm_destroy()
+    assert h.comm_info()[1] == 0
+    with pytest.raises(pkg._lib.DfdError):
+        h.vote_allgather(np.zeros((1, 10)))
