@@ -4,17 +4,22 @@
 
 namespace dfd {
 
+// activation storage: float, or bf16_t when the handle runs with "bf16_activations" (kernel_util.h)
+typedef __bf16 bf16_t;
+
 enum Act { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
 
 // stem: 3x3 stride-2 conv, NCHW (n,3,224,224) -> NHWC (n,112,112,32), folded BN + swish.
+template <typename XT>
 void launch_stem(const float* x_nchw, const float* w /*[3][3][3][32]*/, const float* b,
-                 float* y, int n, hipStream_t s);
+                 XT* y, int n, hipStream_t s);
 
 // stem + block-0 depthwise fused (the stem activation stays in LDS); stem_out may be null, or a buffer
 // [n][112][112][32] that receives a copy of the stem activation for parity taps.  The tile count (98) is
 // that of launch_depthwise for block 0.
+template <typename XT>
 void launch_stem_dw(const float* x_nchw, const float* ws, const float* bs, const float* Wd, const float* bd,
-                    float* Y, float* P, float* stem_out, int n, int* tiles, hipStream_t s);
+                    XT* Y, float* P, XT* stem_out, int n, int* tiles, hipStream_t s);
 
 // pointwise conv as GEMM: Y[m][o] = act( sum_k X[m][k]*gate[m/HW][k] * W[o][k] + b[o] ) + R[m][o]
 // gate / R may be null.  X rows have stride K, Y/R rows stride N.
@@ -52,23 +57,29 @@ void s6_table_set_tuning(S6Table* t, bool on);
 int s6_table_measured(const S6Table* t);           // shapes with a measured tile
 int s6_max_candidates();                           // upper bound of the candidate count over all shapes
 long long s6_chunk_rows(long long M, long long row_bytes, long long HW);
-bool launch_pointwise_split(S6Table* tab, const float* X, const unsigned short* W3, const float* bias, const float* gate,
-                            const float* R, float* Y, int M, int K, int N, int HW, int act, hipStream_t s);
-bool launch_conv_gemm_split(S6Table* tab, const float* X, const unsigned short* W3, const float* bias, const float* R,
-                            float* Y, int n_img, const ConvGeom& g, int Cout, int act, bool res_first, hipStream_t s);
+// XT = float: every fp32 activation is split into three bf16 terms in registers (planes must be 3);
+// XT = bf16_t: bf16 activation storage in and out, `planes` = 3 (fp32-exact weights) or 1 (bf16 weights).
+template <typename XT>
+bool launch_pointwise_split(S6Table* tab, const XT* X, const unsigned short* W3, const float* bias, const float* gate,
+                            const XT* R, XT* Y, int M, int K, int N, int HW, int act, int planes, hipStream_t s);
+template <typename XT>
+bool launch_conv_gemm_split(S6Table* tab, const XT* X, const unsigned short* W3, const float* bias, const XT* R,
+                            XT* Y, int n_img, const ConvGeom& g, int Cout, int act, bool res_first, int planes, hipStream_t s);
 
 // depthwise kxk conv (k in {3,5}, stride in {1,2}, TF-SAME pad) + folded BN + swish, and
 // per-tile channel sums for the squeeze-excite pool: P[n][tile][c].  Returns the tile count
 // through *tiles.  Only the 16 shape classes of EfficientNet-B0 at 224x224 are instantiated.
-bool launch_depthwise(const float* X, const float* W /*[k][k][C]*/, const float* bias, float* Y,
+template <typename XT>
+bool launch_depthwise(const XT* X, const float* W /*[k][k][C]*/, const float* bias, XT* Y,
                       float* P, int n, int H, int C, int k, int stride, int pad_lo,
                       int* tiles, hipStream_t s);
 int depthwise_tiles(int H, int C, int k, int stride);
 // MBConv front half in one kernel: 1x1 expand (+BN+swish) computed per LDS halo tile with MFMA, then the
 // depthwise conv as above.  Xin: block input [n][H][H][Cin]; We [C][Cin], be [C].  Returns false when no
 // instantiation covers the shape (callers then run launch_pointwise + launch_depthwise).
-bool launch_mbconv_front(const float* Xin, int Cin, const float* We, const float* be, const float* Wd,
-                         const float* bd, float* Y, float* P, int n, int H, int C, int k, int stride,
+template <typename XT>
+bool launch_mbconv_front(const XT* Xin, int Cin, const float* We, const float* be, const float* Wd,
+                         const float* bd, XT* Y, float* P, int n, int H, int C, int k, int stride,
                          int pad_lo, int* tiles, hipStream_t s);
 
 // squeeze-excite gate: mean over tiles*pixels -> FC(c_se)+swish -> FC(C)+sigmoid.
@@ -77,6 +88,8 @@ void launch_se(const float* P, int tiles, float inv_hw, const float* w1, const f
                hipStream_t s);
 
 // global average pool over hw pixels: [n][hw][C] -> [n][C]
-void launch_avgpool(const float* X, float* Y, int n, int hw, int C, hipStream_t s);
+template <typename XT>
+void launch_avgpool(const XT* X, float* Y, int n, int hw, int C, hipStream_t s);
+void launch_bf16_to_f32(const bf16_t* x, float* y, size_t n, hipStream_t s);
 
 }  // namespace dfd

@@ -45,10 +45,11 @@ extern "C" int dfd_debug_mb_trace(long long* out, int n) {
 // the 27 input taps are wave-broadcast loads and the 128-byte NHWC output row is one
 // coalesced store per 8 lanes.  TF-SAME for 224 -> 112 at k3 s2 pads one row/col at the
 // high side only (reference dependency efficientnet_pytorch Conv2dStaticSamePadding).
+template <typename XT>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x,
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ b,
-                                                   float* __restrict__ y, int n_img) {
+                                                   XT* __restrict__ y, int n_img) {
     __shared__ float ws[27 * 32];
     for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = w[i];
     __syncthreads();
@@ -77,14 +78,17 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x,
             }
         }
     }
-    stg4(y + (size_t)pix * 32 + 4 * cg, swish4(acc));
+    st4(y + (size_t)pix * 32 + 4 * cg, swish4(acc));
 }
 
-void launch_stem(const float* x, const float* w, const float* b, float* y, int n, hipStream_t s) {
+template <typename XT>
+void launch_stem(const float* x, const float* w, const float* b, XT* y, int n, hipStream_t s) {
     const long long threads = (long long)n * 112 * 112 * 8;
     const int grid = (int)((threads + 255) / 256);
-    hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(256), 0, s, x, w, b, y, n);
+    hipLaunchKernelGGL(stem_kernel<XT>, dim3(grid), dim3(256), 0, s, x, w, b, y, n);
 }
+template void launch_stem<float>(const float*, const float*, const float*, float*, int, hipStream_t);
+template void launch_stem<bf16_t>(const float*, const float*, const float*, bf16_t*, int, hipStream_t);
 
 // ------------------------------------------------------------------------ pointwise GEMM
 // D = A*B with v_mfma_f32_16x16x4_f32: A[i][k] on lane (i = l&15, k = l>>4), B[k][j] on lane
@@ -391,9 +395,9 @@ struct DwShape {
 // depthwise conv of the LDS tile + folded BN + swish + store + per-tile SE partial sums.
 // Ends with a barrier-protected write of P; callers that reuse tile/wl/red afterwards must
 // __syncthreads() first.
-template <int K, int S, int CB, int TH, int TW, int RP, bool SWZ = false>
+template <int K, int S, int CB, int TH, int TW, int RP, bool SWZ = false, typename XT = float>
 __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* red,
-                                           const v4f bv, float* __restrict__ Y,
+                                           const v4f bv, XT* __restrict__ Y,
                                            float* __restrict__ P, int n, int Ho, int C, int c0, int ty0,
                                            int tx0, int t, int tiles_sp) {
     constexpr int CG = CB / 4;
@@ -404,7 +408,7 @@ __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* 
     const int tid = threadIdx.x;
     const int cg = tid % CG, slot = tid / CG;
     v4f psum = (v4f){0.f, 0.f, 0.f, 0.f};
-    float* yb = Y + (size_t)n * Ho * Ho * C + c0 + 4 * cg;
+    XT* yb = Y + (size_t)n * Ho * Ho * C + c0 + 4 * cg;
     for (int strip = slot; strip < NSTRIP; strip += NSLOT) {
         const int oy = strip / SX, ox0 = (strip % SX) * RP;
         v4f acc[RP];
@@ -431,7 +435,7 @@ __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* 
             const int gx = tx0 + ox0 + p;
             if (gy < Ho && gx < Ho) {
                 const v4f v = swish4(acc[p]);
-                stg4(yb + ((size_t)gy * Ho + gx) * C, v);
+                st4(yb + ((size_t)gy * Ho + gx) * C, v);
                 psum += v;
             }
         }
@@ -453,11 +457,11 @@ __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* 
     }
 }
 
-template <int K, int S, int CB, int TH, int TW, int RP>
-__global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const float* __restrict__ X,
+template <int K, int S, int CB, int TH, int TW, int RP, typename XT>
+__global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const XT* __restrict__ X,
                                                  const float* __restrict__ Wt,
                                                  const float* __restrict__ bias,
-                                                 float* __restrict__ Y, float* __restrict__ P,
+                                                 XT* __restrict__ Y, float* __restrict__ P,
                                                  int H, int Ho, int C, int pad_lo, int tiles_x,
                                                  int tiles_sp) {
     using Sh = DwShape<K, S, CB, TH, TW>;
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const float*
     for (int i = tid; i < K * K * CG; i += 256)
         wl[i] = ldg4(Wt + (size_t)(i / CG) * C + c0 + 4 * (i % CG));
     const int iy0 = ty0 * S - pad_lo, ix0 = tx0 * S - pad_lo;
-    const float* xb = X + (size_t)n * H * H * C + c0;
+    const XT* xb = X + (size_t)n * H * H * C + c0;
     // Halo tile -> LDS.  Every load is unconditional (address clamped into the image, VALUE masked) and all of a
     // thread's loads are issued before the first LDS store: a load under `if (inside)` makes hipcc branch and
     // wait per element - the s_memtime trace of the fused stem kernel showed 57 % of a block's time in ten
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const float*
         const int cg = i % CG, pix = i / CG;
         const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
         const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
-        stg[k] = ldg4(xb + ((size_t)(inside ? iy : 0) * H + (inside ? ix : 0)) * C + 4 * cg);
+        stg[k] = ld4(xb + ((size_t)(inside ? iy : 0) * H + (inside ? ix : 0)) * C + 4 * cg);
         stg_ok[k] = inside;
     }
 #pragma unroll
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const float*
         tile[i] = stg_ok[k] ? stg[k] : (v4f){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
-    dw_compute<K, S, CB, TH, TW, RP>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
+    dw_compute<K, S, CB, TH, TW, RP, false, XT>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
 }
 
 // MBConv front half in ONE kernel (blocks 1-5): X is the block INPUT [n][H][H][Cin]; for every
@@ -508,13 +512,13 @@ __global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const float*
 // HBM.  A block walks NSUB channel chunks of CB channels over the same spatial tile: the input
 // fragments of all its pixels are loaded ONCE, up front (one batch of loads in flight), and reused
 // for every chunk.  Price: the halo's expand FLOPs are recomputed (1.1-1.65x).
-template <int K, int S, int CB, int TH, int TW, int RP, int KC, int NSUB>
-__global__ __launch_bounds__(256, 3) void mbconv_kernel(const float* __restrict__ X,
+template <int K, int S, int CB, int TH, int TW, int RP, int KC, int NSUB, typename XT>
+__global__ __launch_bounds__(256, 3) void mbconv_kernel(const XT* __restrict__ X,
                                                      const float* __restrict__ We,
                                                      const float* __restrict__ be,
                                                      const float* __restrict__ Wt,
                                                      const float* __restrict__ bias,
-                                                     float* __restrict__ Y, float* __restrict__ P,
+                                                     XT* __restrict__ Y, float* __restrict__ P,
                                                      int H, int Ho, int C, int Cin, int pad_lo,
                                                      int tiles_x, int tiles_sp) {
     using Sh = DwShape<K, S, CB, TH, TW>;
@@ -535,18 +539,18 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const float* __restrict_
     MB_TP(0);
 
     // B operand for all of this wave's pixel tiles: lane (pixel j, k-quad q); loaded once
-    const float* xb = X + (size_t)n * H * H * Cin;
+    const XT* xb = X + (size_t)n * H * H * Cin;
     v4f xf[NIT][KC];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int p = (wave + 4 * it) * 16 + j;
         const int iy = iy0 + p / IW, ix = ix0 + p % IW;
         const bool inside = p < NP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
-        const float* px = xb + ((size_t)(inside ? iy : 0) * H + (inside ? ix : 0)) * Cin;
+        const XT* px = xb + ((size_t)(inside ? iy : 0) * H + (inside ? ix : 0)) * Cin;
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
             const int k = kk * 16 + 4 * q;
-            const v4f v = ldg4(px + (k < Cin ? k : 0));          // unconditional load, masked value
+            const v4f v = ld4(px + (k < Cin ? k : 0));           // unconditional load, masked value
             xf[it][kk] = (inside && k < Cin) ? v : (v4f){0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const float* __restrict_
         MB_TP(4);
         __syncthreads();
         MB_TP(5);
-        dw_compute<K, S, CB, TH, TW, RP, (CG >= 8)>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
+        dw_compute<K, S, CB, TH, TW, RP, (CG >= 8), XT>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
         MB_TP(6);
     }
 #ifdef MB_TRACE
@@ -627,10 +631,11 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const float* __restrict_
 // conv (+BN+swish) of the 10x18 halo tile is computed from it straight into the depthwise LDS tile
 // (zero outside the 112x112 stem output = the depthwise padding), then dw_compute runs as usual.
 // The 112x112x32 stem activation (1.6 MB per crop, read back with a 1.4x halo) never touches HBM.
+template <typename XT>
 __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict__ x, const float* __restrict__ ws_g,
                                                       const float* __restrict__ bs, const float* __restrict__ Wt,
-                                                      const float* __restrict__ bias, float* __restrict__ Y,
-                                                      float* __restrict__ P, float* __restrict__ stem_out,
+                                                      const float* __restrict__ bias, XT* __restrict__ Y,
+                                                      float* __restrict__ P, XT* __restrict__ stem_out,
                                                       int tiles_x, int tiles_sp) {
     constexpr int K = 3, S = 1, CB = 32, TH = 8, TW = 16, RP = 4, CG = 8;
     constexpr int IH = TH + 2, IW = TW + 2;                 // 10 x 18 stem pixels
@@ -719,45 +724,48 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
             tile[p * CG + cg] = v;
             // optional copy of the stem activation (parity taps only): interior pixels of this tile
             if (stem_out && inside && py >= 1 && py <= TH && px >= 1 && px <= TW)
-                stg4(stem_out + (((size_t)n * 112 + sy) * 112 + sx) * 32 + 4 * cg, v);
+                st4(stem_out + (((size_t)n * 112 + sy) * 112 + sx) * 32 + 4 * cg, v);
         }
     }
     MB_TP(4);
     __syncthreads();
     MB_TP(5);
-    dw_compute<K, S, CB, TH, TW, RP>(tile, wl, red, bv, Y, P, n, 112, 32, 0, ty0, tx0, t, tiles_sp);
+    dw_compute<K, S, CB, TH, TW, RP, false, XT>(tile, wl, red, bv, Y, P, n, 112, 32, 0, ty0, tx0, t, tiles_sp);
     MB_TP(6);
 #ifdef MB_TRACE
     if (blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
 #endif
 }
 
-void launch_stem_dw(const float* x, const float* ws, const float* bs, const float* Wd, const float* bd, float* Y,
-                    float* P, float* stem_out, int n, int* tiles, hipStream_t s) {
+template <typename XT>
+void launch_stem_dw(const float* x, const float* ws, const float* bs, const float* Wd, const float* bd, XT* Y,
+                    float* P, XT* stem_out, int n, int* tiles, hipStream_t s) {
     const int tx = 112 / 16, ty = 112 / 8;
     *tiles = tx * ty;
-    hipLaunchKernelGGL(stem_dw_kernel, dim3(tx * ty, n), dim3(256), 0, s, x, ws, bs, Wd, bd, Y, P, stem_out, tx, tx * ty);
+    hipLaunchKernelGGL(stem_dw_kernel<XT>, dim3(tx * ty, n), dim3(256), 0, s, x, ws, bs, Wd, bd, Y, P, stem_out, tx, tx * ty);
 }
+template void launch_stem_dw<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int*, hipStream_t);
+template void launch_stem_dw<bf16_t>(const float*, const float*, const float*, const float*, const float*, bf16_t*, float*, bf16_t*, int, int*, hipStream_t);
 
-template <int K, int S, int CB, int TH, int TW, int RP>
-static void dw_launch(const float* X, const float* W, const float* b, float* Y, float* P, int n,
+template <int K, int S, int CB, int TH, int TW, int RP, typename XT>
+static void dw_launch(const XT* X, const float* W, const float* b, XT* Y, float* P, int n,
                       int H, int C, int pad_lo, int* tiles, hipStream_t s) {
     const int Ho = (H + S - 1) / S;
     const int tx = (Ho + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
     const int tiles_sp = tx * ty;
     *tiles = tiles_sp;
-    hipLaunchKernelGGL((dw_kernel<K, S, CB, TH, TW, RP>), dim3(tiles_sp * (C / CB), n), dim3(256), 0,
+    hipLaunchKernelGGL((dw_kernel<K, S, CB, TH, TW, RP, XT>), dim3(tiles_sp * (C / CB), n), dim3(256), 0,
                        s, X, W, b, Y, P, H, Ho, C, pad_lo, tx, tiles_sp);
 }
 
-template <int K, int S, int CB, int TH, int TW, int RP, int KC, int NSUB>
-static void mb_launch(const float* X, int Cin, const float* We, const float* be, const float* W, const float* b,
-                      float* Y, float* P, int n, int H, int C, int pad_lo, int* tiles, hipStream_t s) {
+template <int K, int S, int CB, int TH, int TW, int RP, int KC, int NSUB, typename XT>
+static void mb_launch(const XT* X, int Cin, const float* We, const float* be, const float* W, const float* b,
+                      XT* Y, float* P, int n, int H, int C, int pad_lo, int* tiles, hipStream_t s) {
     const int Ho = (H + S - 1) / S;
     const int tx = (Ho + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
     const int tiles_sp = tx * ty;
     *tiles = tiles_sp;
-    hipLaunchKernelGGL((mbconv_kernel<K, S, CB, TH, TW, RP, KC, NSUB>), dim3(tiles_sp * (C / (CB * NSUB)), n),
+    hipLaunchKernelGGL((mbconv_kernel<K, S, CB, TH, TW, RP, KC, NSUB, XT>), dim3(tiles_sp * (C / (CB * NSUB)), n),
                        dim3(256), 0, s, X, We, be, W, b, Y, P, H, Ho, C, Cin, pad_lo, tx, tiles_sp);
 }
 
@@ -776,17 +784,20 @@ static void mb_launch(const float* X, int Cin, const float* We, const float* be,
     OP(5, 1, 7, 1152, 32, 7, 7, 1)    /* blocks 12-14 */  \
     OP(3, 1, 7, 1152, 32, 7, 7, 1)    /* block 15     */
 
-bool launch_depthwise(const float* X, const float* W, const float* bias, float* Y, float* P, int n,
+template <typename XT>
+bool launch_depthwise(const XT* X, const float* W, const float* bias, XT* Y, float* P, int n,
                       int H, int C, int k, int stride, int pad_lo, int* tiles, hipStream_t s) {
 #define DFD_DW_DISPATCH(KK, SS, HH, CC, CB, TH, TW, RP)                                \
     if (k == KK && stride == SS && H == HH && C == CC) {                               \
-        dw_launch<KK, SS, CB, TH, TW, RP>(X, W, bias, Y, P, n, H, C, pad_lo, tiles, s); \
+        dw_launch<KK, SS, CB, TH, TW, RP, XT>(X, W, bias, Y, P, n, H, C, pad_lo, tiles, s); \
         return true;                                                                   \
     }
     DFD_DW_TABLE(DFD_DW_DISPATCH)
 #undef DFD_DW_DISPATCH
     return false;
 }
+template bool launch_depthwise<float>(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int*, hipStream_t);
+template bool launch_depthwise<bf16_t>(const bf16_t*, const float*, const float*, bf16_t*, float*, int, int, int, int, int, int, int*, hipStream_t);
 
 // expand (1x1 + BN + swish) fused into the depthwise kernel; only the five large-spatial MBConv
 // blocks (1..5) are instantiated: there the expanded tensor dominates HBM traffic and C_in <= 48.
@@ -798,18 +809,21 @@ bool launch_depthwise(const float* X, const float* W, const float* bias, float* 
     OP(5, 1, 28, 240, 40, 16, 14, 14, 2, 3, 1)      \
     OP(3, 2, 28, 240, 40, 16, 7, 14, 2, 3, 1)
 
-bool launch_mbconv_front(const float* Xin, int Cin, const float* We, const float* be, const float* Wd,
-                         const float* bd, float* Y, float* P, int n, int H, int C, int k, int stride,
+template <typename XT>
+bool launch_mbconv_front(const XT* Xin, int Cin, const float* We, const float* be, const float* Wd,
+                         const float* bd, XT* Y, float* P, int n, int H, int C, int k, int stride,
                          int pad_lo, int* tiles, hipStream_t s) {
 #define DFD_MB_DISPATCH(KK, SS, HH, CC, CI, CB, TH, TW, RP, KC, NSUB)                                     \
     if (k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                    \
-        mb_launch<KK, SS, CB, TH, TW, RP, KC, NSUB>(Xin, Cin, We, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s); \
+        mb_launch<KK, SS, CB, TH, TW, RP, KC, NSUB, XT>(Xin, Cin, We, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s); \
         return true;                                                                                     \
     }
     DFD_MB_TABLE(DFD_MB_DISPATCH)
 #undef DFD_MB_DISPATCH
     return false;
 }
+template bool launch_mbconv_front<float>(const float*, int, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int*, hipStream_t);
+template bool launch_mbconv_front<bf16_t>(const bf16_t*, int, const float*, const float*, const float*, const float*, bf16_t*, float*, int, int, int, int, int, int, int*, hipStream_t);
 
 int depthwise_tiles(int H, int C, int k, int stride) {
     const int Ho = (H + stride - 1) / stride;
@@ -916,7 +930,8 @@ void launch_se(const float* P, int tiles, float inv_hw, const float* w1, const f
 // lane = (row part p = lane >> 3, channel quad lane & 7): part p sums rows p, p + 8, ...; the eight partial sums
 // are folded with a butterfly over the lane bits 3-5 (a fixed order).  One thread per channel quad walking all 49
 // rows left the chip with 1.25 waves per SIMD and read the 64 MB head activation at 2 TB/s.
-__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ X,
+template <typename XT>
+__global__ __launch_bounds__(256) void avgpool_kernel(const XT* __restrict__ X,
                                                       float* __restrict__ Y, int n_img, int hw, int C) {
     const int c4 = C / 4;
     const long long gid = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;          // wave index
@@ -925,9 +940,9 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
     const bool live = item < (long long)n_img * c4;
     const long long it = live ? item : 0;
     const int n = (int)(it / c4), c = (int)(it % c4) * 4;
-    const float* p = X + (size_t)n * hw * C + c;
+    const XT* p = X + (size_t)n * hw * C + c;
     v4f s = (v4f){0.f, 0.f, 0.f, 0.f};
-    for (int i = part; i < hw; i += 8) s += ldg4(p + (size_t)i * C);
+    for (int i = part; i < hw; i += 8) s += ld4(p + (size_t)i * C);
 #pragma unroll
     for (int off = 8; off < 64; off <<= 1) {
         s.x += __shfl_xor(s.x, off);
@@ -938,9 +953,21 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ 
     if (live && part == 0) stg4(Y + (size_t)n * C + c, s * (1.0f / (float)hw));
 }
 
-void launch_avgpool(const float* X, float* Y, int n, int hw, int C, hipStream_t s) {
+template <typename XT>
+void launch_avgpool(const XT* X, float* Y, int n, int hw, int C, hipStream_t s) {
     const long long waves = ((long long)n * (C / 4) + 7) / 8;
-    hipLaunchKernelGGL(avgpool_kernel, dim3((int)((waves * 64 + 255) / 256)), dim3(256), 0, s, X, Y, n, hw, C);
+    hipLaunchKernelGGL(avgpool_kernel<XT>, dim3((int)((waves * 64 + 255) / 256)), dim3(256), 0, s, X, Y, n, hw, C);
+}
+template void launch_avgpool<float>(const float*, float*, int, int, int, hipStream_t);
+template void launch_avgpool<bf16_t>(const bf16_t*, float*, int, int, int, hipStream_t);
+
+// bf16 activation buffer -> fp32 (parity taps only)
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = (float)x[i];
+}
+void launch_bf16_to_f32(const bf16_t* x, float* y, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, y, n);
 }
 
 }  // namespace dfd

@@ -151,17 +151,27 @@ const unsigned short* split_weights(dfd_handle* h, const float* W, int N, int K)
     return static_cast<unsigned short*>(p);
 }
 
-int pointwise(dfd_handle* h, const float* X, const float* W, const float* bias, const float* gate, const float* R,
-              float* Y, int M, int K, int N, int HW, int act) {
-    if (h->split_gemm && N >= 16 && split_gemm_supports(K, N)) {       // never on M: batch-invariant results
+// 1x1 conv.  XT = float: split path when enabled and the shape allows, else the fp32 MFMA kernel.
+// XT = bf16_t ("bf16_activations"): always the split GEMM's bf16-activation instances.
+template <typename XT>
+int pointwise_t(dfd_handle* h, const XT* X, const float* W, const float* bias, const float* gate, const XT* R,
+                XT* Y, int M, int K, int N, int HW, int act) {
+    constexpr bool BF = sizeof(XT) == 2;
+    if ((BF || h->split_gemm) && N >= 16 && split_gemm_supports(K, N)) {       // never on M: batch-invariant results
         const unsigned short* w3 = split_weights(h, W, N, K);
         if (!w3) return DFD_ERR_HIP;
-        if (!launch_pointwise_split(h->gemm, X, w3, bias, gate, R, Y, M, K, N, HW, act, h->stream))
+        if (!launch_pointwise_split<XT>(h->gemm, X, w3, bias, gate, R, Y, M, K, N, HW, act, BF ? h->bf16_planes : 3, h->stream))
             return fail(h, DFD_ERR_CAPACITY, "1x1 conv M=%d K=%d: one image exceeds the 2^31-byte addressing of the split GEMM", M, K);
     } else {
-        launch_pointwise(X, W, bias, gate, R, Y, M, K, N, HW, act, h->stream);
+        if constexpr (BF) return fail(h, DFD_ERR_STATE, "1x1 conv K=%d N=%d has no bf16-activation kernel", K, N);
+        else launch_pointwise(X, W, bias, gate, R, Y, M, K, N, HW, act, h->stream);
     }
     return DFD_OK;
+}
+
+int pointwise(dfd_handle* h, const float* X, const float* W, const float* bias, const float* gate, const float* R,
+              float* Y, int M, int K, int N, int HW, int act) {
+    return pointwise_t<float>(h, X, W, bias, gate, R, Y, M, K, N, HW, act);
 }
 
 namespace {
@@ -179,12 +189,22 @@ struct Marks {
     }
 };
 
-// copy a device buffer out if it is the requested tap
-int tap_out(dfd_handle* h, B0Tap* tap, const std::string& name, const float* dev, size_t count) {
+// copy a device buffer out if it is the requested tap (bf16 activations are widened to fp32 on the device first)
+template <typename XT>
+int tap_out(dfd_handle* h, B0Tap* tap, const std::string& name, const XT* dev, size_t count) {
     if (!tap || !tap->name || tap->found || name != tap->name) return DFD_OK;
     tap->found = true;
     if (count > tap->capacity) return fail(h, DFD_ERR_ARG, "tap '%s' needs %zu floats, capacity %zu", tap->name, count, tap->capacity);
-    DFD_HIP_TRY(h, hipMemcpyAsync(tap->out, dev, count * 4, hipMemcpyDeviceToHost, h->stream));
+    const float* src = nullptr;
+    if constexpr (sizeof(XT) == 2) {
+        const int rc = ensure(h, &h->tap_buf, count * 4);
+        if (rc) return rc;
+        launch_bf16_to_f32(dev, static_cast<float*>(h->tap_buf.p), count, h->stream);
+        src = static_cast<const float*>(h->tap_buf.p);
+    } else {
+        src = dev;
+    }
+    DFD_HIP_TRY(h, hipMemcpyAsync(tap->out, src, count * 4, hipMemcpyDeviceToHost, h->stream));
     DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
     tap->count = count;
     return DFD_OK;
@@ -199,39 +219,46 @@ const char* layer_name(int blk, const char* what) {
 
 }  // namespace
 
-int b0_forward(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* tap, B0Prof* prof) {
+template <typename XT>
+static int b0_forward_t(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* tap, B0Prof* prof) {
     if (n <= 0) return fail(h, DFD_ERR_ARG, "batch must be positive");
     if (n > h->max_batch) return fail(h, DFD_ERR_CAPACITY, "batch %d exceeds handle capacity %d", n, h->max_batch);
     const B0Plan& P = h->b0;
     hipStream_t s = h->stream;
     Marks mk{prof, s};
     int rc;
+    // the activation workspace is sized for fp32; bf16 storage uses the front half of each buffer
+    XT* const io0 = reinterpret_cast<XT*>(h->io0);
+    XT* const io1 = reinterpret_cast<XT*>(h->io1);
+    XT* const expbuf = reinterpret_cast<XT*>(h->expbuf);
+    XT* const dwbuf = reinterpret_cast<XT*>(h->dwbuf);
+    XT* const headbuf = reinterpret_cast<XT*>(h->headbuf);
     mk.mark("start");
     // block 0 has no expand conv: its depthwise input IS the stem output, so the two fuse (option "fuse_stem")
     const bool stem_fused = h->fuse_stem && P.blocks[0].expand == 1;
     int stem_tiles = 0;
     if (stem_fused) {
         const bool want_stem = tap && tap->name && std::string(tap->name) == "stem";
-        launch_stem_dw(x, P.stem_w, P.stem_b, P.blocks[0].dw_w, P.blocks[0].dw_b, h->dwbuf, h->pool,
-                       want_stem ? h->io0 : nullptr, n, &stem_tiles, s);
+        launch_stem_dw<XT>(x, P.stem_w, P.stem_b, P.blocks[0].dw_w, P.blocks[0].dw_b, dwbuf, h->pool,
+                           want_stem ? io0 : (XT*)nullptr, n, &stem_tiles, s);
         mk.mark("b0.dw");                               // stem + depthwise of block 0 in one launch
     } else {
-        launch_stem(x, P.stem_w, P.stem_b, h->io0, n, s);
+        launch_stem<XT>(x, P.stem_w, P.stem_b, io0, n, s);
         mk.mark("stem");
     }
-    if ((rc = tap_out(h, tap, "stem", h->io0, (size_t)n * 112 * 112 * 32))) return rc;
-    float* cur = h->io0;
-    float* nxt = h->io1;
+    if ((rc = tap_out(h, tap, "stem", io0, (size_t)n * 112 * 112 * 32))) return rc;
+    XT* cur = io0;
+    XT* nxt = io1;
     int bi = 0;
     for (const B0Block& b : P.blocks) {
         const int m_in = n * b.h_in * b.h_in, m_out = n * b.h_out * b.h_out;
         const std::string q = "b" + std::to_string(bi);
-        const float* dw_in = cur;
+        const XT* dw_in = cur;
         int tiles = 0;
         bool fused = false;
         if (b.expand != 1 && h->fuse_expand &&
-            launch_mbconv_front(cur, b.c_in, b.exp_w, b.exp_b, b.dw_w, b.dw_b, h->dwbuf, h->pool, n, b.h_in, b.c_exp,
-                                b.kernel, b.stride, b.pad_lo, &tiles, s)) {
+            launch_mbconv_front<XT>(cur, b.c_in, b.exp_w, b.exp_b, b.dw_w, b.dw_b, dwbuf, h->pool, n, b.h_in, b.c_exp,
+                                    b.kernel, b.stride, b.pad_lo, &tiles, s)) {
             fused = true;
             mk.mark(layer_name(bi, "dw"));            // expand + depthwise in one launch
             if (tap && tap->name && q + ".exp" == tap->name)
@@ -239,39 +266,39 @@ int b0_forward(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* t
                                               "(dfd_set_option(h, \"fuse_expand\", 0))", tap->name);
         }
         if (!fused && b.expand != 1) {
-            if ((rc = pointwise(h, cur, b.exp_w, b.exp_b, nullptr, nullptr, h->expbuf, m_in, b.c_in, b.c_exp,
-                                b.h_in * b.h_in, ACT_SWISH))) return rc;
+            if ((rc = pointwise_t<XT>(h, cur, b.exp_w, b.exp_b, nullptr, nullptr, expbuf, m_in, b.c_in, b.c_exp,
+                                      b.h_in * b.h_in, ACT_SWISH))) return rc;
             mk.mark(layer_name(bi, "exp"));
-            if ((rc = tap_out(h, tap, q + ".exp", h->expbuf, (size_t)m_in * b.c_exp))) return rc;
-            dw_in = h->expbuf;
+            if ((rc = tap_out(h, tap, q + ".exp", expbuf, (size_t)m_in * b.c_exp))) return rc;
+            dw_in = expbuf;
         }
         if (bi == 0 && stem_fused) {
             tiles = stem_tiles;
         } else if (!fused) {
-            if (!launch_depthwise(dw_in, b.dw_w, b.dw_b, h->dwbuf, h->pool, n, b.h_in, b.c_exp, b.kernel,
-                                  b.stride, b.pad_lo, &tiles, s))
+            if (!launch_depthwise<XT>(dw_in, b.dw_w, b.dw_b, dwbuf, h->pool, n, b.h_in, b.c_exp, b.kernel,
+                                      b.stride, b.pad_lo, &tiles, s))
                 return fail(h, DFD_ERR_STATE, "no depthwise kernel for block %d", bi);
             mk.mark(layer_name(bi, "dw"));
         }
-        if ((rc = tap_out(h, tap, q + ".dw", h->dwbuf, (size_t)m_out * b.c_exp))) return rc;
+        if ((rc = tap_out(h, tap, q + ".dw", dwbuf, (size_t)m_out * b.c_exp))) return rc;
         launch_se(h->pool, tiles, 1.0f / (float)(b.h_out * b.h_out), b.se_w1, b.se_b1, b.se_w2, b.se_b2,
                   h->gate, n, b.c_exp, b.c_se, s);
         mk.mark(layer_name(bi, "se"));
         if ((rc = tap_out(h, tap, q + ".gate", h->gate, (size_t)n * b.c_exp))) return rc;
-        if ((rc = pointwise(h, h->dwbuf, b.proj_w, b.proj_b, h->gate, b.skip ? cur : nullptr, nxt, m_out,
-                            b.c_exp, b.c_out, b.h_out * b.h_out, ACT_NONE))) return rc;
+        if ((rc = pointwise_t<XT>(h, dwbuf, b.proj_w, b.proj_b, h->gate, b.skip ? cur : (const XT*)nullptr, nxt, m_out,
+                                  b.c_exp, b.c_out, b.h_out * b.h_out, ACT_NONE))) return rc;
         mk.mark(layer_name(bi, "proj"));
         if ((rc = tap_out(h, tap, q + ".out", nxt, (size_t)m_out * b.c_out))) return rc;
-        float* t = cur; cur = nxt; nxt = t;
+        XT* t = cur; cur = nxt; nxt = t;
         ++bi;
     }
     const B0Block& last = P.blocks.back();
     const int hw = last.h_out * last.h_out;
-    if ((rc = pointwise(h, cur, P.head_w, P.head_b, nullptr, nullptr, h->headbuf, n * hw, last.c_out, 1280, hw,
-                        ACT_SWISH))) return rc;
+    if ((rc = pointwise_t<XT>(h, cur, P.head_w, P.head_b, nullptr, nullptr, headbuf, n * hw, last.c_out, 1280, hw,
+                              ACT_SWISH))) return rc;
     mk.mark("head");
-    if ((rc = tap_out(h, tap, "head", h->headbuf, (size_t)n * hw * 1280))) return rc;
-    launch_avgpool(h->headbuf, h->feat, n, hw, 1280, s);
+    if ((rc = tap_out(h, tap, "head", headbuf, (size_t)n * hw * 1280))) return rc;
+    launch_avgpool<XT>(headbuf, h->feat, n, hw, 1280, s);
     mk.mark("avgpool");
     if ((rc = tap_out(h, tap, "feat", h->feat, (size_t)n * 1280))) return rc;
     if (!logits_dev) return DFD_OK;   // extract_features stops here
@@ -282,6 +309,14 @@ int b0_forward(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* t
     if ((rc = tap_out(h, tap, "logit", logits_dev, (size_t)n))) return rc;
     DFD_HIP_TRY(h, hipGetLastError());
     return DFD_OK;
+}
+
+// fp32 activation storage, or - dfd_set_option(h, "bf16_activations", 1) - bf16 storage of every activation tensor
+// that reaches HBM (depthwise / block / expand / head outputs) with fp32 arithmetic and accumulation throughout:
+// BASELINE.json configs[3].  Squeeze-excite pools, gates, the pooled feature vector and the MLP head stay fp32.
+int b0_forward(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* tap, B0Prof* prof) {
+    return h->act_bf16 ? b0_forward_t<bf16_t>(h, x, n, logits_dev, tap, prof)
+                       : b0_forward_t<float>(h, x, n, logits_dev, tap, prof);
 }
 
 }  // namespace dfd

@@ -38,6 +38,7 @@ int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, in
     if (const char* e = getenv("DFD_FUSE_EXPAND")) h->fuse_expand = atoi(e) != 0;
     if (const char* e = getenv("DFD_FUSE_STEM")) h->fuse_stem = atoi(e) != 0;
     if (const char* e = getenv("DFD_SPLIT_GEMM")) h->split_gemm = atoi(e) != 0;
+    if (const char* e = getenv("DFD_BF16_ACTIVATIONS")) h->act_bf16 = atoi(e) != 0;
     h->gemm = s6_table_create();
     if (!h->gemm) return fail(h, DFD_ERR_ARG, "out of host memory");
     DFD_HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -136,6 +137,12 @@ int dfd_set_option(dfd_handle* h, const char* name, int value) {
     if (strcmp(name, "fuse_stem") == 0) { h->fuse_stem = value != 0; return DFD_OK; }
     if (strcmp(name, "split_gemm") == 0) { h->split_gemm = value != 0; return DFD_OK; }
     if (strcmp(name, "mtcnn") == 0) { h->use_mtcnn = value != 0; return DFD_OK; }
+    if (strcmp(name, "bf16_activations") == 0) { h->act_bf16 = value != 0; return DFD_OK; }
+    if (strcmp(name, "bf16_weight_planes") == 0) {
+        if (value != 1 && value != 3) return fail(h, DFD_ERR_ARG, "bf16_weight_planes must be 1 or 3");
+        h->bf16_planes = value;
+        return DFD_OK;
+    }
     if (strcmp(name, "gemm_tile") == 0) { s6_table_set_force(h->gemm, value); return DFD_OK; }
     if (strcmp(name, "profile_stride") == 0) { h->prof_stride = value > 0 ? value : 1; return DFD_OK; }
     return fail(h, DFD_ERR_ARG, "unknown option '%s'", name);

@@ -103,6 +103,9 @@ struct dfd_handle {
     bool fuse_stem = true;               // stem conv computed inside block 0's depthwise kernel
     bool fuse_expand = true;             // MBConv blocks 1-5: expand conv computed inside the depthwise kernel
     bool split_gemm = true;              // 1x1 / k x k convs on the bf16x3-split MFMA path (gemm_split.hip)
+    bool act_bf16 = false;               // classifier activations stored as bf16 (fp32 arithmetic): configs[3]
+    int bf16_planes = 3;                 // weight planes the bf16-activation GEMMs use: 3 = fp32-exact weights, 1 = bf16 weights
+    dfd::DevBuf tap_buf;                 // fp32 staging for taps of bf16 buffers
     std::map<const float*, unsigned short*> wsplit;   // fp32 weight tensor -> its three-plane bf16 split
     dfd::S6Table* gemm = nullptr;        // split-GEMM tile per shape (measured by dfd_warmup, heuristic otherwise)
     dfd::B0Prof prof;                    // layer events between profile_begin/end

@@ -19,4 +19,27 @@ __device__ __forceinline__ v4f swish4(v4f v) {
 __device__ __forceinline__ v4f ldg4(const float* p) { return *reinterpret_cast<const v4f*>(p); }
 __device__ __forceinline__ void stg4(float* p, v4f v) { *reinterpret_cast<v4f*>(p) = v; }
 
+// Activation storage type XT = float (fp32 path) or bf16_t ("bf16_activations": every activation tensor that
+// reaches HBM is bf16, all arithmetic and every accumulator stays fp32).  ld4 / st4 move 4 consecutive channels
+// of one pixel: 16 bytes of fp32 or 8 bytes of bf16 (bf16 -> fp32 is a shift, fp32 -> bf16 rounds to nearest
+// even: v_cvt_pk_bf16_f32).
+typedef __bf16 bf16_t;
+typedef __bf16 bf4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v4f ld4(const float* p) { return ldg4(p); }
+__device__ __forceinline__ void st4(float* p, v4f v) { stg4(p, v); }
+__device__ __forceinline__ v4f bf4_to_f4(u2v u) {
+    v4f r;
+    r.x = __builtin_bit_cast(float, u.x << 16);
+    r.y = __builtin_bit_cast(float, u.x & 0xffff0000u);
+    r.z = __builtin_bit_cast(float, u.y << 16);
+    r.w = __builtin_bit_cast(float, u.y & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ v4f ld4(const bf16_t* p) { return bf4_to_f4(*reinterpret_cast<const u2v*>(p)); }
+__device__ __forceinline__ void st4(bf16_t* p, v4f v) {
+    const bf4v b = __builtin_convertvector(v, bf4v);
+    *reinterpret_cast<u2v*>(p) = __builtin_bit_cast(u2v, b);
+}
+
 }  // namespace dfd

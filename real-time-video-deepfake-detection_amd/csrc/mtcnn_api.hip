@@ -83,7 +83,7 @@ int gemm_conv_prelu(dfd_handle* h, const MtGemmConv& c, const float* x, float* y
     const int K = c.k * c.k * c.ci;
     const unsigned short* w3 = split_weights(h, c.w, c.co, K);
     if (!w3) return DFD_ERR_HIP;
-    if (!launch_conv_gemm_split(h->gemm, x, w3, c.b, nullptr, y, n, g, c.co, ACT_NONE, false, h->stream))
+    if (!launch_conv_gemm_split<float>(h->gemm, x, w3, c.b, nullptr, y, n, g, c.co, ACT_NONE, false, 3, h->stream))
         return fail(h, DFD_ERR_STATE, "mtcnn: conv shape not supported by the GEMM kernel");
     launch_mt_prelu(y, c.a, (long long)n * g.Ho * g.Wo * c.co, c.co, h->stream);
     return DFD_OK;

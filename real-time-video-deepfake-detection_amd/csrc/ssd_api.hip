@@ -90,7 +90,7 @@ static bool conv_gemm(dfd_handle* h, const float* X, const float* W, const float
     const int K = g.ksize * g.ksize * g.Cin;
     if (h->split_gemm && g.Cin % 32 == 0 && split_gemm_supports(K, Cout)) {
         const unsigned short* w3 = split_weights(h, W, Cout, K);
-        if (w3 && launch_conv_gemm_split(h->gemm, X, w3, bias, R, Y, n, g, Cout, act, res_first, h->stream)) return true;
+        if (w3 && launch_conv_gemm_split<float>(h->gemm, X, w3, bias, R, Y, n, g, Cout, act, res_first, 3, h->stream)) return true;
     }
     return launch_conv_gemm(X, W, bias, R, Y, n, g, Cout, act, res_first, h->stream);
 }
