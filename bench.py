@@ -101,13 +101,23 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, w
     for forensic in (False, True, False, True):
         run(forensic, warmup)
     world = 1 if dist is None else dist.get_world_size()
-    for key, forensic in (("detect_classify", False), ("detect_classify_forensics", True)):
+    for key, forensic, bf16 in (("detect_classify", False, 0), ("detect_classify_forensics", True, 0),
+                                ("detect_classify_forensics_bf16", True, 1)):
+        h.set_option("bf16_activations", bf16)
+        if bf16:
+            h.warmup(h.max_batch, 0)                         # the bf16 GEMM instances have their own tile table entries
+            run(forensic, warmup)
         dts = sorted(run(forensic, steps) for _ in range(3))
         dt = dts[1]                                          # median of three timed repeats
         res[key] = {"frames_per_s": round(frames_per_step * steps * world / dt, 1),
                     "crops_per_s": round(frames_per_step * K * steps * world / dt, 1),
                     "ms_per_frame": round(dt / (frames_per_step * steps) * 1e3, 3),
                     "repeats_frames_per_s": [round(frames_per_step * steps * world / d, 1) for d in dts]}
+    h.set_option("bf16_activations", 0)
+    res["detect_classify_forensics_bf16"]["arithmetic"] = (
+        "configs[3]: classifier activations stored as bf16 (fp32 accumulate, fp32-exact weights); detector, CLAHE and "
+        "forensic kernels unchanged (integer / fp32: box indices must stay bit-exact); vote-equality gate: "
+        "tests/test_b0_bf16_gpu.py::test_config4_gate_votes_equal_fp32_oracle_on_200_frames")
     fd.free()
     if rank == 0 and world == 1:
         res["detect_classify_mtcnn"] = e2e_mtcnn(frames[:8], boxes[:8], K)
@@ -141,6 +151,41 @@ def e2e_mtcnn(frames, boxes, K):
     out["workload"] = f"{n} x 1080p frames, {K} forced boxes each; seeded random-init cascade"
     fd.free()
     h.close()
+    return out
+
+
+def bf16_classify(h, xd, yd, batch, steps, logits_fp32, dw_bytes_bf16):
+    """configs[3]'s classifier half as its own object: the batch-256 step with bf16 activation storage, its own
+    depthwise roofline on 12.55 MB per crop, and the logit error against the fp32 run of the same crops."""
+    out = {}
+    for key, planes in (("weights_fp32_exact", 3), ("weights_bf16", 1)):
+        h.set_option("bf16_activations", 1)
+        h.set_option("bf16_weight_planes", planes)
+        h.warmup(batch, 0)
+        for _ in range(3):
+            h.classify_device(xd.ptr, batch, yd.ptr)
+        h.sync()
+        h.set_option("profile_stride", 4)
+        h.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            h.classify_device(xd.ptr, batch, yd.ptr)
+        h.sync()
+        dt = time.perf_counter() - t0
+        seen, layers = h.profile_end()
+        y = yd.download((batch, 1))
+        dw_ms = sum(ms for name, ms in layers if name.endswith(".dw")) / max(seen, 1)
+        ach = dw_bytes_bf16 / (dw_ms * 1e-3) / 1e9 if dw_ms > 0 else 0.0
+        out[key] = {"crops_per_s": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+                    "max_abs_logit_err_vs_fp32_run": float(np.abs(y - logits_fp32).max()),
+                    "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": dw_bytes_bf16,
+                                 "ms_per_step": round(dw_ms, 4)},
+                    "ms_by_kind": {k: round(sum(ms for n_, ms in layers if n_.split(".")[-1] == k) / max(seen, 1), 3)
+                                   for k in ("dw", "se", "proj", "exp", "head", "avgpool", "mlp")}}
+    h.set_option("bf16_activations", 0)
+    h.set_option("bf16_weight_planes", 3)
+    out["dtype"] = "bf16 activation storage, f32 accumulate (depthwise bytes 12.55 MB per crop)"
     return out
 
 
@@ -361,6 +406,8 @@ def main():
         "kernel_ms_per_step": round(all_ms, 3),
         "parity": {"rows": 8, "max_abs_logit_err_vs_oracle": parity, "tol": 1e-3},
     }
+    if rank == 0 and world == 1:
+        out["bf16"] = bf16_classify(h, xd, yd, args.batch, min(args.steps, 20), logits, b0_arch.depthwise_bytes_per_image(2) * args.batch)
     if not args.no_e2e:
         out["e2e"] = e2e_frames(h, rank, dist, local_rank)
     if not args.no_streams:

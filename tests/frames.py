@@ -50,3 +50,14 @@ def natural_like(h=720, w=1280, seed=3):
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
     base = np.stack([128 + 80 * np.sin(xx / 97.0 + c) * np.cos(yy / 61.0 - c) for c in (0.0, 1.0, 2.0)], -1)
     return np.clip(base + rs.randn(h, w, 3) * 6.0, 0, 255).astype(np.uint8)
+
+
+def varied_frame(i, h=480, w=640):
+    """frames whose contrast, brightness, texture scale and noise level change from frame to frame, so that the
+    classifier's probabilities spread over a wide range (the bf16 vote gate needs a threshold inside the spread)"""
+    rs = np.random.RandomState(900 + i)
+    amp, off, sig = rs.uniform(15, 110), rs.uniform(70, 185), rs.uniform(1, 28)
+    fx, fy = rs.uniform(40, 160), rs.uniform(30, 120)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    base = np.stack([off + amp * np.sin(xx / fx + c) * np.cos(yy / fy - c) for c in (0.0, 1.0, 2.0)], -1)
+    return np.clip(base + rs.randn(h, w, 3) * sig, 0, 255).astype(np.uint8)
