@@ -299,6 +299,13 @@ def main():
     ap.add_argument("--no-streams", action="store_true", help="skip the frame-sharded 8-stream extra (configs[4])")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): libraries that print there (RCCL's version banner at communicator
+    # creation) are sent to stderr for the whole run; the JSON goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    json_out = os.fdopen(json_fd, "w")
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -417,7 +424,7 @@ def main():
         def bail():
             if rank == 0:
                 out["config5"] = {"error": "timed out after 240 s (collective set-up?)"}
-                print(json.dumps(out), flush=True)
+                print(json.dumps(out), file=json_out, flush=True)
             os._exit(0)
 
         guard = threading.Timer(240.0, bail)
@@ -442,7 +449,7 @@ def main():
             print("by kind:", {k: round(v, 3) for k, v in agg.items()}, file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     xd.free()
     yd.free()
     h.close()

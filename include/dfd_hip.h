@@ -79,6 +79,12 @@ int dfd_gemm_tile_count(void);
  * environment skips the measurement. */
 int dfd_warmup(dfd_handle* h, int n_crops, int n_frames);
 
+/* The handle's measured tiles as text (one "M K N mode kind wm wn mt nt ks" line per shape) and back: a later
+ * process - a profiled run, a server restart - imports them and dfd_warmup then measures only what is missing.
+ * text_out == NULL queries the length.  Entries that name an instance this build cannot launch are dropped. */
+int dfd_tiles_export(dfd_handle* h, char* text_out, size_t capacity, size_t* length);
+int dfd_tiles_import(dfd_handle* h, const char* text, size_t length, int* accepted);
+
 /* Host-only arithmetic of the split GEMM's 32-bit addressing guard: how many of `rows` rows of `row_bytes`
  * bytes one kernel launch may cover (a multiple of rows_per_image, whole `rows` when everything fits below
  * 2^31 bytes, -1 when a single image does not).  Batches above that are issued as several launches, so every

@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfd_hip.so")
+LIB_PATH = os.environ.get("DFD_LIB_PATH") or os.path.join(_HERE, "libdfd_hip.so")   # DFD_LIB_PATH: diagnostic builds only
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -36,6 +36,8 @@ SIGNATURES = {
     "dfd_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "dfd_gemm_tile_count": (C.c_int, []),
     "dfd_warmup": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "dfd_tiles_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "dfd_tiles_import": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "dfd_gemm_chunk_rows": (C.c_longlong, [C.c_longlong, C.c_longlong, C.c_longlong]),
     "dfd_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "dfd_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -180,8 +182,32 @@ class Handle:
         self._check(self._lib.dfd_set_option(self._p, name.encode(), int(value)))
 
     def warmup(self, n_crops: int = 0, n_frames: int = 0):
-        """Measure the split-GEMM tiles for these batch sizes (synchronises; serving calls never do)."""
+        """Measure the split-GEMM tiles for these batch sizes (synchronises; serving calls never do).
+        With DFD_TILE_CACHE=<file> in the environment the measured tiles are loaded from / saved to that file, so
+        that e.g. a run under rocprofv3 launches no tuning candidates."""
+        cache = os.environ.get("DFD_TILE_CACHE")
+        if cache and os.path.exists(cache):
+            self.tiles_import(open(cache).read())
         self._check(self._lib.dfd_warmup(self._p, int(n_crops), int(n_frames)))
+        if cache:
+            try:
+                with open(cache, "w") as f:
+                    f.write(self.tiles_export())
+            except OSError:
+                pass
+
+    def tiles_export(self) -> str:
+        n = C.c_size_t()
+        self._check(self._lib.dfd_tiles_export(self._p, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value + 1)
+        self._check(self._lib.dfd_tiles_export(self._p, buf, n.value, C.byref(n)))
+        return buf.raw[: n.value].decode()
+
+    def tiles_import(self, text: str) -> int:
+        acc = C.c_int()
+        b = text.encode()
+        self._check(self._lib.dfd_tiles_import(self._p, b, len(b), C.byref(acc)))
+        return acc.value
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <string>
+
 namespace dfd {
 
 // activation storage: float, or bf16_t when the handle runs with "bf16_activations" (kernel_util.h)
@@ -57,6 +59,8 @@ void s6_table_set_tuning(S6Table* t, bool on);
 int s6_table_measured(const S6Table* t);           // shapes with a measured tile
 int s6_max_candidates();                           // upper bound of the candidate count over all shapes
 long long s6_chunk_rows(long long M, long long row_bytes, long long HW);
+std::string s6_table_export(const S6Table* t);                       // measured entries as text
+int s6_table_import(S6Table* t, const char* text, size_t len);       // -> entries accepted
 // XT = float: every fp32 activation is split into three bf16 terms in registers (planes must be 3);
 // XT = bf16_t: bf16 activation storage in and out, `planes` = 3 (fp32-exact weights) or 1 (bf16 weights).
 template <typename XT>
@@ -74,13 +78,15 @@ bool launch_depthwise(const XT* X, const float* W /*[k][k][C]*/, const float* bi
                       float* P, int n, int H, int C, int k, int stride, int pad_lo,
                       int* tiles, hipStream_t s);
 int depthwise_tiles(int H, int C, int k, int stride);
-// MBConv front half in one kernel: 1x1 expand (+BN+swish) computed per LDS halo tile with MFMA, then the
-// depthwise conv as above.  Xin: block input [n][H][H][Cin]; We [C][Cin], be [C].  Returns false when no
-// instantiation covers the shape (callers then run launch_pointwise + launch_depthwise).
+// MBConv front half in one kernel: 1x1 expand (+BN+swish) computed per LDS halo tile on the bf16 MFMA with
+// split-precision operands (We3 = the three bf16 planes of We [C][Cin] from launch_split_weights, `plane`
+// elements apart, rows Kp long), then the depthwise conv as above.  Xin: block input [n][H][H][Cin]; be [C].
+// Returns false when no instantiation covers the shape (callers then run the GEMM + launch_depthwise).
 template <typename XT>
-bool launch_mbconv_front(const XT* Xin, int Cin, const float* We, const float* be, const float* Wd,
-                         const float* bd, XT* Y, float* P, int n, int H, int C, int k, int stride,
+bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int plane, int Kp, const float* Wef, const float* be,
+                         const float* Wd, const float* bd, XT* Y, float* P, int n, int H, int C, int k, int stride,
                          int pad_lo, int* tiles, hipStream_t s);
+int mbconv_tiles(int H, int C, int k, int stride, int Cin);      // largest pool-tile count of the fused variants, -1: none
 
 // squeeze-excite gate: mean over tiles*pixels -> FC(c_se)+swish -> FC(C)+sigmoid.
 void launch_se(const float* P, int tiles, float inv_hw, const float* w1, const float* b1,

@@ -25,13 +25,16 @@ namespace dfd {
 __device__ long long g_mb_trace[256];
 #define MB_TP(id)                                                                                             \
     do {                                                                                                      \
-        if (H == MB_TRACE_H && blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0 && mtp < 250) {           \
+        if (H == MB_TRACE_H && S == MB_TRACE_S && blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0 && mtp < 250) { \
             g_mb_trace[mtp++] = (long long)(id);                                                              \
             g_mb_trace[mtp++] = (long long)__builtin_amdgcn_s_memtime();                                      \
         }                                                                                                     \
     } while (0)
 #ifndef MB_TRACE_H
 #define MB_TRACE_H 56
+#endif
+#ifndef MB_TRACE_S
+#define MB_TRACE_S 1
 #endif
 extern "C" int dfd_debug_mb_trace(long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mb_trace), (size_t)n * sizeof(long long), 0, hipMemcpyDeviceToHost);
@@ -395,7 +398,7 @@ struct DwShape {
 // depthwise conv of the LDS tile + folded BN + swish + store + per-tile SE partial sums.
 // Ends with a barrier-protected write of P; callers that reuse tile/wl/red afterwards must
 // __syncthreads() first.
-template <int K, int S, int CB, int TH, int TW, int RP, bool SWZ = false, typename XT = float>
+template <int K, int S, int CB, int TH, int TW, int RP, bool SWZ = false, typename XT = float, int ABL = 0>
 __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* red,
                                            const v4f bv, XT* __restrict__ Y,
                                            float* __restrict__ P, int n, int Ho, int C, int c0, int ty0,
@@ -404,56 +407,70 @@ __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* 
     constexpr int IW = (TW - 1) * S + K;
     constexpr int SX = TW / RP, NSTRIP = TH * SX, NSLOT = 256 / CG;
     constexpr int NIN = (RP - 1) * S + K;
-    static_assert(TW % RP == 0 && (CG & (CG - 1)) == 0 && CG <= 64, "tile shape");
+    constexpr bool POW2 = (CG & (CG - 1)) == 0;
+    static_assert(TW % RP == 0 && CG <= 64, "tile shape");
     const int tid = threadIdx.x;
     const int cg = tid % CG, slot = tid / CG;
     v4f psum = (v4f){0.f, 0.f, 0.f, 0.f};
     XT* yb = Y + (size_t)n * Ho * Ho * C + c0 + 4 * cg;
-    for (int strip = slot; strip < NSTRIP; strip += NSLOT) {
-        const int oy = strip / SX, ox0 = (strip % SX) * RP;
-        v4f acc[RP];
+    if (POW2 || slot < NSLOT) {                          // CG not a power of two: the last 256 % CG threads idle
+        for (int strip = slot; strip < NSTRIP; strip += NSLOT) {
+            const int oy = strip / SX, ox0 = (strip % SX) * RP;
+            v4f acc[RP];
 #pragma unroll
-        for (int p = 0; p < RP; ++p) acc[p] = bv;
-        auto tap_row = [&](int ky) {
-            const int p0 = (oy * S + ky) * IW + ox0 * S;
-            v4f in[NIN];
+            for (int p = 0; p < RP; ++p) acc[p] = bv;
+            auto tap_row = [&](int ky) {
+                const int p0 = (oy * S + ky) * IW + ox0 * S;
+                v4f in[NIN];
 #pragma unroll
-            for (int i = 0; i < NIN; ++i) in[i] = tile[tile_unit<CG, SWZ>(p0 + i, cg)];
+                for (int i = 0; i < NIN; ++i) in[i] = tile[tile_unit<CG, SWZ>(p0 + i, cg)];
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const v4f w = wl[(ky * K + kx) * CG + cg];
+                for (int kx = 0; kx < K; ++kx) {
+                    const v4f w = wl[(ky * K + kx) * CG + cg];
 #pragma unroll
-                for (int p = 0; p < RP; ++p) acc[p] += in[p * S + kx] * w;
-            }
-        };
-        // rolled: one kernel row (K weight vectors) live at a time instead of all K * K
+                    for (int p = 0; p < RP; ++p) acc[p] += in[p * S + kx] * w;
+                }
+            };
+            // rolled: one kernel row (K weight vectors) live at a time instead of all K * K
 #pragma unroll 1
-        for (int ky = 0; ky < K; ++ky) tap_row(ky);
-        const int gy = ty0 + oy;
+            for (int ky = 0; ky < K; ++ky) tap_row(ky);
+            const int gy = ty0 + oy;
 #pragma unroll
-        for (int p = 0; p < RP; ++p) {
-            const int gx = tx0 + ox0 + p;
-            if (gy < Ho && gx < Ho) {
-                const v4f v = swish4(acc[p]);
-                st4(yb + ((size_t)gy * Ho + gx) * C, v);
-                psum += v;
+            for (int p = 0; p < RP; ++p) {
+                const int gx = tx0 + ox0 + p;
+                if (gy < Ho && gx < Ho) {
+                    const v4f v = ABL == 4 ? acc[p] : swish4(acc[p]);
+                    if (ABL != 5) st4(yb + ((size_t)gy * Ho + gx) * C, v);
+                    psum += v;
+                }
             }
         }
     }
-    // squeeze-excite pool: lanes whose ids differ by a multiple of CG hold the same channels
+    if constexpr (POW2) {
+        // squeeze-excite pool: lanes whose ids differ by a multiple of CG hold the same channels
 #pragma unroll
-    for (int off = CG; off < 64; off <<= 1) {
-        psum.x += __shfl_xor(psum.x, off);
-        psum.y += __shfl_xor(psum.y, off);
-        psum.z += __shfl_xor(psum.z, off);
-        psum.w += __shfl_xor(psum.w, off);
-    }
-    const int lane = tid & 63, wave = tid >> 6;
-    if (lane < CG) red[wave * CG + lane] = psum;
-    __syncthreads();
-    if (tid < CG) {
-        const v4f v = (red[tid] + red[CG + tid]) + (red[2 * CG + tid] + red[3 * CG + tid]);
-        stg4(P + ((size_t)n * tiles_sp + t) * C + c0 + 4 * tid, v);
+        for (int off = CG; off < 64; off <<= 1) {
+            psum.x += __shfl_xor(psum.x, off);
+            psum.y += __shfl_xor(psum.y, off);
+            psum.z += __shfl_xor(psum.z, off);
+            psum.w += __shfl_xor(psum.w, off);
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane < CG) red[wave * CG + lane] = psum;
+        __syncthreads();
+        if (tid < CG) {
+            const v4f v = (red[tid] + red[CG + tid]) + (red[2 * CG + tid] + red[3 * CG + tid]);
+            stg4(P + ((size_t)n * tiles_sp + t) * C + c0 + 4 * tid, v);
+        }
+    } else {
+        // any CG: every (slot, channel quad) partial through LDS, folded in slot order (a fixed order)
+        if (slot < NSLOT) red[slot * CG + cg] = psum;
+        __syncthreads();
+        if (tid < CG) {
+            v4f v = red[tid];
+            for (int sl = 1; sl < NSLOT; ++sl) v += red[sl * CG + tid];
+            stg4(P + ((size_t)n * tiles_sp + t) * C + c0 + 4 * tid, v);
+        }
     }
 }
 
@@ -622,7 +639,179 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const XT* __restrict__ X
         MB_TP(6);
     }
 #ifdef MB_TRACE
-    if (H == MB_TRACE_H && blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
+    if (H == MB_TRACE_H && S == MB_TRACE_S && blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
+#endif
+}
+
+// ---- MBConv front half, second generation (blocks 1-5) ---------------------------------------------------
+// What the first version spent its time on (s_memtime trace + ISA): per 16-pixel tile ONE dependent chain of
+// up to 12 v_mfma_f32_16x16x4_f32 (32-cycle issue, 40-cycle dependent latency: s_nops between them), then the
+// swish epilogue, then the next tile - nothing overlapped, under exec-masked branches per tile; and the
+// halo's expand FLOPs were recomputed up to 1.65x because tiles had to stay small (X fragments of ALL tiles in
+// registers for the chunk loop).  Here:
+//   * the 1x1 expand runs on v_mfma_f32_16x16x32_bf16 with split-precision operands exactly as gemm_split: the
+//     weights are the handle's three bf16 planes (split_weights), an fp32 activation is split in registers into
+//     three bf16 terms (six products, fp32-exact), a bf16 activation is the operand as loaded (three products);
+//     16 instead of 32 cycles per MFMA and K = 32 per instruction: 96-192 instead of 128-384 cycles per tile;
+//   * a block owns ONE channel chunk of CB = 16 * NTB channels (any multiple of 16: C = 144 / 240 take 48 / 80)
+//     and keeps NTB independent accumulators per pixel tile in flight;
+//   * the pixel-tile loop is branch-free (clamped addresses, masked values) and rolled, with the next tile's
+//     activations requested before the current tile's MFMAs: registers stay bounded for any tile size, so tiles
+//     grow until LDS says stop and the halo recompute shrinks;
+//   * dw_compute takes any CG (pool partials through LDS when CG is not a power of two).
+template <int K, int S, int CB, int TH, int TW, int RP, int NK, typename XT, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void mbconv2_kernel(const XT* __restrict__ X,
+                                                      const unsigned short* __restrict__ We3, int plane, int Kp,
+                                                      const float* __restrict__ Wef,
+                                                      const float* __restrict__ be,
+                                                      const float* __restrict__ Wt,
+                                                      const float* __restrict__ bias,
+                                                      XT* __restrict__ Y, float* __restrict__ P,
+                                                      int H, int Ho, int C, int Cin, int pad_lo,
+                                                      int tiles_x, int tiles_sp) {
+    using Sh = DwShape<K, S, CB, TH, TW>;
+    constexpr int CG = Sh::CG, IH = Sh::IH, IW = Sh::IW;
+    constexpr int NTB = CB / 16;                        // 16-channel MFMA row tiles of the chunk
+    constexpr int NPX = IH * IW, NMT = (NPX + 15) / 16, NIT = (NMT + 3) / 4;
+    constexpr int ESZ = (int)sizeof(XT);
+    // fp32 activations: the expand runs on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, KC = ceil(Cin / 16) steps of
+    // four MFMAs, lane = k-quad q).  These kernels are VALU-bound (SQ_ACTIVE_INST_VALU 80-90 % of the launch) and
+    // the matrix pipe is ~20 % busy: splitting every activation into three bf16 terms costs ~45 VALU instructions
+    // per 8 values - on the bottleneck - to save time on a unit that is idle anyway.  bf16 activations are the
+    // bf16 MFMA's operand as loaded (three products against the three weight planes).
+    constexpr int KC = ESZ == 4 ? (NK * 32 + 15) / 16 : NK;            // loads per pixel tile (16 B each per lane)
+    constexpr bool SWZ = (CG & (CG - 1)) == 0 && CG >= 8;
+    constexpr int NSLOT = 256 / CG;
+    static_assert(CB % 16 == 0, "channel chunk = whole MFMA row tiles");
+    __shared__ v4f tile[IH * IW * CG];
+    __shared__ v4f wl[K * K * CG];
+    __shared__ v4f red[(CG & (CG - 1)) == 0 ? 4 * CG : NSLOT * CG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+    const int n = blockIdx.y;
+    const int t = blockIdx.x % tiles_sp, chunk = blockIdx.x / tiles_sp;
+    const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW, c0 = chunk * CB;
+    const int iy0 = ty0 * S - pad_lo, ix0 = tx0 * S - pad_lo;
+#ifdef MB_TRACE
+    int mtp = 0;
+#endif
+    MB_TP(0);
+
+    // activations of pixel tile `mt` for this lane: pixel p = mt * 16 + j, K-step ks: the 8 channels ks*32 + 8q ..
+    // (channels >= Cin: the address falls back to channel 0 - the weight planes are zero there)
+    const XT* xb = X + (size_t)n * H * H * Cin;
+    struct XTile { v4f raw[KC]; };
+    auto load_tile = [&](int mt, XTile& xt) {
+        int p = mt * 16 + j;
+        p = p < NPX ? p : NPX - 1;
+        const int iy = iy0 + p / IW, ix = ix0 + p % IW;
+        const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
+        const XT* px = xb + ((size_t)(inside ? iy : 0) * H + (inside ? ix : 0)) * Cin;
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+            if constexpr (ESZ == 4) {
+                const int k = kk * 16 + 4 * q;
+                const v4f v = ldg4(reinterpret_cast<const float*>(px) + (k < Cin ? k : 0));
+                xt.raw[kk] = k < Cin ? v : (v4f){0.f, 0.f, 0.f, 0.f};
+            } else {
+                const int k = kk * 32 + 8 * q;
+                xt.raw[kk] = *reinterpret_cast<const v4f*>(px + (k < Cin ? k : 0));          // 8 bf16
+            }
+        }
+    };
+    // Activation tiles are requested RD tiles ahead (register ring, the tile loop is unrolled by RD): with one tile
+    // ahead every iteration ended in an exposed L2 round trip - the ablation runs put the expand phase of block 2
+    // at 155 us of a 232 us launch with MFMAs and swish together accounting for 44 of them.
+    constexpr int RD = NIT < (64 / (4 * KC)) ? NIT : (64 / (4 * KC));
+    XTile ring[RD];
+#pragma unroll
+    for (int d = 0; d < RD; ++d) load_tile(wave + 4 * d < NMT ? wave + 4 * d : NMT - 1, ring[d]);
+
+    // the chunk's expand rows as MFMA A operands (lane: channel row j, k-octet q), its folded-BN biases, the
+    // depthwise taps and bias: all requested together with the first activation tile
+    constexpr int WREG = ESZ == 4 ? KC : NK * 3;             // 16-byte weight registers per 16-channel tile
+    v4f wfr[NTB][WREG];
+    v4f bex[NTB];
+    const unsigned short* wrow = We3 + (size_t)(c0 + j) * Kp + 8 * q;
+#pragma unroll
+    for (int nt = 0; nt < NTB; ++nt) {
+        bex[nt] = ldg4(be + c0 + nt * 16 + 4 * q);
+        if constexpr (ESZ == 4) {
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                const int k = kk * 16 + 4 * q;
+                const v4f v = ldg4(Wef + (size_t)(c0 + nt * 16 + j) * Cin + (k < Cin ? k : 0));
+                wfr[nt][kk] = k < Cin ? v : (v4f){0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    wfr[nt][ks * 3 + pl] = *reinterpret_cast<const v4f*>(wrow + (size_t)pl * plane + (size_t)nt * 16 * Kp + ks * 32);
+        }
+    }
+    const v4f bv = ldg4(bias + c0 + 4 * (tid % CG));
+    for (int i = tid; i < K * K * CG; i += 256) wl[i] = ldg4(Wt + (size_t)(i / CG) * C + c0 + 4 * (i % CG));
+    MB_TP(1);
+
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += RD) {
+#pragma unroll
+      for (int d = 0; d < RD; ++d) {
+        const int it = it0 + d;
+        const int mt = wave + 4 * it;
+        const XTile xa = ring[d];
+        {   // tile it + RD into the slot just read (past the end: re-requests the last tile, never used)
+            const int mn = mt + 4 * RD;
+            load_tile(mn < NMT ? mn : NMT - 1, ring[d]);
+        }
+        v4f acc[NTB];
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        // the NTB accumulators interleaved (independent chains)
+        if constexpr (ABL == 1) {
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt) acc[nt] = xa.raw[0] + wfr[nt][0];
+        } else if constexpr (ESZ == 4) {
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int nt = 0; nt < NTB; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[nt][kk][e], xa.raw[kk][e], acc[nt], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl)                      // smallest weight terms first
+#pragma unroll
+                    for (int nt = 0; nt < NTB; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, wfr[nt][ks * 3 + pl]),
+                                                                          __builtin_bit_cast(bf8, xa.raw[ks]), acc[nt], 0, 0, 0);
+        }
+        const int p = mt * 16 + j;
+        const int pc = p < NPX ? p : NPX - 1;
+        const int iy = iy0 + pc / IW, ix = ix0 + pc % IW;
+        const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
+        if (mt < NMT && p < NPX) {
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt)
+                tile[tile_unit<CG, SWZ>(p, nt * 4 + q)] = inside ? (ABL == 2 ? acc[nt] + bex[nt] : swish4(acc[nt] + bex[nt])) : (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    MB_TP(4);
+    __syncthreads();
+    MB_TP(5);
+    if constexpr (ABL == 3) {
+        if (tid < CG) stg4(P + ((size_t)n * tiles_sp + t) * C + c0 + 4 * tid, tile[tid] + bv);
+    } else {
+        dw_compute<K, S, CB, TH, TW, RP, SWZ, XT, ABL>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
+    }
+    MB_TP(6);
+#ifdef MB_TRACE
+    if (H == MB_TRACE_H && S == MB_TRACE_S && blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
 #endif
 }
 
@@ -801,29 +990,121 @@ template bool launch_depthwise<bf16_t>(const bf16_t*, const float*, const float*
 
 // expand (1x1 + BN + swish) fused into the depthwise kernel; only the five large-spatial MBConv
 // blocks (1..5) are instantiated: there the expanded tensor dominates HBM traffic and C_in <= 48.
+// (k, stride, H, C, Cin) -> <K,S,CB,TH,TW,RP, NK = ceil(Cin/32)>; several variants per block, the first is the
+// default, DFD_MB_VARIANT_<H>_<stride>=i selects another (kernel experiments; the tile counts follow).
+#define DFD_MB2_TABLE(OP)                                  \
+    OP(0, 3, 2, 112, 96, 16, 32, 8, 8, 2, 1)               \
+    OP(1, 3, 2, 112, 96, 16, 16, 8, 8, 2, 1)               \
+    OP(0, 3, 1, 56, 144, 24, 16, 14, 28, 7, 1)             \
+    OP(1, 3, 1, 56, 144, 24, 16, 14, 28, 2, 1)             \
+    OP(0, 5, 2, 56, 144, 24, 16, 7, 14, 7, 1)              \
+    OP(1, 5, 2, 56, 144, 24, 16, 7, 14, 2, 1)              \
+    OP(0, 5, 1, 28, 240, 40, 16, 28, 28, 7, 2)             \
+    OP(1, 5, 1, 28, 240, 40, 16, 14, 28, 4, 2)             \
+    OP(0, 3, 2, 28, 240, 40, 16, 7, 14, 2, 2)              \
+    OP(1, 3, 2, 28, 240, 40, 16, 7, 14, 7, 2)
+
+// first-generation instances still used with fp32 activations where they measure faster (blocks 1, 3, 5:
+// 248 / 183 / 85 us against 329 / 185 / 89 us of the second generation at batch 256; blocks 2 and 4 run the second
+// generation: 214 / 148 us against 263 / 164 us).  With bf16 activations the second generation wins everywhere
+// (229 / 128 / 124 / 99 / 53 us against 263 / 179 / 152 / 151 / 62 us).
 // (k, stride, H, C, Cin) -> <K,S,CB,TH,TW,RP, KC = ceil(Cin/16), NSUB = channel chunks per block>
-#define DFD_MB_TABLE(OP)                            \
+#define DFD_MB1_TABLE(OP)                           \
     OP(3, 2, 112, 96, 16, 32, 8, 8, 2, 1, 3)        \
-    OP(3, 1, 56, 144, 24, 16, 8, 14, 2, 2, 3)       \
     OP(5, 2, 56, 144, 24, 16, 7, 14, 2, 2, 3)       \
-    OP(5, 1, 28, 240, 40, 16, 14, 14, 2, 3, 1)      \
     OP(3, 2, 28, 240, 40, 16, 7, 14, 2, 3, 1)
 
+// ablation builds of the default tiles of blocks 2 and 4 (variant 20 + ABL): where does the time go?
+//   1 no MFMAs, 2 no swish on the expanded tile, 3 no depthwise phase, 4 no swish after the depthwise conv, 5 no stores
+#define DFD_MB2_ABL(OP) OP(1) OP(2) OP(3) OP(4) OP(5)
+
+// DFD_MB_VARIANT_<H>_<stride>=i: kernel experiments (profiles/mb_variants.py); -1 = first generation where built
+static int mb_variant(int H, int stride) {
+    char name[48];
+    snprintf(name, sizeof name, "DFD_MB_VARIANT_%d_%d", H, stride);
+    const char* e = getenv(name);
+    return e ? atoi(e) : -2;
+}
+
+template <int K, int S, int CB, int TH, int TW, int RP, int NK, typename XT>
+static void mb2_launch(const XT* X, int Cin, const unsigned short* We3, int plane, int Kp, const float* Wef, const float* be,
+                       const float* W, const float* b, XT* Y, float* P, int n, int H, int C, int pad_lo, int* tiles, hipStream_t s) {
+    const int Ho = (H + S - 1) / S;
+    const int tx = (Ho + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
+    const int tiles_sp = tx * ty;
+    *tiles = tiles_sp;
+    hipLaunchKernelGGL((mbconv2_kernel<K, S, CB, TH, TW, RP, NK, XT>), dim3(tiles_sp * (C / CB), n), dim3(256), 0, s, X, We3,
+                       plane, Kp, Wef, be, W, b, Y, P, H, Ho, C, Cin, pad_lo, tx, tiles_sp);
+}
+
 template <typename XT>
-bool launch_mbconv_front(const XT* Xin, int Cin, const float* We, const float* be, const float* Wd,
-                         const float* bd, XT* Y, float* P, int n, int H, int C, int k, int stride,
+bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int plane, int Kp, const float* Wef, const float* be,
+                         const float* Wd, const float* bd, XT* Y, float* P, int n, int H, int C, int k, int stride,
                          int pad_lo, int* tiles, hipStream_t s) {
-#define DFD_MB_DISPATCH(KK, SS, HH, CC, CI, CB, TH, TW, RP, KC, NSUB)                                     \
-    if (k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                    \
-        mb_launch<KK, SS, CB, TH, TW, RP, KC, NSUB, XT>(Xin, Cin, We, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s); \
-        return true;                                                                                     \
+    int var = mb_variant(H, stride);
+    if (var == -2) var = (sizeof(XT) == 4 && stride == 2) ? -1 : 0;          // default: see DFD_MB1_TABLE
+    if constexpr (sizeof(XT) == 4) {
+        if (var == -1) {
+#define DFD_MB1_DISPATCH(KK, SS, HH, CC, CI, CB, TH, TW, RP, KC, NSUB)                                                \
+    if (k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                               \
+        mb_launch<KK, SS, CB, TH, TW, RP, KC, NSUB, XT>(Xin, Cin, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);  \
+        return true;                                                                                                \
     }
-    DFD_MB_TABLE(DFD_MB_DISPATCH)
-#undef DFD_MB_DISPATCH
+            DFD_MB1_TABLE(DFD_MB1_DISPATCH)
+#undef DFD_MB1_DISPATCH
+        }
+    }
+    if (var < 0) var = 0;
+#define DFD_MB2_DISPATCH(VV, KK, SS, HH, CC, CI, CB, TH, TW, RP, NK)                                                 \
+    if (var == VV && k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                  \
+        mb2_launch<KK, SS, CB, TH, TW, RP, NK, XT>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s); \
+        return true;                                                                                                \
+    }
+    DFD_MB2_TABLE(DFD_MB2_DISPATCH)
+#undef DFD_MB2_DISPATCH
+#ifdef DFD_MB_ABLATION
+#define DFD_ABL_CASE(A)                                                                                              \
+    if (var == 20 + A && H == 56 && stride == 1) {                                                                  \
+        const int tx = 2, ty = 4;                                                                                   \
+        *tiles = tx * ty;                                                                                           \
+        hipLaunchKernelGGL((mbconv2_kernel<3, 1, 16, 14, 28, 7, 1, XT, A>), dim3(tx * ty * (C / 16), n), dim3(256), 0, s, Xin, \
+                           We3, plane, Kp, Wef, be, Wd, bd, Y, P, H, 56, C, Cin, pad_lo, tx, tx * ty);              \
+        return true;                                                                                                \
+    }                                                                                                               \
+    if (var == 20 + A && H == 28 && stride == 1) {                                                                  \
+        *tiles = 1;                                                                                                 \
+        hipLaunchKernelGGL((mbconv2_kernel<5, 1, 16, 28, 28, 7, 2, XT, A>), dim3(C / 16, n), dim3(256), 0, s, Xin,   \
+                           We3, plane, Kp, Wef, be, Wd, bd, Y, P, H, 28, C, Cin, pad_lo, 1, 1);                     \
+        return true;                                                                                                \
+    }
+    DFD_MB2_ABL(DFD_ABL_CASE)
+#undef DFD_ABL_CASE
+#endif
     return false;
 }
-template bool launch_mbconv_front<float>(const float*, int, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int*, hipStream_t);
-template bool launch_mbconv_front<bf16_t>(const bf16_t*, int, const float*, const float*, const float*, const float*, bf16_t*, float*, int, int, int, int, int, int, int*, hipStream_t);
+template bool launch_mbconv_front<float>(const float*, int, const unsigned short*, int, int, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int*, hipStream_t);
+template bool launch_mbconv_front<bf16_t>(const bf16_t*, int, const unsigned short*, int, int, const float*, const float*, const float*, const float*, bf16_t*, float*, int, int, int, int, int, int, int*, hipStream_t);
+
+// SE pool partial-sum tiles of a fused launch (the workspace is sized for the largest count over all variants)
+int mbconv_tiles(int H, int C, int k, int stride, int Cin) {
+    const int Ho = (H + stride - 1) / stride;
+    int best = -1;
+#define DFD_MB2_TILES(VV, KK, SS, HH, CC, CI, CB, TH, TW, RP, NK)                    \
+    if (k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                \
+        const int tl = ((Ho + TW - 1) / TW) * ((Ho + TH - 1) / TH);                  \
+        if (tl > best) best = tl;                                                    \
+    }
+    DFD_MB2_TABLE(DFD_MB2_TILES)
+#undef DFD_MB2_TILES
+#define DFD_MB1_TILES(KK, SS, HH, CC, CI, CB, TH, TW, RP, KC, NSUB)                  \
+    if (k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                \
+        const int tl = ((Ho + TW - 1) / TW) * ((Ho + TH - 1) / TH);                  \
+        if (tl > best) best = tl;                                                    \
+    }
+    DFD_MB1_TABLE(DFD_MB1_TILES)
+#undef DFD_MB1_TILES
+    return best;
+}
 
 int depthwise_tiles(int H, int C, int k, int stride) {
     const int Ho = (H + stride - 1) / stride;

@@ -2,6 +2,8 @@
 // The block table restates efficientnet_pytorch's B0 arguments (the dependency the
 // reference builds its backbone from, reference model.py:39-43) and must agree with
 // b0_arch.py; dfd_create checks every tensor's shape against it.
+#include <algorithm>
+
 #include "b0_kernels.h"
 #include "dfd_common.h"
 
@@ -115,6 +117,7 @@ int b0_build_plan(dfd_handle* h) {
             b.proj_b = need(h, q + ".proj.b", {co}, &ok);
             b.dw_tiles = depthwise_tiles(b.h_in, b.c_exp, b.kernel, b.stride);
             if (b.dw_tiles < 0) return fail(h, DFD_ERR_STATE, "no depthwise kernel for block %d", idx);
+            b.dw_tiles = std::max(b.dw_tiles, mbconv_tiles(b.h_in, b.c_exp, b.kernel, b.stride, b.c_in));
             auto mx = [](size_t& a, size_t v) { if (v > a) a = v; };
             mx(P.io_floats, (size_t)b.h_out * b.h_out * b.c_out);
             if (b.expand != 1) mx(P.exp_floats, (size_t)b.h_in * b.h_in * b.c_exp);
@@ -256,9 +259,12 @@ static int b0_forward_t(dfd_handle* h, const float* x, int n, float* logits_dev,
         const XT* dw_in = cur;
         int tiles = 0;
         bool fused = false;
-        if (b.expand != 1 && h->fuse_expand &&
-            launch_mbconv_front<XT>(cur, b.c_in, b.exp_w, b.exp_b, b.dw_w, b.dw_b, dwbuf, h->pool, n, b.h_in, b.c_exp,
-                                    b.kernel, b.stride, b.pad_lo, &tiles, s)) {
+        const unsigned short* we3 = nullptr;
+        if (b.expand != 1 && h->fuse_expand && mbconv_tiles(b.h_in, b.c_exp, b.kernel, b.stride, b.c_in) > 0 &&
+            !(we3 = split_weights(h, b.exp_w, b.c_exp, b.c_in))) return DFD_ERR_HIP;
+        if (we3 && launch_mbconv_front<XT>(cur, b.c_in, we3, (int)split_weights_count(b.c_exp, b.c_in), (b.c_in + 63) / 64 * 64,
+                                           b.exp_w, b.exp_b, b.dw_w, b.dw_b, dwbuf, h->pool, n, b.h_in, b.c_exp,
+                                           b.kernel, b.stride, b.pad_lo, &tiles, s)) {
             fused = true;
             mk.mark(layer_name(bi, "dw"));            // expand + depthwise in one launch
             if (tap && tap->name && q + ".exp" == tap->name)

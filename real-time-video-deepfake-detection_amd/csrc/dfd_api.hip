@@ -169,6 +169,23 @@ int dfd_warmup(dfd_handle* h, int n_crops, int n_frames) {
 
 int dfd_gemm_tile_count(void) { return s6_max_candidates(); }
 
+int dfd_tiles_export(dfd_handle* h, char* text_out, size_t capacity, size_t* length) {
+    if (!h || !length) return DFD_ERR_ARG;
+    const std::string t = s6_table_export(h->gemm);
+    *length = t.size();
+    if (!text_out) return DFD_OK;                                 // size query
+    if (t.size() > capacity) return fail(h, DFD_ERR_ARG, "tiles_export: %zu bytes needed, capacity %zu", t.size(), capacity);
+    memcpy(text_out, t.data(), t.size());
+    return DFD_OK;
+}
+
+int dfd_tiles_import(dfd_handle* h, const char* text, size_t length, int* accepted) {
+    if (!h || (!text && length)) return DFD_ERR_ARG;
+    const int n = s6_table_import(h->gemm, text, length);
+    if (accepted) *accepted = n < 0 ? 0 : n;
+    return n < 0 ? fail(h, DFD_ERR_ARG, "tiles_import: bad arguments") : DFD_OK;
+}
+
 long long dfd_gemm_chunk_rows(long long rows, long long row_bytes, long long rows_per_image) {
     return s6_chunk_rows(rows, row_bytes, rows_per_image);
 }

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <map>
 #include <new>
+#include <string>
 #include <tuple>
 #include <vector>
 
@@ -109,6 +110,47 @@ int s6_table_measured(const S6Table* t) {
     if (t) for (const auto& kv : t->tiles) n += kv.second.measured ? 1 : 0;
     return n;
 }
+// the measured entries as text, one "M K N mode kind wm wn mt nt ks" line each (dfd_tiles_export / _import: lets a
+// profiled run reuse the tiles of an earlier run instead of launching ~100 candidates per shape under the profiler)
+std::string s6_table_export(const S6Table* t) {
+    std::string out;
+    if (!t) return out;
+    char line[128];
+    for (const auto& kv : t->tiles) {
+        if (!kv.second.measured) continue;
+        snprintf(line, sizeof line, "%d %d %d %d %d %d %d %d %d %d\n", kv.first.M, kv.first.K, kv.first.N, kv.first.mode,
+                 kv.second.kind, kv.second.wm, kv.second.wn, kv.second.mt, kv.second.nt, kv.second.ks);
+        out += line;
+    }
+    return out;
+}
+int s6_table_import(S6Table* t, const char* text, size_t len) {
+    if (!t || !text) return -1;
+    int n = 0;
+    const std::string all(text, len);
+    size_t pos = 0;
+    while (pos < all.size()) {
+        size_t e = all.find('\n', pos);
+        if (e == std::string::npos) e = all.size();
+        int v[10];
+        if (sscanf(all.substr(pos, e - pos).c_str(), "%d %d %d %d %d %d %d %d %d %d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5],
+                   &v[6], &v[7], &v[8], &v[9]) == 10) {
+            // accept only tiles the dispatcher can launch for this shape
+            bool known = false;
+            for (const S6Tile& c : s6_candidates(v[0], v[1], v[2]))
+                known |= c.kind == v[4] && c.wm == v[5] && c.wn == v[6] && c.mt == v[7] && c.nt == v[8] && c.ks == v[9];
+            if (known) {
+                S6Tile tile = make_tile(v[0], v[2], v[4], v[5], v[6], v[7], v[8], v[9]);
+                tile.measured = true;
+                t->tiles[S6Key{v[0], v[1], v[2], v[3]}] = tile;
+                ++n;
+            }
+        }
+        pos = e + 1;
+    }
+    return n;
+}
+
 int s6_max_candidates() { return (int)s6_candidates(1 << 20, 1152, 1280).size(); }
 
 // Rows of one kernel call: activations (and gates) are addressed with 32-bit byte offsets and sized with a

@@ -46,9 +46,6 @@ __device__ long long g_s6_trace[1024];
 #define S6_TP(id) do { } while (0)
 #endif
 
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u4 __attribute__((ext_vector_type(4)));      // (HIP's uint4 struct does not always leave the stack)
-
 constexpr int S6_BK = 32;                 // K of one MFMA = one K-step
 constexpr int S6_KPAD = 64;               // weight planes are zero-padded in K to two K-steps (pw6 with KS = 2)
 #ifndef S6_XD
@@ -66,21 +63,6 @@ constexpr int S6_ROWB = 3 * 64;           // bytes per weight row per stage: 3 p
 // banks for all three plane reads (checked exhaustively; the unrotated image is 2-way conflicted: 42 % extra LDS
 // cycles measured).  No padding, so two buffers of the widest block are 48 KB: three blocks per CU.
 __host__ __device__ constexpr int s6_chunk_pos(int row, int c) { return (c + 6 * ((row >> 2) & 1)) % 12; }
-// 8 fp32 values -> three bf16x8 terms (exact: see the header)
-__device__ __forceinline__ void split8(const v4f lo, const v4f hi, bf8& s0, bf8& s1, bf8& s2) {
-    const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 h0 = (__bf16)f[i];
-        const float r1 = f[i] - (float)h0;
-        const __bf16 h1 = (__bf16)r1;
-        const float r2 = r1 - (float)h1;
-        s0[i] = h0;
-        s1[i] = h1;
-        s2[i] = (__bf16)r2;
-    }
-}
-
 // bf16 activations (8 consecutive k as loaded: one 16-byte register quad) -> MFMA operand; with GATE the
 // squeeze-excite gate (fp32) is multiplied in and the product rounded to bf16 (round to nearest even)
 template <bool GATE>

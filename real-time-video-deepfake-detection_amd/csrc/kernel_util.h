@@ -42,4 +42,24 @@ __device__ __forceinline__ void st4(bf16_t* p, v4f v) {
     *reinterpret_cast<u2v*>(p) = __builtin_bit_cast(u2v, b);
 }
 
+
+// ---- split-precision operands (gemm_split_impl.h, and the fused expand of b0_kernels.hip) ----
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));      // (HIP's uint4 struct does not always leave the stack)
+
+// 8 fp32 values -> three bf16x8 terms whose sum is exact (a0 = bf16(a), a1 = bf16(a - a0), a2 = bf16(a - a0 - a1))
+__device__ __forceinline__ void split8(const v4f lo, const v4f hi, bf8& s0, bf8& s1, bf8& s2) {
+    const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h0 = (__bf16)f[i];
+        const float r1 = f[i] - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        const float r2 = r1 - (float)h1;
+        s0[i] = h0;
+        s1[i] = h1;
+        s2[i] = (__bf16)r2;
+    }
+}
+
 }  // namespace dfd
