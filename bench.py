@@ -32,8 +32,20 @@ BATCH = 256
 E2E_FRAMES = 64
 
 
-def cpu_baseline(sd_np, sample_crops=32, chunk=16):
-    """Times oracle/b0_ref.forward (the checker, used here only as the CPU baseline)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd_np, with_e2e=True):
+    """Times the CPU oracle (the checker; used here only as the CPU baseline) on a bounded sample of the same
+    workloads, SURVEY 8(d) "CPU baseline beside it": the classifier at reference-style batch 1 and at batch 256,
+    and - beside the e2e object - detector, CLAHE + 224 resize, and the six forensic signals per 1080p frame."""
     import torch
 
     import rtdfd_amd
@@ -49,23 +61,53 @@ def cpu_baseline(sd_np, sample_crops=32, chunk=16):
     torch.set_num_threads(cores)
     sd = rtdfd_amd.weights.to_torch(sd_np)
     torch.manual_seed(1)
-    x = torch.randn(chunk, 3, 224, 224)
+    x = torch.randn(BATCH, 3, 224, 224)
     b0_ref.forward(sd, x[:2])                       # warm-up
     t0 = time.perf_counter()
-    done = 0
-    while done < sample_crops:
-        b0_ref.forward(sd, x)
-        done += chunk
-    dt = time.perf_counter() - t0
-    # reference-style batch 1 (how backend_server.py drives it), a few calls
+    b0_ref.forward(sd, x)                           # ONE batch-256 forward: the benchmark's own step
+    dt256 = time.perf_counter() - t0
     t1 = time.perf_counter()
-    for _ in range(4):
+    for _ in range(8):                              # reference-style batch 1 (how backend_server.py drives it)
         b0_ref.forward(sd, x[:1])
-    dt1 = (time.perf_counter() - t1) / 4
-    return {"value": round(done / dt, 2), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{done} crops as {done // chunk} batches of {chunk}, torch-CPU fp32 oracle; "
-                      f"batch-1 latency {dt1 * 1e3:.0f} ms",
-            "batch1_crops_per_s": round(1.0 / dt1, 2)}
+    dt1 = (time.perf_counter() - t1) / 8
+    t2 = time.perf_counter()
+    for i in range(2):                              # cache-friendlier chunks of 16 (round 1's figure)
+        b0_ref.forward(sd, x[16 * i:16 * i + 16])
+    dt16 = (time.perf_counter() - t2) / 32
+    out = {"value": round(BATCH / dt256, 2), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+           "cpu_model": cpu_model(),
+           "sample": f"one batch-{BATCH} forward of the torch-CPU fp32 oracle ({dt256:.2f} s); batch-1 latency "
+                     f"{dt1 * 1e3:.0f} ms over 8 calls",
+           "batch1_crops_per_s": round(1.0 / dt1, 2), "batch16_crops_per_s": round(1.0 / dt16, 2)}
+    if with_e2e:
+        from oracle import forensics_ref, imgproc_ref, ssd_ref
+
+        W = rtdfd_amd.weights
+        ssd_sd = W.to_torch(W.seeded_ssd_state_dict(0))
+        frame = np.random.default_rng(7).integers(50, 200, (1080, 1920, 3), dtype=np.uint8)
+        boxes = [(200, 150, 320, 400), (900, 300, 256, 256), (1400, 500, 400, 480), (600, 700, 224, 224)]
+
+        def timed(fn, reps):
+            fn()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return (time.perf_counter() - t) / reps
+
+        t_det = timed(lambda: ssd_ref.detect_bounding_box(ssd_sd, rtdfd_amd.ssd_arch, frame), 3)
+        t_pre = timed(lambda: [imgproc_ref.crop_resize_normalize(imgproc_ref.preprocess_face_quality(
+            frame[y:y + h, x0:x0 + w])) for (x0, y, w, h) in boxes], 2)
+        an = forensics_ref.ForensicsRef()
+        t_for = timed(lambda: an.analyze(frame), 2)
+        t_cls = dt1 * len(boxes)
+        per_frame = t_det + t_pre + t_cls
+        out["e2e_port"] = {
+            "workload": "one 1080p frame, 4 forced boxes: detector (300x300 SSD) + CLAHE/224 resize + B0 batch 1 per face",
+            "detect_ms": round(t_det * 1e3, 1), "clahe_resize_ms_4_faces": round(t_pre * 1e3, 1),
+            "classify_ms_4_faces": round(t_cls * 1e3, 1), "forensics_full_ms": round(t_for * 1e3, 1),
+            "detect_classify_frames_per_s": round(1.0 / per_frame, 2),
+            "detect_classify_forensics_frames_per_s": round(1.0 / (per_frame + t_for), 2)}
+    return out
 
 
 def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, warmup=3):
@@ -394,6 +436,16 @@ def main():
         except Exception:
             traffic = None
 
+    # per depthwise launch: algorithmic bytes of that layer (input + output + k*k*C weights, fp32) / its duration
+    per_layer = []
+    for i, blk in enumerate(b0_arch.BLOCKS):
+        ms = sum(m for name, m in layers if name == f"b{i}.dw") / max(steps_seen, 1)
+        nbytes = (blk.h_in * blk.h_in + blk.h_out * blk.h_out + blk.kernel * blk.kernel) * blk.c_exp * 4 * args.batch
+        if ms > 0:
+            per_layer.append({"block": i, "k": blk.kernel, "stride": blk.stride, "hw": blk.h_in, "c_exp": blk.c_exp,
+                              "us": round(ms * 1e3, 1), "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                              "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)})
+
     out = {
         "metric": "face-crops/sec (224x224 crops through EfficientNet-B0 classify)",
         "value": round(value, 1), "unit": "crops/s", "n_gpus": world, "steps": args.steps,
@@ -409,7 +461,10 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "dfd::dw_kernel<...> / dfd::mbconv_kernel<...> (the 16 depthwise launches per step; blocks 1-5 compute their 1x1 expand inside the launch)",
                      "algorithmic_bytes_per_step": dw_bytes, "ms_per_step": round(dw_ms, 4),
-                     "share_of_step": round(dw_ms / all_ms, 4) if all_ms else None},
+                     "share_of_step": round(dw_ms / all_ms, 4) if all_ms else None,
+                     "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                       "profiles/b0_profile_driver.py at this commit; counters cannot be read inside the run)",
+                     "per_layer": per_layer},
         "kernel_ms_per_step": round(all_ms, 3),
         "parity": {"rows": 8, "max_abs_logit_err_vs_oracle": parity, "tol": 1e-3},
     }
@@ -448,7 +503,7 @@ def main():
                 print(f"  {name:10s} {ms / max(steps_seen, 1):8.4f}", file=sys.stderr)
             print("by kind:", {k: round(v, 3) for k, v in agg.items()}, file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd)
+            out["cpu_baseline"] = cpu_baseline(sd, with_e2e=not args.no_e2e)
         print(json.dumps(out), file=json_out, flush=True)
     xd.free()
     yd.free()

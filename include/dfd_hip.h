@@ -170,6 +170,9 @@ int dfd_frequency_features(dfd_handle* h, const uint8_t* img, int height, int wi
 int dfd_detect_faces(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
                      float conf_thr, int32_t* xywh_out, float* conf_out, int max_out, int* n_out);
 int dfd_has_detector(const dfd_handle* h);
+/* Number of detections of the last dfd_detect_faces / dfd_analyze_frame call BEFORE the max_out / max_faces cut:
+ * `len(faces)` of the reference (backend_server.py:181 reports it while classifying faces[0] only). */
+int dfd_last_detection_count(const dfd_handle* h);
 /* One named detector intermediate for parity tests: a layer name of ssd_arch.LAYERS,
  * "<source>.head", "prob", "boxes" (per prior) or "rows" (DetectionOutput: score,x1,y1,x2,y2). */
 int dfd_ssd_tap(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
@@ -222,7 +225,7 @@ int dfd_forensics_state(dfd_handle* h, int stream_id, int* frame_count, int* n_d
  * and of the /analyze handler (reference backend_server.py:147-164) with ONE upload of the
  * frame: forensics (full or fast) on `stream_id`, face detection, then crop -> CLAHE -> 224x224
  * -> classifier for the first min(n_detected, max_faces) boxes (predict uses all faces, the
- * server faces[0]).  scores_out[6]/forensic_prob_out as dfd_forensics; xywh_out receives
+ * server faces[0]; more faces than the handle's max_batch are classified in several passes).  scores_out[6]/forensic_prob_out as dfd_forensics; xywh_out receives
  * n_faces_out boxes and logits_out one logit per box.  Calibration, the +0.10 small-face
  * heuristic and the vote are host logic (scalars). */
 int dfd_analyze_frame(dfd_handle* h, int stream_id, const uint8_t* bgr, int height, int width,

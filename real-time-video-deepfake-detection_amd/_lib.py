@@ -61,6 +61,7 @@ SIGNATURES = {
     "dfd_detect_faces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                    C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dfd_has_detector": (C.c_int, [C.c_void_p]),
+    "dfd_last_detection_count": (C.c_int, [C.c_void_p]),
     "dfd_ssd_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p,
                               C.c_size_t, C.POINTER(C.c_size_t)]),
     "dfd_has_mtcnn": (C.c_int, [C.c_void_p]),
@@ -361,7 +362,7 @@ class Handle:
         """One upload: forensics + detect + crop/CLAHE + classify.
         -> (scores dict, forensic probability, [(x,y,w,h)...], logits (n,))"""
         a = self._as_bgr(frame)
-        max_faces = max(1, min(int(max_faces), self.max_batch))
+        max_faces = max(1, int(max_faces))
         sc = np.empty(6, np.float64)
         prob = C.c_double()
         boxes = np.zeros((max_faces, 4), np.int32)
@@ -373,6 +374,10 @@ class Handle:
                                                 _ptr(logits)))
         scores = {k: float(v) for k, v in zip(self.FORENSIC_KEYS, sc) if not np.isnan(v)}
         return scores, float(prob.value), [tuple(int(v) for v in boxes[i]) for i in range(n.value)], logits[: n.value].copy()
+
+    def last_detection_count(self) -> int:
+        """len(faces) of the last detect_faces / analyze_frame call, before its max_out / max_faces cut"""
+        return int(self._lib.dfd_last_detection_count(self._p))
 
     def analyze_batch_device(self, frames_dev: int, n: int, height: int, width: int, forced_boxes=None,
                              confidence_threshold: float = 0.5, max_faces: int = 4, apply_clahe: bool = True,

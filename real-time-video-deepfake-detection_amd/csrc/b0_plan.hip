@@ -42,7 +42,7 @@ bool parse_blob(const void* blob, size_t len, std::map<std::string, Tensor>* out
         uint64_t off, nb;
         memcpy(&off, e + 68, 8);
         memcpy(&nb, e + 76, 8);
-        if (t.ndim > 4 || off % 4 || off + nb > len) { *err = std::string("blob: bad entry ") + name; return false; }
+        if (t.ndim > 4 || off % 4 || nb > len || off > len - nb) { *err = std::string("blob: bad entry ") + name; return false; }
         t.count = 1;
         for (uint32_t d = 0; d < t.ndim; ++d) t.count *= t.dims[d];
         if (t.count * 4 != nb) { *err = std::string("blob: size mismatch for ") + name; return false; }

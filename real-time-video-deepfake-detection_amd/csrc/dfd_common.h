@@ -93,6 +93,7 @@ struct dfd_handle {
     dfd::ColorTables color{};
     bool has_color = false;
     dfd::DevBuf frame_buf, lab_buf, crop_buf, lut_buf, desc_buf, u8_out, face_batch;
+    int last_detections = 0;             // detections of the last single-frame detector run, before the max_out cut
     std::vector<char> crop_valid;        // per crop of the last preprocess: 0 = the MTCNN stage found no face
     dfd::ForensicState* forensic = nullptr;   // per-stream temporal state + work buffers
     dfd::FreqState* freq = nullptr;           // compute_frequency_features tables + scratch

@@ -174,17 +174,20 @@ int dfd_analyze_frame(dfd_handle* h, int stream_id, const uint8_t* bgr, int hh, 
     const uint8_t* fd = (const uint8_t*)h->frame_buf.p;
     if ((rc = forensics_run(h, stream_id, fd, hh, ww, stride, full_forensics, scores_out, forensic_prob_out, nullptr))) return rc;
     *n_faces_out = 0;
-    if (max_faces > h->max_batch) max_faces = h->max_batch;
     int n = 0;
     if ((rc = detect_run(h, fd, hh, ww, stride, conf_thr, xywh_out, nullptr, max_faces, &n))) return rc;
     *n_faces_out = n;
-    if (n == 0) return DFD_OK;
-    if ((rc = preprocess_on_device(h, fd, hh, ww, stride, xywh_out, n, apply_clahe))) return rc;
-    if ((rc = b0_forward(h, h->in_nchw, n, h->logits, nullptr, nullptr))) return rc;
-    DFD_HIP_TRY(h, hipMemcpyAsync(logits_out, h->logits, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
-    for (int i = 0; i < n; ++i)
-        if (!h->crop_valid[i]) logits_out[i] = NAN;      // MTCNN found no face in this crop
+    // every returned face is classified, in chunks of the handle's batch capacity (predict votes on all detections,
+    // reference deepfake_detection.py:611-626; dfd_last_detection_count gives len(faces) when max_faces cut the list)
+    for (int start = 0; start < n; start += h->max_batch) {
+        const int m = n - start < h->max_batch ? n - start : h->max_batch;
+        if ((rc = preprocess_on_device(h, fd, hh, ww, stride, xywh_out + (size_t)start * 4, m, apply_clahe))) return rc;
+        if ((rc = b0_forward(h, h->in_nchw, m, h->logits, nullptr, nullptr))) return rc;
+        DFD_HIP_TRY(h, hipMemcpyAsync(logits_out + start, h->logits, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
+        DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < m; ++i)
+            if (!h->crop_valid[i]) logits_out[start + i] = NAN;      // MTCNN found no face in this crop
+    }
     return DFD_OK;
 }
 

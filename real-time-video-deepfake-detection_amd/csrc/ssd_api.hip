@@ -290,9 +290,9 @@ int ssd_warmup(dfd_handle* h, int n) {
 
 // reference face_detection.py:84-105 on one image's DetectionOutput rows
 int ssd_postprocess(const float* rows, int nrows, int hh, int ww, float conf_thr, int32_t* xywh, float* conf,
-                    int max_out) {
-    int k = 0;
-    for (int i = 0; i < nrows && k < max_out; ++i) {
+                    int max_out, int* total = nullptr) {
+    int k = 0, all = 0;
+    for (int i = 0; i < nrows; ++i) {
         const float* r = rows + (size_t)i * 5;
         if (!(r[0] > conf_thr)) continue;                                   // strict '>'
         // float32 box * int64 [w,h,w,h] is a float64 product in numpy; astype(int) truncates toward zero
@@ -304,11 +304,15 @@ int ssd_postprocess(const float* rows, int nrows, int hh, int ww, float conf_thr
         if (y2 > hh) y2 = hh;
         const long long bw = x2 - x1, bh = y2 - y1;
         if (bw > 20 && bh > 20) {
-            xywh[4 * k] = (int32_t)x1; xywh[4 * k + 1] = (int32_t)y1; xywh[4 * k + 2] = (int32_t)bw; xywh[4 * k + 3] = (int32_t)bh;
-            if (conf) conf[k] = r[0];
-            ++k;
+            ++all;                                                   // every detection counts (len(faces)) ...
+            if (k < max_out) {                                       // ... the first max_out are returned
+                xywh[4 * k] = (int32_t)x1; xywh[4 * k + 1] = (int32_t)y1; xywh[4 * k + 2] = (int32_t)bw; xywh[4 * k + 3] = (int32_t)bh;
+                if (conf) conf[k] = r[0];
+                ++k;
+            }
         }
     }
+    if (total) *total = all;
     return k;
 }
 
@@ -316,6 +320,7 @@ int ssd_postprocess(const float* rows, int nrows, int hh, int ww, float conf_thr
 int detect_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, float conf_thr, int32_t* xywh_out,
                float* conf_out, int max_out, int* n_out) {
     *n_out = 0;
+    h->last_detections = 0;
     if (hh < 30 || ww < 30) return DFD_OK;                                    // face_detection.py:55-56
     if (!h->ssd || !h->ssd->ready) return fail(h, DFD_ERR_STATE, "detector weights were not packed into the blob (weights.pack_all)");
     int rc;
@@ -327,7 +332,7 @@ int detect_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stri
     DFD_HIP_TRY(h, hipMemcpyAsync(&cnt, h->ssd->count.p, 4, hipMemcpyDeviceToHost, h->stream));
     DFD_HIP_TRY(h, hipMemcpyAsync(rows, h->ssd->rows.p, sizeof rows, hipMemcpyDeviceToHost, h->stream));
     DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
-    *n_out = ssd_postprocess(rows, cnt, hh, ww, conf_thr, xywh_out, conf_out, max_out);
+    *n_out = ssd_postprocess(rows, cnt, hh, ww, conf_thr, xywh_out, conf_out, max_out, &h->last_detections);
     return DFD_OK;
 }
 
@@ -357,6 +362,8 @@ int detect_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, in
 extern "C" {
 
 int dfd_has_detector(const dfd_handle* h) { return h && h->ssd && h->ssd->ready ? 1 : 0; }
+
+int dfd_last_detection_count(const dfd_handle* h) { return h ? h->last_detections : DFD_ERR_ARG; }
 
 int dfd_detect_faces(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride, float conf_thr, int32_t* xywh_out,
                      float* conf_out, int max_out, int* n_out) {

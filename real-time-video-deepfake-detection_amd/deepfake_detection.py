@@ -173,8 +173,12 @@ class DeepfakeDetector:
         """forensics + detection + per-face logits in one library call."""
         full = self._forensic_is_full()
         with self._lock:
-            scores, prob, boxes, logits = self.handle.analyze_frame(
-                frame, full, stream_id=self.frame_analyzer.stream_id, confidence_threshold=0.5, max_faces=max_faces)
+            if self.handle.has_detector:
+                scores, prob, boxes, logits = self.handle.analyze_frame(
+                    frame, full, stream_id=self.frame_analyzer.stream_id, confidence_threshold=0.5, max_faces=max_faces)
+            else:                                   # no detector weights: 'frame_only' mode (runtime.py)
+                scores, prob, _ = self.handle.forensics(frame, full=full, stream_id=self.frame_analyzer.stream_id)
+                boxes, logits = [], []
             number = self.frame_analyzer.frame_count
         forensic = {'scores': scores, 'fake_probability': prob,
                     'analysis_type': 'frame_forensic' if full else 'frame_forensic_fast', 'frame_number': number}
@@ -186,7 +190,7 @@ class DeepfakeDetector:
         self.frame_count += 1
         frame = np.ascontiguousarray(frame)
         small = frame.shape[0] < 30 or frame.shape[1] < 30
-        frame_forensic, faces, logits = self._frame_on_gpu(frame, max_faces=self.handle.max_batch)
+        frame_forensic, faces, logits = self._frame_on_gpu(frame, max_faces=200)       # DetectionOutput keeps <= 200
         if small:
             faces, logits = [], []
         trigger_forensic, forensic_frame = False, None
@@ -255,12 +259,11 @@ class DeepfakeDetector:
                 'frame_count': self.frame_count}
 
     def _last_face_count(self, frame, faces):
-        """`faces_detected` of the server response counts ALL detections (backend_server.py:181); the fused
-        call classified only the first, so ask the detector for the full list when there was one."""
+        """`faces_detected` of the server response counts ALL detections (backend_server.py:181); the fused call
+        classified only the first and the library remembers how many there were."""
         if not faces:
             return 0
-        with self._lock:
-            return len(self.handle.detect_faces(frame, 0.5))
+        return self.handle.last_detection_count()
 
 
 _detector: Optional[DeepfakeDetector] = None

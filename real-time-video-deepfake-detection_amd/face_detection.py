@@ -30,6 +30,8 @@ def detect_bounding_box(frame, confidence_threshold: float = 0.5, *, handle: Opt
         if frame.ndim != 3 or frame.shape[2] != 3:
             return []
         h = handle or runtime.default_handle()
+        if not h.has_detector:                      # no detector weights were configured (runtime.py)
+            return []
         return h.detect_faces(frame, confidence_threshold)
     except (DfdError, ValueError, TypeError) as e:
         log.warning("face detection failed: %s", e)

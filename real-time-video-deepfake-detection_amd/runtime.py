@@ -2,9 +2,18 @@
 ``model = DeepfakeEfficientNet(...); model.to(DEVICE).eval()`` singleton,
 reference deepfake_detection.py:30-90), created lazily on first use.
 
-Weights: ``$DFD_WEIGHTS`` or ``weights/best_model.pth`` next to the package if present
-(reference checkpoint layout), else the seeded random-init state dict - the reference tree ships
-no weights.  Device: ``$DFD_DEVICE`` or ``$LOCAL_RANK`` or 0.
+Weights (the reference tree ships none):
+  classifier  ``$DFD_WEIGHTS`` or ``weights/best_model.pth`` next to the package (reference checkpoint layout),
+              else seeded random-init weights with a warning (`model_loaded` stays False, /health says so);
+  detector    ``$DFD_SSD_WEIGHTS``: an .npz / .pth state dict in `ssd_arch` naming.  Without it there is NO detector:
+              the handle is built without one, `detect_bounding_box` returns [] and every frame is analysed in
+              'frame_only' mode (where the reference, whose model files are missing too, face_detection.py:22-34,
+              falls back to a Haar cascade - not built here, DESIGN.md section 8);
+  MTCNN       ``$DFD_MTCNN_WEIGHTS``: directory with pnet.pt / rnet.pt / onet.pt (facenet-pytorch's files); without it
+              the align stage is left out.
+``DFD_SYNTHETIC_WEIGHTS=1`` (benchmarks, demos) substitutes seeded random-init detector and MTCNN weights of the same
+topologies - boxes and alignments are then meaningless, and a warning says so.
+Device: ``$DFD_DEVICE`` or ``$LOCAL_RANK`` or 0.
 """
 from __future__ import annotations
 
@@ -22,7 +31,10 @@ log = logging.getLogger(__name__)
 _lock = threading.Lock()
 _default: Optional[Handle] = None
 _state: Optional[Dict[str, np.ndarray]] = None
-model_loaded = False          # True when a trained checkpoint was found
+model_loaded = False          # True when a trained classifier checkpoint was found
+detector_loaded = False       # True when real detector weights were loaded ($DFD_SSD_WEIGHTS)
+mtcnn_loaded = False          # True when real MTCNN weights were loaded ($DFD_MTCNN_WEIGHTS)
+detector_synthetic = False    # seeded stand-ins in use (DFD_SYNTHETIC_WEIGHTS=1)
 
 
 def device_index() -> int:
@@ -44,21 +56,47 @@ def default_state_dict() -> Dict[str, np.ndarray]:
     return _state
 
 
+def load_detector_weights(path: str) -> Dict[str, np.ndarray]:
+    """an .npz / .pth state dict in ssd_arch naming"""
+    if path.endswith(".npz"):
+        with np.load(path) as z:
+            return {k: np.asarray(z[k], np.float32) for k in z.files}
+    import torch
+
+    sd = torch.load(path, map_location="cpu")
+    return {k: v.detach().cpu().numpy().astype(np.float32) for k, v in sd.items()}
+
+
 def default_handle() -> Handle:
-    global _default
+    global _default, detector_loaded, mtcnn_loaded, detector_synthetic
     with _lock:
         if _default is None:
-            # detector: the reference's Caffe files are not in its tree either (face_detection.py:19-20);
-            # seeded random-init weights of the same topology stand in
             seed = int(os.environ.get("DFD_SEED", "0"))
-            ssd = W.seeded_ssd_state_dict(seed)
-            # MTCNN: facenet-pytorch ships its trained pnet/rnet/onet inside the pip package, which is absent here;
-            # $DFD_MTCNN_WEIGHTS = directory with pnet.pt / rnet.pt / onet.pt, else seeded random-init; DFD_MTCNN=0
-            # leaves the stage out (the detector crop then feeds the classifier directly)
+            synthetic = os.environ.get("DFD_SYNTHETIC_WEIGHTS", "0") == "1"
+            ssd = None
+            path = os.environ.get("DFD_SSD_WEIGHTS")
+            if path:
+                ssd = load_detector_weights(path)
+                detector_loaded = True
+                log.info("loaded detector weights %s", path)
+            elif synthetic:
+                ssd = W.seeded_ssd_state_dict(seed)
+                detector_synthetic = True
+                log.warning("DFD_SYNTHETIC_WEIGHTS=1: random-init detector weights - face boxes are meaningless")
+            else:
+                log.warning("no detector weights ($DFD_SSD_WEIGHTS): no face detection, every frame is analysed in "
+                            "'frame_only' mode")
             mt = None
             if os.environ.get("DFD_MTCNN", "1") != "0":
                 d = os.environ.get("DFD_MTCNN_WEIGHTS")
-                mt = W.load_mtcnn_checkpoints(d) if d else W.seeded_mtcnn_state_dict(seed)
+                if d:
+                    mt = W.load_mtcnn_checkpoints(d)
+                    mtcnn_loaded = True
+                elif synthetic:
+                    mt = W.seeded_mtcnn_state_dict(seed)
+                    log.warning("DFD_SYNTHETIC_WEIGHTS=1: random-init MTCNN cascade - alignments are meaningless")
+                else:
+                    log.warning("no MTCNN weights ($DFD_MTCNN_WEIGHTS): the align stage is left out")
             _default = Handle(W.pack_all(default_state_dict(), ssd, mt), device=device_index(),
                               max_batch=int(os.environ.get("DFD_MAX_BATCH", "16")))
         return _default
