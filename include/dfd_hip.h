@@ -246,6 +246,17 @@ int dfd_analyze_batch_device(dfd_handle* h, const uint8_t* frames_dev, int n, in
                              int apply_clahe, int with_forensics, int32_t* xywh_out, int* n_faces_out,
                              float* logits_out, double* forensic_prob_out);
 
+/* ---- many frames from host memory, upload overlapped with compute ---------------------------------------------
+ * The PCIe-inclusive form of dfd_analyze_batch_device: n_total packed BGR frames in host memory (ideally from
+ * dfd_host_alloc = pinned, so that the copies run asynchronously) are processed `batch` at a time; batch k + 1 is
+ * uploaded on a second HIP stream while batch k is analysed.  Output arrays are sized for n_total frames. */
+int dfd_host_alloc(dfd_handle* h, size_t bytes, void** ptr);
+int dfd_host_free(dfd_handle* h, void* ptr);
+int dfd_analyze_frames_host(dfd_handle* h, const uint8_t* frames_host, int n_total, int batch, int height, int width,
+                            const int32_t* forced_xywh, int forced_k, float conf_thr, int max_faces, int apply_clahe,
+                            int with_forensics, int32_t* xywh_out, int* n_faces_out, float* logits_out,
+                            double* forensic_prob_out);
+
 /* ---- frame-sharded streams (BASELINE.json configs[4]) ------------------------------
  * With frame t of a stream on rank t % G, the only state that crosses frames is the vote window (reference
  * deepfake_detection.py:111-118) and the analyzer's temporal signal (reference frame_analysis.py:349-389: the

@@ -79,6 +79,11 @@ SIGNATURES = {
     "dfd_forensics_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "dfd_forensics_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_int)]),
+    "dfd_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "dfd_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dfd_analyze_frames_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                          C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
     "dfd_forensic_signals_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                               C.c_void_p, C.c_void_p]),
     "dfd_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -374,6 +379,43 @@ class Handle:
                                                 _ptr(logits)))
         scores = {k: float(v) for k, v in zip(self.FORENSIC_KEYS, sc) if not np.isnan(v)}
         return scores, float(prob.value), [tuple(int(v) for v in boxes[i]) for i in range(n.value)], logits[: n.value].copy()
+
+    def host_alloc(self, shape, dtype=np.uint8) -> np.ndarray:
+        """A numpy array over pinned host memory (hipHostMalloc); release with host_free(arr)."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._check(self._lib.dfd_host_alloc(self._p, nbytes, C.byref(p)))
+        buf = (C.c_char * nbytes).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p:
+            self._check(self._lib.dfd_host_free(self._p, p))
+
+    def analyze_frames_host(self, frames: np.ndarray, batch: int, forced_boxes=None, confidence_threshold: float = 0.5,
+                            max_faces: int = 4, apply_clahe: bool = True, with_forensics: bool = False):
+        """frames: (n, H, W, 3) uint8 in host memory (pinned: host_alloc) -> as analyze_batch_device, PCIe included."""
+        if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[3] != 3 or not frames.flags["C_CONTIGUOUS"]:
+            raise ValueError("expected a contiguous (n,H,W,3) uint8 array")
+        n, height, width = frames.shape[:3]
+        forced, forced_k = None, 0
+        if forced_boxes is not None:
+            forced = np.ascontiguousarray(np.asarray(forced_boxes, np.int32).reshape(n, -1, 4))
+            forced_k = forced.shape[1]
+        xy = np.zeros((n, max_faces, 4), np.int32)
+        nf = np.zeros(n, np.int32)
+        lg = np.zeros((n, max_faces), np.float32)
+        fp = np.zeros(n, np.float64)
+        self._check(self._lib.dfd_analyze_frames_host(
+            self._p, frames.ctypes.data, n, int(batch), height, width, _ptr(forced) if forced is not None else None, forced_k,
+            float(confidence_threshold), int(max_faces), int(bool(apply_clahe)), int(bool(with_forensics)),
+            _ptr(xy), _ptr(nf), _ptr(lg), _ptr(fp)))
+        boxes = [[tuple(int(v) for v in xy[f, i]) for i in range(nf[f])] for f in range(n)]
+        return boxes, [lg[f, : nf[f]].copy() for f in range(n)], (fp if with_forensics else None)
 
     def last_detection_count(self) -> int:
         """len(faces) of the last detect_faces / analyze_frame call, before its max_out / max_faces cut"""

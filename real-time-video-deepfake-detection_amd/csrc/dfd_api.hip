@@ -96,6 +96,11 @@ void destroy_impl(dfd_handle* h) {
     h->gemm = nullptr;
     for (void* p : h->owned)
         if (p) hipFree(p);
+    for (int i = 0; i < 2; ++i) {
+        if (h->copy_done[i]) hipEventDestroy(h->copy_done[i]);
+        if (h->slot_free[i]) hipEventDestroy(h->slot_free[i]);
+    }
+    if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);

@@ -82,6 +82,10 @@ struct dfd_handle {
     int max_batch = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // dfd_analyze_frames_host: copy stream + two staging slots (uploads overlap the previous batch's compute)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_done[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr};
+    dfd::DevBuf stage[2];
     std::map<std::string, dfd::Tensor> tensors;
     std::vector<void*> owned;            // every hipMalloc the handle must free
     dfd::B0Plan b0;

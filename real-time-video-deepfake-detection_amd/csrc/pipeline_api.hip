@@ -3,6 +3,7 @@
 // optionally with the six forensic signals.  The per-frame semantics are those of
 // dfd_analyze_frame; this entry point exists for throughput (no per-frame host round trips
 // except the small DetectionOutput read-back that sizes the crop batch).
+#include <algorithm>
 #include <cmath>
 #include "b0_kernels.h"
 #include "dfd_common.h"
@@ -62,6 +63,70 @@ int dfd_analyze_batch_device(dfd_handle* h, const uint8_t* frames_dev, int n, in
     int k = 0;
     for (int f = 0; f < n; ++f)
         for (int i = 0; i < n_faces_out[f]; ++i) logits_out[(size_t)f * max_faces + i] = logits[k++];
+    return DFD_OK;
+}
+
+
+// ---- host frames, PCIe-inclusive (BASELINE.json metric "frames/sec/GPU" with the upload counted) -------------
+// n_total frames in (pinned) host memory are analysed `batch` at a time through two device staging buffers: the
+// upload of batch k + 1 is issued on the handle's copy stream before batch k is computed on the compute stream, so
+// the 6.2 MB per 1080p frame cross PCIe while the previous batch runs (reference flow: one cv2.imdecode'd frame per
+// request, backend_server.py:139-164 - here many frames per call).  Results as dfd_analyze_batch_device.
+int dfd_host_alloc(dfd_handle* h, size_t bytes, void** ptr) {
+    if (!h || !ptr) return DFD_ERR_ARG;
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    DFD_HIP_TRY(h, hipHostMalloc(ptr, bytes ? bytes : 4, hipHostMallocDefault));
+    return DFD_OK;
+}
+
+int dfd_host_free(dfd_handle* h, void* ptr) {
+    if (!h) return DFD_ERR_ARG;
+    DFD_HIP_TRY(h, hipHostFree(ptr));
+    return DFD_OK;
+}
+
+int dfd_analyze_frames_host(dfd_handle* h, const uint8_t* frames_host, int n_total, int batch, int hh, int ww,
+                            const int32_t* forced_xywh, int forced_k, float conf_thr, int max_faces, int apply_clahe,
+                            int with_forensics, int32_t* xywh_out, int* n_faces_out, float* logits_out,
+                            double* forensic_prob_out) {
+    if (!h) return DFD_ERR_ARG;
+    if (!frames_host || n_total <= 0 || batch <= 0 || hh <= 0 || ww <= 0 || max_faces <= 0)
+        return fail(h, DFD_ERR_ARG, "analyze_frames_host: bad pointer or geometry");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    const size_t frame_bytes = (size_t)hh * ww * 3;
+    int rc;
+    if (!h->copy_stream) {
+        DFD_HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->copy_done[i], hipEventDisableTiming));
+            DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->slot_free[i], hipEventDisableTiming));
+        }
+    }
+    for (int i = 0; i < 2; ++i)
+        if ((rc = ensure(h, &h->stage[i], (size_t)batch * frame_bytes))) return rc;
+    auto upload = [&](int k) -> int {                       // batch k -> staging slot k & 1, on the copy stream
+        const int slot = k & 1, first = k * batch, cnt = std::min(batch, n_total - first);
+        if (k >= 2) DFD_HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->slot_free[slot], 0));   // batch k - 2 done with it
+        DFD_HIP_TRY(h, hipMemcpyAsync(h->stage[slot].p, frames_host + (size_t)first * frame_bytes, (size_t)cnt * frame_bytes,
+                                      hipMemcpyHostToDevice, h->copy_stream));
+        DFD_HIP_TRY(h, hipEventRecord(h->copy_done[slot], h->copy_stream));
+        return DFD_OK;
+    };
+    const int nb = (n_total + batch - 1) / batch;
+    if ((rc = upload(0))) return rc;
+    for (int k = 0; k < nb; ++k) {
+        const int slot = k & 1, first = k * batch, cnt = std::min(batch, n_total - first);
+        if (k + 1 < nb && (rc = upload(k + 1))) return rc;              // in flight while batch k computes
+        DFD_HIP_TRY(h, hipStreamWaitEvent(h->stream, h->copy_done[slot], 0));
+        rc = dfd_analyze_batch_device(h, (const uint8_t*)h->stage[slot].p, cnt, hh, ww,
+                                      forced_xywh ? forced_xywh + (size_t)first * forced_k * 4 : nullptr, forced_k, conf_thr,
+                                      max_faces, apply_clahe, with_forensics, xywh_out + (size_t)first * max_faces * 4,
+                                      n_faces_out + first, logits_out + (size_t)first * max_faces,
+                                      forensic_prob_out ? forensic_prob_out + first : nullptr);
+        if (rc) return rc;
+        DFD_HIP_TRY(h, hipEventRecord(h->slot_free[slot], h->stream));
+    }
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
     return DFD_OK;
 }
 

@@ -153,3 +153,28 @@ def test_streams_with_mtcnn_alignment_match_oracle(pkg, mt_handle, refs, mtcnn_s
         assert det2.temporal_tracker.get_voting_stats() == want['votes']
         modes.add((got['analysis_mode'], got['faces_detected'] > 0))
     assert ('frame_only', False) in modes and ('face+frame', True) in modes
+
+
+def test_host_frames_pipeline_equals_resident_batch(b0_handle):
+    """dfd_analyze_frames_host (pinned host frames, uploads overlapped with compute, batches of 4 out of 10 frames incl.
+    a ragged last batch) returns exactly what dfd_analyze_batch_device returns for the same frames resident in HBM."""
+    h = b0_handle
+    frames = np.stack([F.natural_like(480, 640, seed=70 + i) if i % 3 else F.face_frame(640, 480, i) for i in range(10)])
+    pinned = h.host_alloc(frames.shape)
+    pinned[:] = frames
+    try:
+        hb, hl, hp = h.analyze_frames_host(pinned, 4, confidence_threshold=0.3, max_faces=3, with_forensics=True)
+        fb = [[(40, 30, 200, 240), (300, 100, 224, 224)]] * 10
+        hfb, hfl, _ = h.analyze_frames_host(pinned, 4, forced_boxes=fb, max_faces=2)
+    finally:
+        h.host_free(pinned)
+    fd = h.alloc(frames.nbytes).upload(frames)
+    try:
+        db, dl, dp = h.analyze_batch_device(fd.ptr, 10, 480, 640, confidence_threshold=0.3, max_faces=3, with_forensics=True)
+        dfb, dfl, _ = h.analyze_batch_device(fd.ptr, 10, 480, 640, forced_boxes=fb, max_faces=2)
+    finally:
+        fd.free()
+    assert hb == db and hfb == dfb
+    assert all(np.array_equal(a, b) for a, b in zip(hl, dl)) and all(np.array_equal(a, b) for a, b in zip(hfl, dfl))
+    assert np.array_equal(hp, dp)
+    assert sum(len(b) for b in hb) > 0
