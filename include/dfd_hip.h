@@ -37,7 +37,8 @@ typedef enum dfd_status {
     DFD_ERR_HIP = -3,      /* a HIP runtime call failed                   */
     DFD_ERR_NO_DEVICE = -4,/* no usable gfx950 device                     */
     DFD_ERR_STATE = -5,    /* call order (e.g. detector weights not set)  */
-    DFD_ERR_CAPACITY = -6  /* batch larger than the handle was created for*/
+    DFD_ERR_CAPACITY = -6, /* batch larger than the handle was created for*/
+    DFD_ERR_UNSUPPORTED = -7 /* valid input of a kind this path does not handle (e.g. progressive JPEG) */
 } dfd_status;
 
 #define DFD_ABI_VERSION 1
@@ -97,6 +98,9 @@ int dfd_device_free(dfd_handle* h, void* dptr);
 int dfd_memcpy_h2d(dfd_handle* h, void* dst_dev, const void* src_host, size_t bytes);
 int dfd_memcpy_d2h(dfd_handle* h, void* dst_host, const void* src_dev, size_t bytes);
 int dfd_sync(dfd_handle* h);
+/* device address of the handle's frame buffer: the last frame uploaded by a host-frame entry point or decoded by
+ * dfd_decode_jpeg (packed BGR); valid until the next such call */
+void* dfd_frame_ptr(dfd_handle* h);
 /* HIP events on the handle's own stream (what bench.py times kernels with). */
 int dfd_timer_begin(dfd_handle* h);
 int dfd_timer_end(dfd_handle* h, float* elapsed_ms);
@@ -232,6 +236,26 @@ int dfd_analyze_frame(dfd_handle* h, int stream_id, const uint8_t* bgr, int heig
                       int stride, int full_forensics, float conf_thr, int max_faces, int apply_clahe,
                       double* scores_out, double* forensic_prob_out, int32_t* xywh_out,
                       int* n_faces_out, float* logits_out);
+
+/* ---- image decode at the HTTP edge -----------------------------------------------------
+ * cv2.imdecode(np.frombuffer(bytes), cv2.IMREAD_COLOR) of reference backend_server.py:139-145 for JPEG input (what
+ * the extension sends): entropy decoding on the host, dequantisation + libjpeg's islow IDCT + fancy chroma
+ * upsampling + YCbCr->RGB on the device - bit-identical to libjpeg's defaults.  8-bit sequential Huffman JPEGs, gray
+ * or YCbCr 4:4:4 / 4:2:2 / 4:2:0, one interleaved scan, restart intervals; anything else returns
+ * DFD_ERR_UNSUPPORTED (the host then decodes with its own library and calls dfd_analyze_frame).
+ * dfd_decode_jpeg: bgr_out may be NULL (size query through height / width; the frame stays on the device).
+ * dfd_analyze_jpeg: dfd_analyze_frame without the raw upload - the decoded frame never visits the host. */
+/* The host half alone (no GPU needed; tests pin it against libjpeg through the oracle's IDCT): info[14] = width,
+ * height, components, hmax, vmax, then per component (blocks_w, blocks_h, quantisation table index);
+ * qtables_out = 4 x 64 uint16 in natural order (NULL: skip); coef_out = int16 quantised coefficients in natural
+ * order, 64 per block, blocks row-major per component incl. MCU padding, components concatenated (NULL: count only).
+ * Errors of this function are reported through dfd_last_error(NULL). */
+int dfd_jpeg_coefficients(const uint8_t* jpeg, size_t len, int* info, uint16_t* qtables_out, int16_t* coef_out,
+                          size_t capacity, size_t* count);
+int dfd_decode_jpeg(dfd_handle* h, const uint8_t* jpeg, size_t len, uint8_t* bgr_out, size_t capacity, int* height, int* width);
+int dfd_analyze_jpeg(dfd_handle* h, int stream_id, const uint8_t* jpeg, size_t len, int full_forensics, float conf_thr,
+                     int max_faces, int apply_clahe, double* scores_out, double* forensic_prob_out, int32_t* xywh_out,
+                     int* n_faces_out, float* logits_out, int* height_out, int* width_out);
 
 /* ---- many frames, resident in HBM (throughput path; BASELINE.json configs[2]/[3]) ----------
  * frames_dev: n packed 8-bit BGR frames of height x width on the handle's device (row stride

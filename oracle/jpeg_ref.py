@@ -199,3 +199,41 @@ def roundtrip_pil(bgr: np.ndarray, quality: int = 90) -> np.ndarray:
     Image.fromarray(np.ascontiguousarray(bgr[..., ::-1])).save(buf, format="JPEG", quality=quality)
     buf.seek(0)
     return np.asarray(Image.open(buf).convert("RGB"))[..., ::-1].copy()
+
+
+# ------------------------------------------------------------------ decoding from coefficients
+def h2v1_fancy_upsample(p: np.ndarray) -> np.ndarray:
+    """jdsample.c h2v1_fancy_upsample: 3/4 + 1/4 with rounding 1 (even) / 2 (odd output columns); ends copy."""
+    h, w = p.shape
+    out = np.empty((h, 2 * w), np.int64)
+    left = np.concatenate([p[:, :1], p[:, :-1]], 1)
+    right = np.concatenate([p[:, 1:], p[:, -1:]], 1)
+    out[:, 0::2] = (3 * p + left + 1) >> 2
+    out[:, 1::2] = (3 * p + right + 2) >> 2
+    out[:, 0] = p[:, 0]
+    out[:, -1] = p[:, -1]
+    return out
+
+
+def decode_from_coefficients(info: dict) -> np.ndarray:
+    """What libjpeg does after entropy decoding, for the dict `_lib.jpeg_coefficients` returns: dequantise, islow
+    IDCT, crop each component plane to its real (downsampled) size, fancy upsample, YCbCr -> RGB.  -> BGR u8."""
+    W, H, n = info["width"], info["height"], info["components"]
+    planes, off = [], 0
+    for c, (bw, bh, tq) in enumerate(info["comps"]):
+        cnt = bw * bh * 64
+        blk = info["coef"][off:off + cnt].astype(np.int64).reshape(bh, bw, 8, 8)
+        off += cnt
+        q = info["qtables"][tq].astype(np.int64).reshape(8, 8)
+        planes.append(_unblocks(idct_islow(blk * q)))
+    y = planes[0][:H, :W]
+    if n == 1:
+        return np.repeat(y[..., None], 3, -1).astype(np.uint8)
+    hmax, vmax = info["hmax"], info["vmax"]
+    cw, ch = -(-W // hmax), -(-H // vmax)
+    cb, cr = planes[1][:ch, :cw], planes[2][:ch, :cw]
+    if hmax == 2 and vmax == 2:
+        cb, cr = h2v2_fancy_upsample(cb), h2v2_fancy_upsample(cr)
+    elif hmax == 2:
+        cb, cr = h2v1_fancy_upsample(cb), h2v1_fancy_upsample(cr)
+    return ycc_to_rgb(y, cb[:H, :W], cr[:H, :W])[..., ::-1].copy()

@@ -44,6 +44,7 @@ SIGNATURES = {
     "dfd_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dfd_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dfd_sync": (C.c_int, [C.c_void_p]),
+    "dfd_frame_ptr": (C.c_void_p, [C.c_void_p]),
     "dfd_timer_begin": (C.c_int, [C.c_void_p]),
     "dfd_timer_end": (C.c_int, [C.c_void_p, c_float_p]),
     "dfd_classify_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -71,6 +72,13 @@ SIGNATURES = {
                                 C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
     "dfd_analyze_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
+    "dfd_jpeg_coefficients": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.POINTER(C.c_size_t)]),
+    "dfd_decode_jpeg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int)]),
+    "dfd_analyze_jpeg": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int)]),
     "dfd_analyze_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                            C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),
@@ -120,6 +128,26 @@ def load() -> C.CDLL:
 
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def jpeg_coefficients(data: bytes):
+    """Host half of the JPEG decoder (no GPU): -> dict(width, height, components, hmax, vmax, comps=[(bw, bh, tq)],
+    qtables (4,64) uint16, coef int16 flat).  Raises DfdError (code -7 = flavour not decoded on the device path)."""
+    lib = load()
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    info = (C.c_int * 16)()
+    cnt = C.c_size_t()
+    rc = lib.dfd_jpeg_coefficients(buf, len(data), info, None, None, 0, C.byref(cnt))
+    if rc != 0:
+        raise DfdError(rc, (lib.dfd_last_error(None) or b"").decode())
+    q = np.zeros((4, 64), np.uint16)
+    coef = np.zeros(cnt.value, np.int16)
+    rc = lib.dfd_jpeg_coefficients(buf, len(data), info, _ptr(q), _ptr(coef), coef.size, C.byref(cnt))
+    if rc != 0:
+        raise DfdError(rc, (lib.dfd_last_error(None) or b"").decode())
+    n = info[2]
+    return {"width": info[0], "height": info[1], "components": n, "hmax": info[3], "vmax": info[4],
+            "comps": [(info[5 + 3 * c], info[6 + 3 * c], info[7 + 3 * c]) for c in range(n)], "qtables": q, "coef": coef}
 
 
 class DeviceBuffer:
@@ -379,6 +407,39 @@ class Handle:
                                                 _ptr(logits)))
         scores = {k: float(v) for k, v in zip(self.FORENSIC_KEYS, sc) if not np.isnan(v)}
         return scores, float(prob.value), [tuple(int(v) for v in boxes[i]) for i in range(n.value)], logits[: n.value].copy()
+
+    UNSUPPORTED = -7
+
+    def decode_jpeg(self, data: bytes) -> np.ndarray:
+        """cv2.imdecode(IMREAD_COLOR) for a sequential-Huffman JPEG -> (H,W,3) uint8 BGR.  DfdError with
+        .code == Handle.UNSUPPORTED for flavours the device path does not decode."""
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        hh, ww = C.c_int(), C.c_int()
+        self._check(self._lib.dfd_decode_jpeg(self._p, buf, len(data), None, 0, C.byref(hh), C.byref(ww)))
+        out = np.empty((hh.value, ww.value, 3), np.uint8)
+        self._check(self._lib.dfd_memcpy_d2h(self._p, _ptr(out), self.frame_ptr(), out.nbytes))
+        return out
+
+    def frame_ptr(self) -> int:
+        """device address of the last uploaded / decoded frame"""
+        return self._lib.dfd_frame_ptr(self._p)
+
+    def analyze_jpeg(self, data: bytes, full_forensics: bool, stream_id: int = 0, confidence_threshold: float = 0.5,
+                     max_faces: int = 16, apply_clahe: bool = True):
+        """analyze_frame from JPEG bytes, decoded on the device -> (scores, forensic prob, boxes, logits, (H, W))"""
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        max_faces = max(1, int(max_faces))
+        sc = np.empty(6, np.float64)
+        prob = C.c_double()
+        boxes = np.zeros((max_faces, 4), np.int32)
+        logits = np.zeros(max_faces, np.float32)
+        n, hh, ww = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.dfd_analyze_jpeg(self._p, int(stream_id), buf, len(data), int(bool(full_forensics)),
+                                               float(confidence_threshold), max_faces, int(bool(apply_clahe)), _ptr(sc),
+                                               C.byref(prob), _ptr(boxes), C.byref(n), _ptr(logits), C.byref(hh), C.byref(ww)))
+        scores = {k: float(v) for k, v in zip(self.FORENSIC_KEYS, sc) if not np.isnan(v)}
+        return (scores, float(prob.value), [tuple(int(v) for v in boxes[i]) for i in range(n.value)], logits[: n.value].copy(),
+                (hh.value, ww.value))
 
     def host_alloc(self, shape, dtype=np.uint8) -> np.ndarray:
         """A numpy array over pinned host memory (hipHostMalloc); release with host_free(arr)."""

@@ -4,8 +4,11 @@ Routes, methods, status codes and JSON keys follow reference backend_server.py:8
 contract the Chrome extension reads): ``POST /analyze`` (multipart field
 ``frame``), ``GET /health``, ``POST /reset``, ``GET /stats``; 400 for a missing/undecodable
 frame, 429 from the 100 ms rate limiter, 500 with ``{'error': ...}`` for anything else.  The
-per-request work is `DeepfakeDetector.analyze_request` (one GPU call).  Differences: images are
-decoded with Pillow (cv2 is not a dependency here), CORS headers are added by hand (no
+per-request work is `DeepfakeDetector.analyze_request` (one GPU call).  Differences: sequential-Huffman
+JPEGs (what the extension sends) are decoded on the GPU from the request bytes (dfd_analyze_jpeg: entropy decoding
+on the host, IDCT / upsampling / colour on the device, bit-identical to libjpeg) and everything else with
+Pillow (cv2 is not a dependency here); ``POST /analyze_batch`` takes several ``frame`` parts of one stream in one
+request; CORS headers are added by hand (no
 flask_cors), and the rate limiter and detector are guarded by locks (the reference shares them
 unsynchronised across Flask's worker threads, :57,62-80,275).
 """
@@ -120,11 +123,21 @@ def analyze_frame():
     try:
         if 'frame' not in request.files:
             return jsonify({'error': 'No frame provided'}), 400
-        frame = decode_image(request.files['frame'].read())
-        if frame is None:
-            return jsonify({'error': 'Invalid image format'}), 400
-        with _detector_lock:
-            response = detector.analyze_request(frame)
+        image_bytes = request.files['frame'].read()
+        response = None
+        if image_bytes[:2] == b'\xff\xd8':                        # JPEG: decode on the device, no raw upload
+            try:
+                with _detector_lock:
+                    response = detector.analyze_request(jpeg=image_bytes)
+            except runtime.DfdError as e:
+                if e.code not in (-7, -1):                          # unsupported flavour / not decodable here: Pillow decides
+                    raise
+        if response is None:
+            frame = decode_image(image_bytes)
+            if frame is None:
+                return jsonify({'error': 'Invalid image format'}), 400
+            with _detector_lock:
+                response = detector.analyze_request(frame)
         ms = (time.time() - start_time) * 1000
         # key order as the reference builds it (:178-195 / :213-225)
         bbox = response.pop('face_bbox', None)
@@ -136,6 +149,42 @@ def analyze_frame():
         return jsonify(response), 200
     except Exception as e:
         logger.error("Error analyzing frame: %s", e)
+        logger.error(traceback.format_exc())
+        return jsonify({'error': str(e)}), 500
+
+
+@app.route('/analyze_batch', methods=['POST'])
+def analyze_batch():
+    """Several consecutive frames of ONE stream in a single request (multipart parts all named ``frame``, in stream
+    order): the same per-frame flow and vote order as /analyze, one JSON object per frame under ``results``.  Not in the
+    reference (its extension posts one frame per request, throttled to 10 per second, backend_server.py:62-80); this
+    is the batched entry SURVEY 8(f) N2 asks for."""
+    start_time = time.time()
+    try:
+        files = request.files.getlist('frame')
+        if not files:
+            return jsonify({'error': 'No frame provided'}), 400
+        results = []
+        with _detector_lock:
+            for f in files:
+                data = f.read()
+                resp = None
+                if data[:2] == b'\xff\xd8':
+                    try:
+                        resp = detector.analyze_request(jpeg=data)
+                    except runtime.DfdError as e:
+                        if e.code not in (-7, -1):
+                            raise
+                if resp is None:
+                    frame = decode_image(data)
+                    if frame is None:
+                        return jsonify({'error': f'Invalid image format (frame {len(results)})'}), 400
+                    resp = detector.analyze_request(frame)
+                results.append(resp)
+        ms = (time.time() - start_time) * 1000
+        return jsonify({'success': True, 'frames': len(results), 'processing_time_ms': round(ms, 1), 'results': results}), 200
+    except Exception as e:
+        logger.error("Error analyzing batch: %s", e)
         logger.error(traceback.format_exc())
         return jsonify({'error': str(e)}), 500
 

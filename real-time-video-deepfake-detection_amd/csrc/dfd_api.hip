@@ -229,6 +229,8 @@ int dfd_sync(dfd_handle* h) {
     return DFD_OK;
 }
 
+void* dfd_frame_ptr(dfd_handle* h) { return h ? h->frame_buf.p : nullptr; }
+
 int dfd_timer_begin(dfd_handle* h) {
     if (!h) return DFD_ERR_ARG;
     DFD_HIP_TRY(h, hipEventRecord(h->ev0, h->stream));

@@ -110,6 +110,7 @@ struct dfd_handle {
     bool split_gemm = true;              // 1x1 / k x k convs on the bf16x3-split MFMA path (gemm_split.hip)
     bool act_bf16 = false;               // classifier activations stored as bf16 (fp32 arithmetic): configs[3]
     int bf16_planes = 3;                 // weight planes the bf16-activation GEMMs use: 3 = fp32-exact weights, 1 = bf16 weights
+    dfd::DevBuf jpeg_work;               // dfd_decode_jpeg: coefficients, component planes, quantisation tables
     dfd::DevBuf tap_buf;                 // fp32 staging for taps of bf16 buffers
     std::map<const float*, unsigned short*> wsplit;   // fp32 weight tensor -> its three-plane bf16 split
     dfd::S6Table* gemm = nullptr;        // split-GEMM tile per shape (measured by dfd_warmup, heuristic otherwise)
@@ -162,6 +163,14 @@ int mtcnn_align_batch_device(dfd_handle* h, const MtImage* imgs, int n, uint8_t*
 int mtcnn_align_device(dfd_handle* h, const uint8_t* img_dev, int hh, int ww, size_t stride, float* box_out, int* found,
                        const char* tap_name, std::vector<float>* tap, int* tap_dims);
 const uint8_t* mtcnn_face_dev(dfd_handle* h);
+
+// imgproc_api.hip: the per-frame work on a frame that is already in h->frame_buf
+int analyze_frame_resident(dfd_handle* h, int stream_id, int hh, int ww, int stride, int full_forensics, float conf_thr,
+                           int max_faces, int apply_clahe, double* scores_out, double* forensic_prob_out, int32_t* xywh_out,
+                           int* n_faces_out, float* logits_out);
+
+// jpeg_decode.hip: baseline JPEG bytes -> packed BGR frame in h->frame_buf (stride width * 3)
+int jpeg_decode_to_frame(dfd_handle* h, const uint8_t* jpeg, size_t len, int* hh, int* ww);
 
 // b0_plan.hip
 // three-plane bf16 split of a weight tensor of the handle, made on first use; null (+ error set) on failure

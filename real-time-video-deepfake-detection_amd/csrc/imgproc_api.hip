@@ -171,9 +171,39 @@ int dfd_analyze_frame(dfd_handle* h, int stream_id, const uint8_t* bgr, int hh, 
     int rc = ensure(h, &h->frame_buf, (size_t)hh * stride);
     if (rc) return rc;
     DFD_HIP_TRY(h, hipMemcpyAsync(h->frame_buf.p, bgr, (size_t)hh * stride, hipMemcpyHostToDevice, h->stream));
+    return analyze_frame_resident(h, stream_id, hh, ww, stride, full_forensics, conf_thr, max_faces, apply_clahe, scores_out,
+                                  forensic_prob_out, xywh_out, n_faces_out, logits_out);
+}
+
+// the same from JPEG bytes: the frame is decoded on the device (jpeg_decode.hip) instead of uploaded raw
+int dfd_analyze_jpeg(dfd_handle* h, int stream_id, const uint8_t* jpeg, size_t len, int full_forensics, float conf_thr,
+                     int max_faces, int apply_clahe, double* scores_out, double* forensic_prob_out, int32_t* xywh_out,
+                     int* n_faces_out, float* logits_out, int* height_out, int* width_out) {
+    if (!h) return DFD_ERR_ARG;
+    if (!jpeg || !scores_out || !forensic_prob_out || !xywh_out || !n_faces_out || !logits_out || max_faces <= 0)
+        return fail(h, DFD_ERR_ARG, "analyze_jpeg: bad pointer");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    int hh = 0, ww = 0;
+    int rc = jpeg_decode_to_frame(h, jpeg, len, &hh, &ww);
+    if (rc) return rc;
+    if (height_out) *height_out = hh;
+    if (width_out) *width_out = ww;
+    return analyze_frame_resident(h, stream_id, hh, ww, ww * 3, full_forensics, conf_thr, max_faces, apply_clahe, scores_out,
+                                  forensic_prob_out, xywh_out, n_faces_out, logits_out);
+}
+
+}  // extern "C"
+
+namespace dfd {
+// the frame is in h->frame_buf: forensics -> detect -> crop/CLAHE -> classify
+int analyze_frame_resident(dfd_handle* h, int stream_id, int hh, int ww, int stride, int full_forensics, float conf_thr,
+                           int max_faces, int apply_clahe, double* scores_out, double* forensic_prob_out, int32_t* xywh_out,
+                           int* n_faces_out, float* logits_out) {
+    int rc;
     const uint8_t* fd = (const uint8_t*)h->frame_buf.p;
     if ((rc = forensics_run(h, stream_id, fd, hh, ww, stride, full_forensics, scores_out, forensic_prob_out, nullptr))) return rc;
     *n_faces_out = 0;
+    if (!h->ssd || hh < 30 || ww < 30) return DFD_OK;              // no detector weights / tiny frame: no faces
     int n = 0;
     if ((rc = detect_run(h, fd, hh, ww, stride, conf_thr, xywh_out, nullptr, max_faces, &n))) return rc;
     *n_faces_out = n;
@@ -190,6 +220,9 @@ int dfd_analyze_frame(dfd_handle* h, int stream_id, const uint8_t* bgr, int hh, 
     }
     return DFD_OK;
 }
+}  // namespace dfd
+
+extern "C" {
 
 int dfd_resize_bgr(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride, int dh, int dw, uint8_t* out) {
     if (!h) return DFD_ERR_ARG;

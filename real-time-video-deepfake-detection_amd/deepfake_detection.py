@@ -169,10 +169,19 @@ class DeepfakeDetector:
             log.warning("face analysis error: %s", e)
             return None, None, None
 
-    def _frame_on_gpu(self, frame, max_faces):
-        """forensics + detection + per-face logits in one library call."""
+    def _frame_on_gpu(self, frame, max_faces, jpeg: Optional[bytes] = None):
+        """forensics + detection + per-face logits in one library call.  With `jpeg` the frame is decoded on the
+        device from the request's bytes (dfd_analyze_jpeg) instead of uploaded raw; returns its (H, W) as 4th item."""
         full = self._forensic_is_full()
         with self._lock:
+            if jpeg is not None:
+                scores, prob, boxes, logits, shape = self.handle.analyze_jpeg(
+                    jpeg, full, stream_id=self.frame_analyzer.stream_id, confidence_threshold=0.5, max_faces=max_faces)
+                number = self.frame_analyzer.frame_count
+                forensic = {'scores': scores, 'fake_probability': prob,
+                            'analysis_type': 'frame_forensic' if full else 'frame_forensic_fast', 'frame_number': number}
+                self.last_frame_forensic_result = forensic
+                return forensic, boxes, logits, shape
             if self.handle.has_detector:
                 scores, prob, boxes, logits = self.handle.analyze_frame(
                     frame, full, stream_id=self.frame_analyzer.stream_id, confidence_threshold=0.5, max_faces=max_faces)
@@ -228,13 +237,22 @@ class DeepfakeDetector:
         """`result_data` of `predict` - the name BASELINE.json's north_star uses."""
         return self.predict(frame)[3]
 
-    def analyze_request(self, frame):
+    def analyze_request(self, frame=None, *, jpeg: Optional[bytes] = None):
         """The /analyze flow of the reference server (backend_server.py:147-233): forensics BEFORE the
         frame counter moves, only faces[0] is classified, one vote per request.  Returns the response
-        dict without timing."""
-        frame = np.ascontiguousarray(frame)
-        small = frame.shape[0] < 30 or frame.shape[1] < 30
-        frame_forensic, faces, logits = self._frame_on_gpu(frame, max_faces=1)
+        dict without timing.  `jpeg`: the request's bytes, decoded on the device; raises
+        DfdError (code -7 / -1) when the library does not decode that file - the caller then passes a frame."""
+        if jpeg is not None:
+            if not self.handle.has_detector:
+                frame = self.handle.decode_jpeg(jpeg)              # frame_only mode has no fused JPEG entry point
+                jpeg = None
+            else:
+                frame_forensic, faces, logits, shape = self._frame_on_gpu(None, max_faces=1, jpeg=jpeg)
+                small = shape[0] < 30 or shape[1] < 30
+        if jpeg is None:
+            frame = np.ascontiguousarray(frame)
+            small = frame.shape[0] < 30 or frame.shape[1] < 30
+            frame_forensic, faces, logits = self._frame_on_gpu(frame, max_faces=1)
         n_detected = 0 if small else self._last_face_count(frame, faces)
         self.frame_count += 1
         tr = self.temporal_tracker

@@ -25,7 +25,7 @@ from typing import Dict, Optional
 import numpy as np
 
 from . import weights as W
-from ._lib import Handle
+from ._lib import DfdError, Handle  # noqa: F401  (re-exported: backend_server catches runtime.DfdError)
 
 log = logging.getLogger(__name__)
 _lock = threading.Lock()

@@ -101,3 +101,48 @@ def test_analyze_round_trip(client, pkg, b0_handle, fmt, name, kw):
     assert client.get("/stats").get_json()["history_length"] == 1
     client.post("/reset")
     assert client.get("/stats").get_json()["frame_count"] == 0
+
+
+@pytest.mark.gpu
+def test_jpeg_request_is_decoded_on_the_device_and_equals_the_pillow_path(client, pkg, b0_handle):
+    """/analyze on JPEG bytes goes through dfd_analyze_jpeg (no raw upload); the response equals what the Pillow-decode
+    path gives for the same bytes, and a progressive JPEG (not decoded on the device) still works through Pillow."""
+    pkg.runtime.set_default_handle(b0_handle)
+    frame = F.natural_like(480, 640, 33)
+    data = _encode(frame, "JPEG", quality=85)
+    srv = pkg.backend_server
+    client.post("/reset")
+    srv._last_request_time = 0.0
+    a = _post(client, data).get_json()
+    client.post("/reset")
+    want = srv.detector.analyze_request(srv.decode_image(data))           # host decode + raw upload
+    for k, v in want.items():
+        assert a[k] == v, k
+    client.post("/reset")
+    srv._last_request_time = 0.0
+    r = _post(client, _encode(frame, "JPEG", quality=85, progressive=True))
+    assert r.status_code == 200 and r.get_json()["success"] is True
+
+
+@pytest.mark.gpu
+def test_analyze_batch_equals_consecutive_single_requests(client, pkg, b0_handle):
+    pkg.runtime.set_default_handle(b0_handle)
+    srv = pkg.backend_server
+    frames = [F.natural_like(480, 640, 40 + i) if i % 3 else F.blank_frame(640, 480) for i in range(7)]
+    payloads = [_encode(f, "JPEG", quality=85) for f in frames]
+    client.post("/reset")
+    singles = []
+    for p in payloads:
+        srv._last_request_time = 0.0
+        singles.append(_post(client, p).get_json())
+    client.post("/reset")
+    r = client.post("/analyze_batch", data={"frame": [(io.BytesIO(p), f"f{i}.jpg") for i, p in enumerate(payloads)]},
+                    content_type="multipart/form-data")
+    assert r.status_code == 200, r.get_data()
+    b = r.get_json()
+    assert b["success"] is True and b["frames"] == 7 and len(b["results"]) == 7
+    for got, want in zip(b["results"], singles):
+        for k in ("analysis_mode", "faces_detected", "fake_probability", "frame_forensic_probability", "confidence_level",
+                  "frame_count"):
+            assert got[k] == want[k], k
+    assert client.post("/analyze_batch").status_code == 400
