@@ -26,10 +26,15 @@ import torch.nn.functional as F
 from . import imgproc_ref as I
 
 
-def preprocess(frame: np.ndarray, size: int, mean_bgr) -> torch.Tensor:
-    """cv2.resize + blobFromImage -> (1,3,size,size) float32, BGR order."""
+def preprocess(frame: np.ndarray, size: int, mean_bgr, in_scale=None, in_shift=None) -> torch.Tensor:
+    """cv2.resize + blobFromImage -> (1,3,size,size) float32, BGR order.  With in_scale / in_shift (an imported
+    topology whose data blob passes a BatchNorm/Scale before the first convolution): x * scale + shift instead of
+    x - mean (the shift already contains the mean)."""
     r = I.resize_linear_u8(frame, size, size).astype(np.float32)
-    r -= np.asarray(mean_bgr, np.float32)
+    if in_scale is None:
+        r -= np.asarray(mean_bgr, np.float32)
+    else:
+        r = r * np.asarray(in_scale, np.float32) + np.asarray(in_shift, np.float32)
     return torch.from_numpy(r).permute(2, 0, 1).unsqueeze(0).contiguous()
 
 
@@ -53,6 +58,14 @@ def run_trunk(sd: Mapping[str, torch.Tensor], layers, x: torch.Tensor, taps=None
             src = a[0]
             v = t[src]
             t[name] = v / torch.sqrt((v * v).sum(1, keepdim=True) + 1e-10) * sd[name + ".scale"].view(1, -1, 1, 1)
+        elif kind == "affine":
+            src, c, relu = a
+            y = t[src] * sd[name + ".scale"].view(1, -1, 1, 1) + sd[name + ".shift"].view(1, -1, 1, 1)
+            t[name] = F.relu(y) if relu else y
+        elif kind == "add":
+            src, other, c, relu = a
+            y = t[src] + t[other]
+            t[name] = F.relu(y) if relu else y
         if taps is not None:
             taps[name] = t[name]
     return t
@@ -128,7 +141,7 @@ def detection_output(boxes: np.ndarray, face_prob: np.ndarray, conf_thr, nms_thr
 @torch.no_grad()
 def forward(sd, arch, frame: np.ndarray, taps=None):
     """frame (BGR u8) -> DetectionOutput rows.  `arch` is the package's ssd_arch module."""
-    x = preprocess(frame, arch.INPUT, arch.MEAN_BGR)
+    x = preprocess(frame, arch.INPUT, arch.MEAN_BGR, getattr(arch, "IN_SCALE", None), getattr(arch, "IN_SHIFT", None))
     t = run_trunk(sd, arch.LAYERS, x, taps)
     loc, conf = heads(sd, arch.SOURCES, t)
     e = np.exp(conf - conf.max(1, keepdims=True))

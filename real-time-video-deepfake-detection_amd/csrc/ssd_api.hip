@@ -11,55 +11,64 @@ using namespace dfd;
 
 namespace dfd {
 
-enum SsdKind { SK_CONV1, SK_POOL, SK_CONV, SK_NORM };
+enum SsdKind { SK_CONV1 = 0, SK_POOL = 1, SK_CONV = 2, SK_NORM = 3, SK_AFFINE = 4, SK_ADD = 5 };
 
+// One layer of the detector's trunk.  The table is either the built-in one below (this build's statement of the
+// res10 family: BatchNorm/Scale folded, post-activation blocks) or comes from the weights blob ("ssd.plan" +
+// "ssd.names", written by weights.pack_ssd_tensors for an architecture that caffe_io built from a deploy.prototxt:
+// SURVEY section 8(f) N3).  src / res name the producing layers ("data" = the 300x300 input).
 struct SsdLayer {
-    const char* name;
+    std::string name;
     SsdKind kind;
-    const char* src;
+    std::string src;
     int cin, cout, k, stride, pad, dil;
     bool relu;
-    const char* res;
+    std::string res;           // conv: tensor added before the activation; add: second operand; "" = none
 };
 
 static const SsdLayer kSsdLayers[] = {
-    {"conv1", SK_CONV1, "data", 3, 32, 7, 2, 3, 1, true, nullptr},
-    {"pool1", SK_POOL, "conv1", 32, 32, 3, 2, 0, 1, false, nullptr},
-    {"res2a", SK_CONV, "pool1", 32, 32, 3, 1, 1, 1, true, nullptr},
+    {"conv1", SK_CONV1, "data", 3, 32, 7, 2, 3, 1, true, ""},
+    {"pool1", SK_POOL, "conv1", 32, 32, 3, 2, 0, 1, false, ""},
+    {"res2a", SK_CONV, "pool1", 32, 32, 3, 1, 1, 1, true, ""},
     {"res2b", SK_CONV, "res2a", 32, 32, 3, 1, 1, 1, true, "pool1"},
-    {"res3p", SK_CONV, "res2b", 32, 128, 1, 2, 0, 1, false, nullptr},
-    {"res3a", SK_CONV, "res2b", 32, 128, 3, 2, 1, 1, true, nullptr},
+    {"res3p", SK_CONV, "res2b", 32, 128, 1, 2, 0, 1, false, ""},
+    {"res3a", SK_CONV, "res2b", 32, 128, 3, 2, 1, 1, true, ""},
     {"res3b", SK_CONV, "res3a", 128, 128, 3, 1, 1, 1, true, "res3p"},
-    {"res4p", SK_CONV, "res3b", 128, 256, 1, 2, 0, 1, false, nullptr},
-    {"res4a", SK_CONV, "res3b", 128, 256, 3, 2, 1, 1, true, nullptr},
+    {"res4p", SK_CONV, "res3b", 128, 256, 1, 2, 0, 1, false, ""},
+    {"res4a", SK_CONV, "res3b", 128, 256, 3, 2, 1, 1, true, ""},
     {"res4b", SK_CONV, "res4a", 256, 256, 3, 1, 1, 1, true, "res4p"},
-    {"res5a", SK_CONV, "res4b", 256, 256, 3, 1, 2, 2, true, nullptr},
+    {"res5a", SK_CONV, "res4b", 256, 256, 3, 1, 2, 2, true, ""},
     {"res5b", SK_CONV, "res5a", 256, 256, 3, 1, 2, 2, true, "res4b"},
-    {"conv6_1", SK_CONV, "res5b", 256, 128, 1, 1, 0, 1, true, nullptr},
-    {"conv6_2", SK_CONV, "conv6_1", 128, 256, 3, 2, 1, 1, true, nullptr},
-    {"conv7_1", SK_CONV, "conv6_2", 256, 64, 1, 1, 0, 1, true, nullptr},
-    {"conv7_2", SK_CONV, "conv7_1", 64, 128, 3, 2, 1, 1, true, nullptr},
-    {"conv8_1", SK_CONV, "conv7_2", 128, 64, 1, 1, 0, 1, true, nullptr},
-    {"conv8_2", SK_CONV, "conv8_1", 64, 128, 3, 1, 0, 1, true, nullptr},
-    {"conv9_1", SK_CONV, "conv8_2", 128, 64, 1, 1, 0, 1, true, nullptr},
-    {"conv9_2", SK_CONV, "conv9_1", 64, 128, 3, 1, 0, 1, true, nullptr},
-    {"norm3", SK_NORM, "res3b", 128, 128, 1, 1, 0, 1, false, nullptr},
+    {"conv6_1", SK_CONV, "res5b", 256, 128, 1, 1, 0, 1, true, ""},
+    {"conv6_2", SK_CONV, "conv6_1", 128, 256, 3, 2, 1, 1, true, ""},
+    {"conv7_1", SK_CONV, "conv6_2", 256, 64, 1, 1, 0, 1, true, ""},
+    {"conv7_2", SK_CONV, "conv7_1", 64, 128, 3, 2, 1, 1, true, ""},
+    {"conv8_1", SK_CONV, "conv7_2", 128, 64, 1, 1, 0, 1, true, ""},
+    {"conv8_2", SK_CONV, "conv8_1", 64, 128, 3, 1, 0, 1, true, ""},
+    {"conv9_1", SK_CONV, "conv8_2", 128, 64, 1, 1, 0, 1, true, ""},
+    {"conv9_2", SK_CONV, "conv9_1", 64, 128, 3, 1, 0, 1, true, ""},
+    {"norm3", SK_NORM, "res3b", 128, 128, 1, 1, 0, 1, false, ""},
 };
 
-struct SsdSource { const char* tensor; int c, map; double mn, mx; int nar; double ar[2]; double step; };
+struct SsdSource { std::string tensor; int c, map; double mn, mx; int nar; double ar[2]; double step; };
 static const SsdSource kSsdSources[6] = {
     {"norm3", 128, 38, 30, 60, 1, {2, 0}, 8},     {"res5b", 256, 19, 60, 111, 2, {2, 3}, 16},
     {"conv6_2", 256, 10, 111, 162, 2, {2, 3}, 32}, {"conv7_2", 128, 5, 162, 213, 2, {2, 3}, 64},
     {"conv8_2", 128, 3, 213, 264, 1, {2, 0}, 100}, {"conv9_2", 128, 1, 264, 315, 1, {2, 0}, 300},
 };
-constexpr int SSD_IN = 300, SSD_KEEP = 200;
-constexpr float SSD_CONF = 0.01f;
-constexpr double SSD_NMS = 0.45;
+constexpr int SSD_IN = 300, SSD_KEEP = 200, SSD_TOPK = 400;
 
 struct SsdTensor { int c = 0, size = 0; size_t off = 0; };    // NHWC [n][size][size][c], offset in floats per image
 
 struct SsdState {
     bool ready = false;
+    std::vector<SsdLayer> layers;
+    std::vector<SsdSource> sources;          // exactly six
+    float in_scale[3] = {1.f, 1.f, 1.f}, in_shift[3] = {-104.f, -177.f, -123.f};      // conv1 input: x * scale + shift
+    float var[4] = {0.1f, 0.1f, 0.2f, 0.2f};
+    float conf_thr = 0.01f;
+    double nms_thr = 0.45;
+    int keep_top_k = SSD_KEEP;
     std::map<std::string, SsdTensor> t;
     size_t floats_per_image = 0;
     int n_priors = 0;
@@ -95,36 +104,106 @@ static bool conv_gemm(dfd_handle* h, const float* X, const float* W, const float
     return launch_conv_gemm(X, W, bias, R, Y, n, g, Cout, act, res_first, h->stream);
 }
 
+// The layer table: "ssd.plan" [L][10] (kind, src index, res index, cin, cout, k, stride, pad, dil, relu; index -1 =
+// "data" / none), "ssd.names" [L][32] (character codes), "ssd.srcs" [6][9] (layer index, channels, map, min, max,
+// number of aspect ratios, ar0, ar1, step), "ssd.det" [15] (input size, conv1 input scale b,g,r, shift b,g,r,
+// variances x4, nms threshold, top_k, keep_top_k, confidence threshold) - all float32, written by
+// weights.pack_ssd_tensors.  A blob without them runs the built-in table.
+static int load_plan(dfd_handle* h, SsdState* S) {
+    auto plan = h->tensors.find("ssd.plan");
+    if (plan == h->tensors.end()) {
+        S->layers.assign(std::begin(kSsdLayers), std::end(kSsdLayers));
+        S->sources.assign(std::begin(kSsdSources), std::end(kSsdSources));
+        return DFD_OK;
+    }
+    auto names = h->tensors.find("ssd.names"), srcs = h->tensors.find("ssd.srcs"), det = h->tensors.find("ssd.det");
+    if (names == h->tensors.end() || srcs == h->tensors.end() || det == h->tensors.end())
+        return fail(h, DFD_ERR_BLOB, "detector plan: ssd.names / ssd.srcs / ssd.det missing");
+    const size_t L = plan->second.count / 10;
+    if (plan->second.count != L * 10 || names->second.count != L * 32 || srcs->second.count != 6 * 9 || det->second.count != 15 || L == 0 || L > 256)
+        return fail(h, DFD_ERR_BLOB, "detector plan: malformed tables");
+    std::vector<float> pv(L * 10), nv(L * 32), sv(54), dv(15);
+    DFD_HIP_TRY(h, hipMemcpy(pv.data(), plan->second.dev, pv.size() * 4, hipMemcpyDeviceToHost));
+    DFD_HIP_TRY(h, hipMemcpy(nv.data(), names->second.dev, nv.size() * 4, hipMemcpyDeviceToHost));
+    DFD_HIP_TRY(h, hipMemcpy(sv.data(), srcs->second.dev, sv.size() * 4, hipMemcpyDeviceToHost));
+    DFD_HIP_TRY(h, hipMemcpy(dv.data(), det->second.dev, dv.size() * 4, hipMemcpyDeviceToHost));
+    auto name_of = [&](int i) -> std::string {
+        if (i < 0) return "data";
+        std::string s;
+        for (int k = 0; k < 32 && nv[(size_t)i * 32 + k] != 0.f; ++k) s.push_back((char)(int)nv[(size_t)i * 32 + k]);
+        return s;
+    };
+    for (size_t i = 0; i < L; ++i) {
+        const float* r = &pv[i * 10];
+        const int kind = (int)r[0], src = (int)r[1], res = (int)r[2];
+        if (kind < 0 || kind > 5 || src >= (int)i || res >= (int)i) return fail(h, DFD_ERR_BLOB, "detector plan: bad row %zu", i);
+        SsdLayer Ly{name_of((int)i), (SsdKind)kind, name_of(src), (int)r[3], (int)r[4], (int)r[5], (int)r[6], (int)r[7], (int)r[8],
+                    r[9] != 0.f, res >= 0 ? name_of(res) : std::string()};
+        if (Ly.name.empty() || Ly.name == "data") return fail(h, DFD_ERR_BLOB, "detector plan: bad layer name in row %zu", i);
+        S->layers.push_back(Ly);
+    }
+    for (int s = 0; s < 6; ++s) {
+        const float* r = &sv[(size_t)s * 9];
+        const int li = (int)r[0];
+        if (li < 0 || li >= (int)L || (int)r[5] < 1 || (int)r[5] > 2) return fail(h, DFD_ERR_BLOB, "detector plan: bad source %d", s);
+        S->sources.push_back(SsdSource{name_of(li), (int)r[1], (int)r[2], r[3], r[4], (int)r[5], {r[6], r[7]}, r[8]});
+    }
+    if ((int)dv[0] != SSD_IN) return fail(h, DFD_ERR_BLOB, "detector plan: input size %d (this build resizes to %d)", (int)dv[0], SSD_IN);
+    for (int c = 0; c < 3; ++c) { S->in_scale[c] = dv[1 + c]; S->in_shift[c] = dv[4 + c]; }
+    for (int c = 0; c < 4; ++c) S->var[c] = dv[7 + c];
+    S->nms_thr = (double)dv[11];
+    S->keep_top_k = (int)dv[13];
+    S->conf_thr = dv[14];
+    if ((int)dv[12] != SSD_TOPK || S->keep_top_k < 1 || S->keep_top_k > SSD_KEEP)
+        return fail(h, DFD_ERR_BLOB, "detector plan: DetectionOutput top_k must be %d and keep_top_k <= %d", SSD_TOPK, SSD_KEEP);
+    return DFD_OK;
+}
+
 // shapes, per-image workspace layout and the prior table
 int ssd_init(dfd_handle* h) {
-    if (h->tensors.find("ssd.conv1.w") == h->tensors.end()) return DFD_OK;      // blob without a detector
+    if (h->tensors.find("ssd.conv1.w") == h->tensors.end() && h->tensors.find("ssd.plan") == h->tensors.end())
+        return DFD_OK;                                                          // blob without a detector
     SsdState* S = new SsdState();
     h->ssd = S;
+    int prc = load_plan(h, S);
+    if (prc) return prc;
     SsdTensor data;
     data.c = 3; data.size = SSD_IN;
     S->t["data"] = data;
     size_t off = 0;
-    for (const SsdLayer& L : kSsdLayers) {
+    for (const SsdLayer& L : S->layers) {
+        if (S->t.find(L.src) == S->t.end() || (!L.res.empty() && S->t.find(L.res) == S->t.end()))
+            return fail(h, DFD_ERR_BLOB, "detector plan: layer %s reads a tensor that no earlier layer produces", L.name.c_str());
         const SsdTensor& src = S->t[L.src];
+        if (src.c != L.cin) return fail(h, DFD_ERR_BLOB, "detector plan: layer %s expects %d input channels, %s has %d", L.name.c_str(), L.cin, L.src.c_str(), src.c);
         SsdTensor o;
         o.c = L.cout;
         if (L.kind == SK_POOL) o.size = (src.size - L.k + L.stride - 1) / L.stride + 1;            // ceil mode
-        else if (L.kind == SK_NORM) o.size = src.size;
+        else if (L.kind == SK_NORM || L.kind == SK_AFFINE || L.kind == SK_ADD) o.size = src.size;
         else o.size = (src.size + 2 * L.pad - L.dil * (L.k - 1) - 1) / L.stride + 1;
+        // what the kernels are built for
+        if (L.kind == SK_CONV1 && !(L.k == 7 && L.stride == 2 && L.pad == 3 && L.cin == 3 && L.cout == 32 && L.src == "data"))
+            return fail(h, DFD_ERR_BLOB, "detector plan: the first convolution must be 7x7 stride 2 pad 3, 3 -> 32 channels");
+        if (L.kind == SK_POOL && !(L.k == 3 && L.stride == 2 && L.pad == 0 && L.cin % 4 == 0))
+            return fail(h, DFD_ERR_BLOB, "detector plan: pooling %s must be 3x3 stride 2 (ceil mode)", L.name.c_str());
+        if (L.kind == SK_NORM && L.cin != 128) return fail(h, DFD_ERR_BLOB, "detector plan: Normalize is built for 128 channels");
+        if (L.kind == SK_CONV && L.cin % 32 != 0) return fail(h, DFD_ERR_BLOB, "detector plan: convolution %s: C_in %d is not a multiple of 32", L.name.c_str(), L.cin);
+        if ((L.kind == SK_AFFINE || L.kind == SK_ADD) && L.cin % 4 != 0) return fail(h, DFD_ERR_BLOB, "detector plan: %s: channels must be a multiple of 4", L.name.c_str());
         o.off = off;
         off += ((size_t)o.size * o.size * o.c + 63) & ~(size_t)63;
         S->t[L.name] = o;
     }
     int first = 0;
     for (int s = 0; s < 6; ++s) {
-        const SsdSource& src = kSsdSources[s];
+        const SsdSource& src = S->sources[s];
+        if (S->t.find(src.tensor) == S->t.end()) return fail(h, DFD_ERR_BLOB, "detector plan: source %s is not a layer", src.tensor.c_str());
         const int p = 2 + 2 * src.nar;
         SsdTensor o;
         o.c = p * 6; o.size = src.map; o.off = off;
         off += ((size_t)o.size * o.size * o.c + 63) & ~(size_t)63;
         S->t[std::string(src.tensor) + ".head"] = o;
         if (S->t[src.tensor].size != src.map || S->t[src.tensor].c != src.c)
-            return fail(h, DFD_ERR_STATE, "detector plan: source %s has the wrong shape", src.tensor);
+            return fail(h, DFD_ERR_STATE, "detector plan: source %s has the wrong shape", src.tensor.c_str());
         first += src.map * src.map * p;
     }
     S->floats_per_image = off;
@@ -133,7 +212,7 @@ int ssd_init(dfd_handle* h) {
     std::vector<float> tab((size_t)first * 4);
     size_t k = 0;
     for (int s = 0; s < 6; ++s) {
-        const SsdSource& src = kSsdSources[s];
+        const SsdSource& src = S->sources[s];
         std::vector<std::pair<double, double>> sizes = {{src.mn, src.mn}, {std::sqrt(src.mn * src.mx), std::sqrt(src.mn * src.mx)}};
         for (int a = 0; a < src.nar; ++a) {
             const double r = std::sqrt(src.ar[a]);
@@ -158,14 +237,15 @@ int ssd_init(dfd_handle* h) {
     S->prior_tab = static_cast<float*>(d);
     // every weight tensor must be present with the planned size
     bool ok = true;
-    for (const SsdLayer& L : kSsdLayers) {
+    for (const SsdLayer& L : S->layers) {
         const std::string q = std::string("ssd.") + L.name;
         if (L.kind == SK_CONV1 || L.kind == SK_CONV) {
             wt(h, q + ".w", (size_t)L.cout * L.k * L.k * L.cin, &ok);
             wt(h, q + ".b", L.cout, &ok);
         } else if (L.kind == SK_NORM) wt(h, q + ".scale", L.cout, &ok);
+        else if (L.kind == SK_AFFINE) { wt(h, q + ".scale", L.cout, &ok); wt(h, q + ".shift", L.cout, &ok); }
     }
-    for (const SsdSource& src : kSsdSources) {
+    for (const SsdSource& src : S->sources) {
         const int p = 2 + 2 * src.nar;
         wt(h, std::string("ssd.") + src.tensor + ".head.w", (size_t)p * 6 * 9 * src.c, &ok);
         wt(h, std::string("ssd.") + src.tensor + ".head.b", p * 6, &ok);
@@ -195,7 +275,6 @@ int ssd_forward(dfd_handle* h, const uint8_t* in300, int n, const char* tap_name
     auto ptr = [&](const std::string& name) { return base + S->t[name].off * n; };
     bool ok = true;
     auto W_ = [&](const std::string& nm, size_t c) { return wt(h, nm, c, &ok); };
-    const float mean[3] = {104.0f, 177.0f, 123.0f};
     bool tapped = false;
     auto tap = [&](const std::string& name) -> int {
         if (!tap_name || tapped || name != tap_name) return DFD_OK;
@@ -208,13 +287,22 @@ int ssd_forward(dfd_handle* h, const uint8_t* in300, int n, const char* tap_name
         tapped = true;
         return DFD_OK;
     };
-    for (const SsdLayer& L : kSsdLayers) {
+    for (const SsdLayer& L : S->layers) {
         const SsdTensor& src = S->t[L.src];
         const SsdTensor& dst = S->t[L.name];
         const std::string q = std::string("ssd.") + L.name;
         switch (L.kind) {
             case SK_CONV1:
-                launch_ssd_conv1(in300, W_(q + ".w", 147 * 32), W_(q + ".b", 32), ptr(L.name), n, mean, s);
+                launch_ssd_conv1(in300, W_(q + ".w", 147 * 32), W_(q + ".b", 32), ptr(L.name), n, S->in_scale, S->in_shift,
+                                 L.relu, s);
+                break;
+            case SK_AFFINE:
+                launch_channel_affine(ptr(L.src), W_(q + ".scale", L.cout), W_(q + ".shift", L.cout), nullptr, ptr(L.name),
+                                      (long long)n * src.size * src.size, L.cout, L.relu, s);
+                break;
+            case SK_ADD:
+                launch_channel_affine(ptr(L.src), nullptr, nullptr, ptr(L.res), ptr(L.name),
+                                      (long long)n * src.size * src.size, L.cout, L.relu, s);
                 break;
             case SK_POOL:
                 launch_maxpool3s2(ptr(L.src), ptr(L.name), n, src.size, dst.size, src.c, s);
@@ -227,9 +315,9 @@ int ssd_forward(dfd_handle* h, const uint8_t* in300, int n, const char* tap_name
                 g.H = g.W = src.size; g.Ho = g.Wo = dst.size; g.Cin = L.cin; g.ksize = L.k; g.stride = L.stride;
                 g.pad = L.pad; g.dil = L.dil;
                 if (!conv_gemm(h, ptr(L.src), W_(q + ".w", (size_t)L.cout * L.k * L.k * L.cin), W_(q + ".b", L.cout),
-                               L.res ? ptr(L.res) : nullptr, ptr(L.name), n, g, L.cout,
+                               !L.res.empty() ? ptr(L.res) : nullptr, ptr(L.name), n, g, L.cout,
                                L.relu ? ACT_RELU : ACT_NONE, true))
-                    return fail(h, DFD_ERR_STATE, "detector layer %s: C_in not a multiple of 32", L.name);
+                    return fail(h, DFD_ERR_STATE, "detector layer %s: C_in not a multiple of 32", L.name.c_str());
                 break;
             }
         }
@@ -239,7 +327,7 @@ int ssd_forward(dfd_handle* h, const uint8_t* in300, int n, const char* tap_name
     H.prior_tab = S->prior_tab;
     int first = 0;
     for (int i = 0; i < 6; ++i) {
-        const SsdSource& src = kSsdSources[i];
+        const SsdSource& src = S->sources[i];
         const int p = 2 + 2 * src.nar;
         const std::string hn = std::string(src.tensor) + ".head", q = std::string("ssd.") + src.tensor + ".head";
         ConvGeom g;
@@ -255,9 +343,8 @@ int ssd_forward(dfd_handle* h, const uint8_t* in300, int n, const char* tap_name
     }
     H.first[6] = first;
     if (!ok) return DFD_ERR_BLOB;
-    const float var[4] = {0.1f, 0.1f, 0.2f, 0.2f};
-    launch_ssd_decode(H, (float*)S->boxes.p, (float*)S->prob.p, n, S->n_priors, (float)SSD_IN, var, s);
-    launch_ssd_nms((const float*)S->boxes.p, (const float*)S->prob.p, n, S->n_priors, SSD_CONF, SSD_NMS, SSD_KEEP,
+    launch_ssd_decode(H, (float*)S->boxes.p, (float*)S->prob.p, n, S->n_priors, (float)SSD_IN, S->var, s);
+    launch_ssd_nms((const float*)S->boxes.p, (const float*)S->prob.p, n, S->n_priors, S->conf_thr, S->nms_thr, S->keep_top_k,
                    (float*)S->rows.p, (int*)S->count.p, s);
     if (tap_name && !tapped) {
         const std::string tn = tap_name;

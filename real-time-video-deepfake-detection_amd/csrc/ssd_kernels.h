@@ -14,8 +14,15 @@ struct SsdHeads {
     int map[6];                // map edge
 };
 
-void launch_ssd_conv1(const uint8_t* img, const float* w, const float* b, float* y, int n, const float mean_bgr[3],
-                      hipStream_t s);
+// 7x7 s2 pad 3 conv from the resized u8 BGR image; inside the image a pixel enters as x * in_scale[c] + in_shift[c]
+// (blobFromImage's mean subtraction, and a BatchNorm/Scale on the data blob where the prototxt has one), outside
+// it as 0 (Caffe pads the transformed blob)
+void launch_ssd_conv1(const uint8_t* img, const float* w, const float* b, float* y, int n, const float in_scale[3],
+                      const float in_shift[3], bool relu, hipStream_t s);
+// y = [relu](x * scale[c] + shift[c]) (scale/shift may be null: 1 / 0) (+ add, before the relu); NHWC fp32, C % 4 == 0:
+// a BatchNorm+Scale(+ReLU) that cannot be folded into a convolution (pre-activation ResNet), or an Eltwise SUM
+void launch_channel_affine(const float* x, const float* scale, const float* shift, const float* add, float* y,
+                           long long npix, int C, bool relu, hipStream_t s);
 void launch_maxpool3s2(const float* x, float* y, int n, int H, int Ho, int C, hipStream_t s);
 void launch_l2norm128(const float* x, const float* scale, float* y, long long npix, hipStream_t s);
 void launch_ssd_decode(const SsdHeads& H, float* boxes, float* prob, int n, int n_priors, float image_size,

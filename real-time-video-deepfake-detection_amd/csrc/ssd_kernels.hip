@@ -18,7 +18,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // thread = (output pixel, 4 of the 32 output channels); weights [7][7][3][32] staged in LDS
 __global__ __launch_bounds__(256) void ssd_conv1_kernel(const uint8_t* __restrict__ img, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y, int n_img,
-                                                        float mb, float mg, float mr) {
+                                                        float sb, float sg, float sr, float hb, float hg, float hr, int relu) {
     __shared__ float ws[147 * 32];
     for (int i = threadIdx.x; i < 147 * 32; i += 256) ws[i] = w[i];
     __syncthreads();
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void ssd_conv1_kernel(const uint8_t* __restric
     if (pix >= (long long)n_img * 150 * 150) return;
     const int ox = (int)(pix % 150), oy = (int)((pix / 150) % 150), n = (int)(pix / 22500);
     const uint8_t* src = img + (size_t)n * 300 * 300 * 3;
-    const float mean[3] = {mb, mg, mr};
+    const float sc[3] = {sb, sg, sr}, sh[3] = {hb, hg, hr};
     v4f acc = *reinterpret_cast<const v4f*>(b + 4 * cg);
     // (taps outside the image contribute 0: Caffe pads the mean-subtracted blob with zeros.  The branchy form is
     // kept on purpose: with all 147 byte loads made unconditional and unrolled the kernel ran 20x slower.)
@@ -42,20 +42,41 @@ __global__ __launch_bounds__(256) void ssd_conv1_kernel(const uint8_t* __restric
             const uint8_t* p = src + ((size_t)iy * 300 + ix) * 3;
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
-                const float v = (float)p[ci] - mean[ci];
+                const float v = (float)p[ci] * sc[ci] + sh[ci];
                 acc += v * *reinterpret_cast<const v4f*>(&ws[((ky * 7 + kx) * 3 + ci) * 32 + 4 * cg]);
             }
         }
     }
-    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
     *reinterpret_cast<v4f*>(y + (size_t)pix * 32 + 4 * cg) = acc;
 }
 
-void launch_ssd_conv1(const uint8_t* img, const float* w, const float* b, float* y, int n, const float mean_bgr[3],
-                      hipStream_t s) {
+void launch_ssd_conv1(const uint8_t* img, const float* w, const float* b, float* y, int n, const float in_scale[3],
+                      const float in_shift[3], bool relu, hipStream_t s) {
     const long long threads = (long long)n * 150 * 150 * 8;
     hipLaunchKernelGGL(ssd_conv1_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, img, w, b, y, n,
-                       mean_bgr[0], mean_bgr[1], mean_bgr[2]);
+                       in_scale[0], in_scale[1], in_scale[2], in_shift[0], in_shift[1], in_shift[2], relu ? 1 : 0);
+}
+
+// ------------------------------------------------------------------- per-channel affine / add
+__global__ __launch_bounds__(256) void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const float* __restrict__ add,
+                                                             float* __restrict__ y, long long nvec, int c4, int relu) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    const int c = (int)(i % c4) * 4;
+    v4f v = *reinterpret_cast<const v4f*>(x + i * 4);
+    if (scale) v = v * *reinterpret_cast<const v4f*>(scale + c) + *reinterpret_cast<const v4f*>(shift + c);
+    if (add) v += *reinterpret_cast<const v4f*>(add + i * 4);
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<v4f*>(y + i * 4) = v;
+}
+
+void launch_channel_affine(const float* x, const float* scale, const float* shift, const float* add, float* y,
+                           long long npix, int C, bool relu, hipStream_t s) {
+    const long long nvec = npix * (C / 4);
+    hipLaunchKernelGGL(channel_affine_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, x, scale, shift, add, y,
+                       nvec, C / 4, relu ? 1 : 0);
 }
 
 // -------------------------------------------------------------------------------- maxpool

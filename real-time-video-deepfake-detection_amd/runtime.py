@@ -5,7 +5,9 @@ reference deepfake_detection.py:30-90), created lazily on first use.
 Weights (the reference tree ships none):
   classifier  ``$DFD_WEIGHTS`` or ``weights/best_model.pth`` next to the package (reference checkpoint layout),
               else seeded random-init weights with a warning (`model_loaded` stays False, /health says so);
-  detector    ``$DFD_SSD_WEIGHTS``: an .npz / .pth state dict in `ssd_arch` naming.  Without it there is NO detector:
+  detector    ``$DFD_SSD_WEIGHTS``: the reference's Caffe pair (face_detection.py:19-24) - a .caffemodel with its
+              deploy.prototxt (``$DFD_SSD_PROTOTXT``, default: ``deploy.prototxt`` next to it), read by `caffe_io`
+              into a detector plan - or an .npz / .pth state dict in `ssd_arch` naming.  Without it there is NO detector:
               the handle is built without one, `detect_bounding_box` returns [] and every frame is analysed in
               'frame_only' mode (where the reference, whose model files are missing too, face_detection.py:22-34,
               falls back to a Haar cascade - not built here, DESIGN.md section 8);
@@ -56,8 +58,19 @@ def default_state_dict() -> Dict[str, np.ndarray]:
     return _state
 
 
-def load_detector_weights(path: str) -> Dict[str, np.ndarray]:
-    """an .npz / .pth state dict in ssd_arch naming"""
+def load_detector_weights(path: str):
+    """-> (state dict, arch or None).  .caffemodel: (deploy.prototxt + caffemodel) through caffe_io -> its own layer
+    plan; .npz / .pth: a state dict in ssd_arch naming (built-in topology)."""
+    if path.endswith(".caffemodel"):
+        from . import caffe_io
+
+        proto = os.environ.get("DFD_SSD_PROTOTXT", os.path.join(os.path.dirname(path), "deploy.prototxt"))
+        arch, sd = caffe_io.load_caffe_detector(proto, path)
+        return sd, arch
+    return _load_state_dict(path), None
+
+
+def _load_state_dict(path: str) -> Dict[str, np.ndarray]:
     if path.endswith(".npz"):
         with np.load(path) as z:
             return {k: np.asarray(z[k], np.float32) for k in z.files}
@@ -73,10 +86,10 @@ def default_handle() -> Handle:
         if _default is None:
             seed = int(os.environ.get("DFD_SEED", "0"))
             synthetic = os.environ.get("DFD_SYNTHETIC_WEIGHTS", "0") == "1"
-            ssd = None
+            ssd, ssd_arch = None, None
             path = os.environ.get("DFD_SSD_WEIGHTS")
             if path:
-                ssd = load_detector_weights(path)
+                ssd, ssd_arch = load_detector_weights(path)
                 detector_loaded = True
                 log.info("loaded detector weights %s", path)
             elif synthetic:
@@ -97,7 +110,7 @@ def default_handle() -> Handle:
                     log.warning("DFD_SYNTHETIC_WEIGHTS=1: random-init MTCNN cascade - alignments are meaningless")
                 else:
                     log.warning("no MTCNN weights ($DFD_MTCNN_WEIGHTS): the align stage is left out")
-            _default = Handle(W.pack_all(default_state_dict(), ssd, mt), device=device_index(),
+            _default = Handle(W.pack_all(default_state_dict(), ssd, mt, ssd_arch=ssd_arch), device=device_index(),
                               max_batch=int(os.environ.get("DFD_MAX_BATCH", "16")))
         return _default
 

@@ -18,6 +18,10 @@ from typing import Dict, List, Tuple
 
 INPUT = 300
 MEAN_BGR = (104.0, 177.0, 123.0)          # reference face_detection.py:78
+# the first convolution sees x * IN_SCALE + IN_SHIFT per channel (blobFromImage's mean subtraction; a prototxt with a
+# BatchNorm/Scale on the data blob folds into these two, caffe_io.build_arch)
+IN_SCALE = (1.0, 1.0, 1.0)
+IN_SHIFT = (-104.0, -177.0, -123.0)
 NUM_CLASSES = 2
 VARIANCES = (0.1, 0.1, 0.2, 0.2)
 NMS_THRESHOLD = 0.45
@@ -28,6 +32,8 @@ NORM_SCALE_INIT = 20.0
 
 # conv: (src, c_in, c_out, k, stride, pad, dilation, relu, residual_src or None)
 #   residual is added BEFORE the ReLU (ResNet basic block)
+# further kinds an imported topology may use (caffe_io): "affine" (src, c, relu): y = [relu](x * scale[c] + shift[c]),
+#   a BatchNorm+Scale that cannot be folded into a convolution; "add" (src, other, c, relu): Eltwise SUM
 LAYERS: List[Tuple[str, str, tuple]] = [
     ("conv1", "conv", ("data", 3, 32, 7, 2, 3, 1, True, None)),               # 150
     ("pool1", "maxpool", ("conv1", 3, 2)),                                     # 75 (ceil mode)

@@ -217,26 +217,70 @@ def seeded_ssd_state_dict(seed: int = 0, background_bias: float = 4.0) -> Dict[s
     return sd
 
 
-def pack_ssd_tensors(sd: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
-    """Detector tensors for the GPU: GEMM convs as [co][ky][kx][ci], conv1 as [ky][kx][ci][co],
-    per-source loc+conf heads fused into one [p*6][ky][kx][ci] matrix (loc rows first)."""
+def pack_ssd_tensors(sd: Mapping[str, np.ndarray], arch=None) -> Dict[str, np.ndarray]:
+    """Detector tensors for the GPU: GEMM convs as [co][ky][kx][ci], the first conv as [ky][kx][ci][co],
+    per-source loc+conf heads fused into one [p*6][ky][kx][ci] matrix (loc rows first).  With an `arch` other than
+    the built-in `ssd_arch` (caffe_io.build_arch: a deploy.prototxt) the layer table travels in the blob too
+    ("ssd.plan" / "ssd.names" / "ssd.srcs" / "ssd.det", read by csrc/ssd_api.hip load_plan)."""
     from . import ssd_arch as S
 
+    A = arch if arch is not None else S
     t: Dict[str, np.ndarray] = {}
-    for name, kind, a in S.LAYERS:
+    kinds = {"conv": 2, "maxpool": 1, "l2norm": 3, "affine": 4, "add": 5}
+    index = {"data": -1}
+    rows, first_conv = [], True
+    for i, (name, kind, a) in enumerate(A.LAYERS):
+        index[name] = i
+        if len(name) > 31 or not name.isascii():
+            raise ValueError(f"layer name {name!r} does not fit the 31-character plan entry")
         if kind == "conv":
+            src, ci, co, k, st, pd, dl, relu, res = a
             w = np.asarray(sd[name + ".weight"], np.float32)
-            if name == "conv1":
-                t["ssd.conv1.w"] = np.ascontiguousarray(w.transpose(2, 3, 1, 0))
+            if first_conv:                                   # the 3-channel convolution on the image
+                t[f"ssd.{name}.w"] = np.ascontiguousarray(w.transpose(2, 3, 1, 0))
+                rows.append((0, index[src], -1, ci, co, k, st, pd, dl, int(bool(relu))))
+                first_conv = False
             else:
                 t[f"ssd.{name}.w"] = np.ascontiguousarray(w.transpose(0, 2, 3, 1)).reshape(w.shape[0], -1)
+                rows.append((2, index[src], index[res] if res is not None else -1, ci, co, k, st, pd, dl, int(bool(relu))))
             t[f"ssd.{name}.b"] = np.asarray(sd[name + ".bias"], np.float32)
+        elif kind == "maxpool":
+            src, k, st = a
+            c = rows[index[src]][4]
+            rows.append((1, index[src], -1, c, c, k, st, 0, 1, 0))
         elif kind == "l2norm":
+            src, c = a
             t[f"ssd.{name}.scale"] = np.asarray(sd[name + ".scale"], np.float32)
-    for src, c, m, _, _, ars, _ in S.SOURCES:
+            rows.append((3, index[src], -1, c, c, 1, 1, 0, 1, 0))
+        elif kind == "affine":
+            src, c, relu = a
+            t[f"ssd.{name}.scale"] = np.asarray(sd[name + ".scale"], np.float32)
+            t[f"ssd.{name}.shift"] = np.asarray(sd[name + ".shift"], np.float32)
+            rows.append((4, index[src], -1, c, c, 1, 1, 0, 1, int(bool(relu))))
+        elif kind == "add":
+            src, other, c, relu = a
+            rows.append((5, index[src], index[other], c, c, 1, 1, 0, 1, int(bool(relu))))
+        else:
+            raise ValueError(f"unknown detector layer kind {kind!r}")
+    for src, c, m, _, _, ars, _ in A.SOURCES:
         w = np.concatenate([sd[src + "_loc.weight"], sd[src + "_conf.weight"]], 0).astype(np.float32)
         t[f"ssd.{src}.head.w"] = np.ascontiguousarray(w.transpose(0, 2, 3, 1)).reshape(w.shape[0], -1)
         t[f"ssd.{src}.head.b"] = np.concatenate([sd[src + "_loc.bias"], sd[src + "_conf.bias"]]).astype(np.float32)
+    if A is not S:
+        if len(A.SOURCES) != 6:
+            raise ValueError("the detector kernels are built for six source maps")
+        t["ssd.plan"] = np.asarray(rows, np.float32)
+        names = np.zeros((len(rows), 32), np.float32)
+        for i, (name, _, _) in enumerate(A.LAYERS):
+            names[i, :len(name)] = [ord(ch) for ch in name]
+        t["ssd.names"] = names
+        srcs = []
+        for src, c, m, mn, mx, ars, step in A.SOURCES:
+            ar = list(ars) + [0.0] * (2 - len(ars))
+            srcs.append((index[src], c, m, mn, mx, len(ars), ar[0], ar[1], step))
+        t["ssd.srcs"] = np.asarray(srcs, np.float32)
+        t["ssd.det"] = np.asarray([A.INPUT, *A.IN_SCALE, *A.IN_SHIFT, *A.VARIANCES, A.NMS_THRESHOLD, A.TOP_K, A.KEEP_TOP_K,
+                                   A.CONF_THRESHOLD], np.float32)
     return t
 
 
@@ -397,14 +441,15 @@ def pack_mtcnn_tensors(sd: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
 
 
 def pack_all(b0_sd: Mapping[str, np.ndarray], ssd_sd: Mapping[str, np.ndarray] = None,
-             mtcnn_sd: Mapping[str, np.ndarray] = None) -> bytes:
-    """One blob for `dfd_create`: classifier + colour tables (+ detector, + MTCNN cascade when given)."""
+             mtcnn_sd: Mapping[str, np.ndarray] = None, ssd_arch=None) -> bytes:
+    """One blob for `dfd_create`: classifier + colour tables (+ detector, + MTCNN cascade when given).
+    `ssd_arch`: the detector topology `ssd_sd` belongs to (default: the built-in `ssd_arch` module)."""
     from . import luts
 
     t = pack_b0_tensors(b0_sd)
     t.update(luts.as_float_tensors())
     if ssd_sd is not None:
-        t.update(pack_ssd_tensors(ssd_sd))
+        t.update(pack_ssd_tensors(ssd_sd, ssd_arch))
     if mtcnn_sd is not None:
         t.update(pack_mtcnn_tensors(mtcnn_sd))
     return serialize(t)
