@@ -23,5 +23,5 @@ h.warmup(256, 0)
 for _ in range(int(os.environ.get("B0_STEPS", "4"))):
     h.classify_device(xd.ptr, 256, yd.ptr)
 h.sync()
-print("measured tile entries:", len(h.tiles_export().splitlines()))
+print("measured tile entries:", len(h.tiles_export().splitlines()), "forwards:", 1 + int(os.environ.get("B0_STEPS", "4")))
 h.close()

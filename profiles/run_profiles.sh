@@ -1,0 +1,35 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for one build (run on the GPU box from the repo root):
+#   bash profiles/run_profiles.sh r02
+# 1. an un-profiled run measures the split-GEMM tiles and saves them (DFD_TILE_CACHE), so that the profiled runs
+#    launch no tuning candidates; 2. kernel trace + stats of bench.py (the command BENCH_rNN records, minus the
+#    extras) and of the classifier-only / e2e drivers; 3. PMC passes - FETCH_SIZE and WRITE_SIZE in separate
+#    passes, SQ counters in two passes of 8 - of the classifier-only driver (fp32 and bf16).
+set -u
+TAG=${1:-r02}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export DFD_TILE_CACHE=$OUT/tiles.txt
+export TMPDIR=/tmp
+python3 profiles/b0_profile_driver.py > "$OUT/warm_fp32.log" 2>&1 || exit 1
+B0_BF16=1 python3 profiles/b0_profile_driver.py > "$OUT/warm_bf16.log" 2>&1 || exit 1
+python3 bench.py --steps 20 --warmup 5 --no-e2e --no-streams --no-cpu-baseline > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err" || exit 1
+cd /tmp
+run() { name=$1; shift; rocprofv3 "$@" > "$OUT/$name.log" 2>&1 || { echo "rocprofv3 $name failed"; tail -5 "$OUT/$name.log"; exit 1; }; }
+run stats_bench --kernel-trace --stats -d "$OUT/stats_bench" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-e2e --no-streams --no-cpu-baseline
+run stats_b0 --kernel-trace --stats -d "$OUT/stats_b0" -o s --output-format csv -- python3 "$ROOT/profiles/b0_profile_driver.py"
+export B0_BF16=1
+run stats_b0_bf16 --kernel-trace --stats -d "$OUT/stats_b0_bf16" -o s --output-format csv -- python3 "$ROOT/profiles/b0_profile_driver.py"
+unset B0_BF16
+run stats_e2e --kernel-trace --stats -d "$OUT/stats_e2e" -o s --output-format csv -- python3 "$ROOT/profiles/e2e_profile_driver.py"
+run pmc_fetch --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o p --output-format csv -- python3 "$ROOT/profiles/b0_profile_driver.py"
+run pmc_write --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o p --output-format csv -- python3 "$ROOT/profiles/b0_profile_driver.py"
+run pmc_sqa --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace -d "$OUT/pmc_sqa" -o p --output-format csv -- python3 "$ROOT/profiles/b0_profile_driver.py"
+run pmc_sqb --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_WAVES --kernel-trace -d "$OUT/pmc_sqb" -o p --output-format csv -- python3 "$ROOT/profiles/b0_profile_driver.py"
+export B0_BF16=1
+run pmc_fetch_bf16 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch_bf16" -o p --output-format csv -- python3 "$ROOT/profiles/b0_profile_driver.py"
+run pmc_write_bf16 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write_bf16" -o p --output-format csv -- python3 "$ROOT/profiles/b0_profile_driver.py"
+unset B0_BF16
+cd "$ROOT"
+find "$OUT" -name "*.csv" | sort

@@ -12,6 +12,37 @@ import sys
 from collections import defaultdict
 
 
+def demangle(name):
+    """rocprofv3 leaves names with bf16 template arguments (DF16b) mangled and this image has no demangler that knows
+    them: rebuild `void dfd::kernel<args>` for this library's kernels (integer, bool, float and bf16 arguments)."""
+    import re
+
+    m = re.match(r"_ZN3dfd(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    ident = name[m.end():m.end() + n]
+    rest = name[m.end() + n:]
+    if not rest.startswith("I"):
+        return "dfd::" + ident
+    args, i = [], 1
+    while i < len(rest) and rest[i] != "E":
+        if rest.startswith("Li", i) or rest.startswith("Lb", i):
+            j = rest.index("E", i)
+            v = rest[i + 2:j]
+            args.append(("true" if v == "1" else "false") if rest[i + 1] == "b" else v.replace("n", "-"))
+            i = j + 1
+        elif rest.startswith("DF16b", i):
+            args.append("__bf16")
+            i += 5
+        elif rest[i] == "f":
+            args.append("float")
+            i += 1
+        else:
+            return name
+    return "void dfd::" + ident + "<" + ", ".join(args) + ">(...)"
+
+
 def main():
     flt = re.compile(sys.argv[1])
     acc = defaultdict(lambda: defaultdict(list))
@@ -20,7 +51,7 @@ def main():
     for path in sys.argv[2:]:
         with open(path, newline="") as f:
             for r in csv.DictReader(f):
-                name = r["Kernel_Name"]
+                name = demangle(r["Kernel_Name"])
                 if not flt.search(name):
                     continue
                 short = re.sub(r"^void |dfd::|\(.*$", "", name)
