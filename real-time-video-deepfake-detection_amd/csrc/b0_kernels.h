@@ -19,9 +19,11 @@ void launch_stem(const float* x_nchw, const float* w /*[3][3][3][32]*/, const fl
 // stem + block-0 depthwise fused (the stem activation stays in LDS); stem_out may be null, or a buffer
 // [n][112][112][32] that receives a copy of the stem activation for parity taps.  The tile count (98) is
 // that of launch_depthwise for block 0.
+// (ws3: the stem weights [32][27] as three bf16 planes, `plane` elements apart, rows Kp long: the 3x3x3 -> 32 stem conv
+// runs on the bf16 MFMA with split-precision operands, K = 27 padded to 32)
 template <typename XT>
-void launch_stem_dw(const float* x_nchw, const float* ws, const float* bs, const float* Wd, const float* bd,
-                    XT* Y, float* P, XT* stem_out, int n, int* tiles, hipStream_t s);
+void launch_stem_dw(const float* x_nchw, const unsigned short* ws3, int plane, int Kp, const float* bs, const float* Wd,
+                    const float* bd, XT* Y, float* P, XT* stem_out, int n, int* tiles, hipStream_t s);
 
 // pointwise conv as GEMM: Y[m][o] = act( sum_k X[m][k]*gate[m/HW][k] * W[o][k] + b[o] ) + R[m][o]
 // gate / R may be null.  X rows have stride K, Y/R rows stride N.
@@ -44,7 +46,7 @@ bool launch_conv_gemm(const float* X, const float* W, const float* bias, const f
 // of W [N][K] written by launch_split_weights (out: 3 * split_weights_count(N, K) bf16, zero-padded planes).
 // fp32-exact products, fp32 accumulate.
 size_t split_weights_count(int N, int K);
-void launch_split_weights(const float* W, unsigned short* out, int N, int K, hipStream_t s);
+void launch_split_weights(const float* W, unsigned short* out, int N, int K, hipStream_t s, bool transposed = false);
 bool split_gemm_supports(int K, int N);
 // `tab` is the handle's tile table (null: heuristic tile, nothing remembered).  A shape the table has no
 // measurement for runs the heuristic tile unless the table is in tuning mode (dfd_warmup), where every

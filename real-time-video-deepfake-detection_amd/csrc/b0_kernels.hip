@@ -821,7 +821,8 @@ __global__ __launch_bounds__(256, 2) void mbconv2_kernel(const XT* __restrict__ 
 // (zero outside the 112x112 stem output = the depthwise padding), then dw_compute runs as usual.
 // The 112x112x32 stem activation (1.6 MB per crop, read back with a 1.4x halo) never touches HBM.
 template <typename XT>
-__global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict__ x, const float* __restrict__ ws_g,
+__global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict__ x, const unsigned short* __restrict__ ws3,
+                                                      int plane, int Kp,
                                                       const float* __restrict__ bs, const float* __restrict__ Wt,
                                                       const float* __restrict__ bias, XT* __restrict__ Y,
                                                       float* __restrict__ P, XT* __restrict__ stem_out,
@@ -829,25 +830,36 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
     constexpr int K = 3, S = 1, CB = 32, TH = 8, TW = 16, RP = 4, CG = 8;
     constexpr int IH = TH + 2, IW = TW + 2;                 // 10 x 18 stem pixels
     constexpr int PH = (IH - 1) * 2 + 3, PW = (IW - 1) * 2 + 3, PWP = PW + 1;   // 21 x 37 input patch
+    constexpr int NPX = IH * IW, NMT = (NPX + 15) / 16, NIT = (NMT + 3) / 4;    // 180 pixels = 12 MFMA column tiles
     __shared__ v4f tile[IH * IW * CG];
     __shared__ v4f wl[K * K * CG];
     __shared__ v4f red[4 * CG];
     __shared__ float patch[3 * PH * PWP];
-    __shared__ __attribute__((aligned(16))) float ws[27 * 32];
     const int tid = threadIdx.x, n = blockIdx.y, t = blockIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
     const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
 #ifdef MB_TRACE
     int mtp = 0;
     const int H = 224;
 #endif
     MB_TP(0);
-    // weights: one 16-byte load per thread each (216 + 72 vectors), requested together with the patch below -
-    // the element-wise copy loops were four more serialized round trips in front of the patch loads
-    static_assert(27 * 32 / 4 <= 256 && K * K * CG <= 256, "one vector per thread");
-    const v4f ws_v = ldg4(ws_g + 4 * (tid < 216 ? tid : 215));
+    // The 3x3x3 -> 32 stem convolution on the bf16 MFMA, operands split exactly as in gemm_split: A = the two
+    // 16-channel row tiles of the weights [32][27 -> 32] (three bf16 planes, requested here, with the patch), B = for
+    // pixel j the 8 patch values k = 8q .. 8q + 7 (k = (ky * 3 + kx) * 3 + ci) gathered from the LDS patch and split
+    // in registers.  As 27 FMAs per pixel and channel quad this loop was the bulk of a kernel whose VALU was busy
+    // 89 % of the time (profiles/r02_sq_counters.md); as 12 MFMAs per 16 pixels the matrix pipe does it.
+    bf8 wfr[2][3];
+    {
+        const unsigned short* wrow = ws3 + (size_t)j * Kp + 8 * q;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wfr[nt][pl] = *reinterpret_cast<const bf8*>(wrow + (size_t)pl * plane + (size_t)nt * 16 * Kp);
+    }
     const int wi = tid < K * K * CG ? tid : 0;
     const v4f wl_v = ldg4(Wt + (size_t)(wi / CG) * 32 + 4 * (wi % CG));
     const v4f bv = ldg4(bias + 4 * (tid % CG));
+    const v4f bs0 = ldg4(bs + 4 * q), bs1 = ldg4(bs + 16 + 4 * q);
     // stem pixel (sy, sx) = (ty0 - 1 + py, tx0 - 1 + px) reads input rows 2*sy .. 2*sy+2 (TF-SAME: pad high only)
     const int r0 = 2 * (ty0 - 1), c0 = 2 * (tx0 - 1);
     const float* xb = x + (size_t)n * 3 * 224 * 224;
@@ -870,50 +882,53 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
         const int ci = i / (PH * PW), r = (i / PW) % PH, c = i % PW;
         patch[(ci * PH + r) * PWP + c] = pok[k] ? pv[k] : 0.f;
     }
-    if (tid < 216) *reinterpret_cast<v4f*>(&ws[4 * tid]) = ws_v;
     if (tid < K * K * CG) wl[tid] = wl_v;
     MB_TP(1);
     __syncthreads();
     MB_TP(2);
-    const int cg = tid & 7;
-    const v4f bsv = ldg4(bs + 4 * cg);
-    // thread = 4 output channels x 6 of the 180 halo pixels; taps outermost so each weight vector is read
-    // from LDS once per thread, not once per pixel
-    constexpr int NPX = (IH * IW + 31) / 32;
-    v4f acc[NPX];
-    int poff[NPX];
+    // patch offsets of this lane's 8 k values (relative to the pixel's top-left input sample); k >= 27: offset 0, the
+    // weight planes are zero there
+    int koff[8];
 #pragma unroll
-    for (int i = 0; i < NPX; ++i) {
-        const int p = (tid >> 3) + 32 * i, pc = p < IH * IW ? p : 0;
-        acc[i] = bsv;
-        poff[i] = (2 * (pc / IW)) * PWP + 2 * (pc % IW);
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * q + e, kc = k < 27 ? k : 0;
+        const int tap = kc / 3, ci = kc - 3 * tap, ky = tap / 3, kx = tap - 3 * ky;
+        koff[e] = (ci * PH + ky) * PWP + kx;
     }
-    // (ci, ky) stay rolled: fully unrolled, the compiler hoists all 27 weight vectors and 162 patch values
-    // (256 VGPRs, one wave per SIMD)
-#pragma unroll 1
-    for (int ci = 0; ci < 3; ++ci)
-#pragma unroll 1
-        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const v4f w = *reinterpret_cast<const v4f*>(&ws[((ky * 3 + kx) * 3 + ci) * 32 + 4 * cg]);
-                const float* pp = &patch[(ci * PH + ky) * PWP + kx];
+    for (int it = 0; it < NIT; ++it) {
+        const int mt = wave + 4 * it;                       // wave-uniform
+        if (mt < NMT) {
+            const int p = mt * 16 + j, pc = p < NPX ? p : NPX - 1;
+            const int py = pc / IW, px = pc - py * IW;
+            const float* pp = &patch[(2 * py) * PWP + 2 * px];
+            v4f lo, hi;
+            lo.x = pp[koff[0]]; lo.y = pp[koff[1]]; lo.z = pp[koff[2]]; lo.w = pp[koff[3]];
+            hi.x = pp[koff[4]]; hi.y = pp[koff[5]]; hi.z = pp[koff[6]]; hi.w = pp[koff[7]];
+            bf8 x0, x1, x2;
+            split8(lo, hi, x0, x1, x2);
+            v4f acc[2] = {(v4f){0.f, 0.f, 0.f, 0.f}, (v4f){0.f, 0.f, 0.f, 0.f}};
+            const bf8* xs[3] = {&x0, &x1, &x2};
+            const int wsel[6] = {2, 1, 0, 1, 0, 0}, xsel[6] = {0, 1, 2, 0, 1, 0};      // smallest terms first
 #pragma unroll
-                for (int i = 0; i < NPX; ++i) acc[i] += pp[poff[i]] * w;
-            }
-    MB_TP(3);
+            for (int p6 = 0; p6 < 6; ++p6)
 #pragma unroll
-    for (int i = 0; i < NPX; ++i) {
-        const int p = (tid >> 3) + 32 * i;
-        if (p < IH * IW) {
-            const int py = p / IW, px = p % IW;
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[nt][wsel[p6]], *xs[xsel[p6]], acc[nt], 0, 0, 0);
             const int sy = ty0 - 1 + py, sx = tx0 - 1 + px;
             const bool inside = (unsigned)sy < 112u && (unsigned)sx < 112u;
-            const v4f v = inside ? swish4(acc[i]) : (v4f){0.f, 0.f, 0.f, 0.f};
-            tile[p * CG + cg] = v;
-            // optional copy of the stem activation (parity taps only): interior pixels of this tile
-            if (stem_out && inside && py >= 1 && py <= TH && px >= 1 && px <= TW)
-                st4(stem_out + (((size_t)n * 112 + sy) * 112 + sx) * 32 + 4 * cg, v);
+            if (p < NPX) {
+                const v4f v0 = inside ? swish4(acc[0] + bs0) : (v4f){0.f, 0.f, 0.f, 0.f};
+                const v4f v1 = inside ? swish4(acc[1] + bs1) : (v4f){0.f, 0.f, 0.f, 0.f};
+                tile[p * CG + q] = v0;
+                tile[p * CG + 4 + q] = v1;
+                // optional copy of the stem activation (parity taps only): interior pixels of this tile
+                if (stem_out && inside && py >= 1 && py <= TH && px >= 1 && px <= TW) {
+                    XT* so = stem_out + (((size_t)n * 112 + sy) * 112 + sx) * 32;
+                    st4(so + 4 * q, v0);
+                    st4(so + 16 + 4 * q, v1);
+                }
+            }
         }
     }
     MB_TP(4);
@@ -927,14 +942,15 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
 }
 
 template <typename XT>
-void launch_stem_dw(const float* x, const float* ws, const float* bs, const float* Wd, const float* bd, XT* Y,
-                    float* P, XT* stem_out, int n, int* tiles, hipStream_t s) {
+void launch_stem_dw(const float* x, const unsigned short* ws3, int plane, int Kp, const float* bs, const float* Wd,
+                    const float* bd, XT* Y, float* P, XT* stem_out, int n, int* tiles, hipStream_t s) {
     const int tx = 112 / 16, ty = 112 / 8;
     *tiles = tx * ty;
-    hipLaunchKernelGGL(stem_dw_kernel<XT>, dim3(tx * ty, n), dim3(256), 0, s, x, ws, bs, Wd, bd, Y, P, stem_out, tx, tx * ty);
+    hipLaunchKernelGGL(stem_dw_kernel<XT>, dim3(tx * ty, n), dim3(256), 0, s, x, ws3, plane, Kp, bs, Wd, bd, Y, P, stem_out, tx,
+                       tx * ty);
 }
-template void launch_stem_dw<float>(const float*, const float*, const float*, const float*, const float*, float*, float*, float*, int, int*, hipStream_t);
-template void launch_stem_dw<bf16_t>(const float*, const float*, const float*, const float*, const float*, bf16_t*, float*, bf16_t*, int, int*, hipStream_t);
+template void launch_stem_dw<float>(const float*, const unsigned short*, int, int, const float*, const float*, const float*, float*, float*, float*, int, int*, hipStream_t);
+template void launch_stem_dw<bf16_t>(const float*, const unsigned short*, int, int, const float*, const float*, const float*, bf16_t*, float*, bf16_t*, int, int*, hipStream_t);
 
 template <int K, int S, int CB, int TH, int TW, int RP, typename XT>
 static void dw_launch(const XT* X, const float* W, const float* b, XT* Y, float* P, int n,

@@ -139,7 +139,7 @@ int b0_build_plan(dfd_handle* h) {
     return ok ? DFD_OK : DFD_ERR_BLOB;
 }
 
-const unsigned short* split_weights(dfd_handle* h, const float* W, int N, int K) {
+const unsigned short* split_weights(dfd_handle* h, const float* W, int N, int K, bool transposed) {
     const size_t count = split_weights_count(N, K);
     auto it = h->wsplit.find(W);
     if (it != h->wsplit.end()) return it->second;
@@ -149,7 +149,7 @@ const unsigned short* split_weights(dfd_handle* h, const float* W, int N, int K)
         return nullptr;
     }
     h->owned.push_back(p);
-    launch_split_weights(W, static_cast<unsigned short*>(p), N, K, h->stream);
+    launch_split_weights(W, static_cast<unsigned short*>(p), N, K, h->stream, transposed);
     h->wsplit[W] = static_cast<unsigned short*>(p);
     return static_cast<unsigned short*>(p);
 }
@@ -242,8 +242,10 @@ static int b0_forward_t(dfd_handle* h, const float* x, int n, float* logits_dev,
     int stem_tiles = 0;
     if (stem_fused) {
         const bool want_stem = tap && tap->name && std::string(tap->name) == "stem";
-        launch_stem_dw<XT>(x, P.stem_w, P.stem_b, P.blocks[0].dw_w, P.blocks[0].dw_b, dwbuf, h->pool,
-                           want_stem ? io0 : (XT*)nullptr, n, &stem_tiles, s);
+        const unsigned short* ws3 = split_weights(h, P.stem_w, 32, 27, true);          // [ky][kx][ci][co] = [27][32], transposed
+        if (!ws3) return DFD_ERR_HIP;
+        launch_stem_dw<XT>(x, ws3, (int)split_weights_count(32, 27), 64, P.stem_b, P.blocks[0].dw_w, P.blocks[0].dw_b, dwbuf,
+                           h->pool, want_stem ? io0 : (XT*)nullptr, n, &stem_tiles, s);
         mk.mark("b0.dw");                               // stem + depthwise of block 0 in one launch
     } else {
         launch_stem<XT>(x, P.stem_w, P.stem_b, io0, n, s);

@@ -174,7 +174,7 @@ int jpeg_decode_to_frame(dfd_handle* h, const uint8_t* jpeg, size_t len, int* hh
 
 // b0_plan.hip
 // three-plane bf16 split of a weight tensor of the handle, made on first use; null (+ error set) on failure
-const unsigned short* split_weights(dfd_handle* h, const float* W, int N, int K);
+const unsigned short* split_weights(dfd_handle* h, const float* W, int N, int K, bool transposed = false);
 // 1x1 conv through the split path when enabled and the shape allows, else the fp32 MFMA kernel
 int pointwise(dfd_handle* h, const float* X, const float* W, const float* bias, const float* gate, const float* R,
               float* Y, int M, int K, int N, int HW, int act);

@@ -17,12 +17,13 @@ DFD_S6_INSTANTIATE(float, 3)
 
 // W [N][K] fp32 -> three planes [Np][Kp] bf16, zero outside N x K (Kp = K rounded up to 64, Np = s6_np(N)):
 // the GEMM's weight loads need neither clamps nor zero-fill selects.
+// (transposed: W is stored [K][N] - the stem convolution's [ky][kx][ci][co] tensor read as a [27][32] matrix)
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ W, __bf16* __restrict__ out,
-                                                            int N, int K, int Np, int Kp) {
+                                                            int N, int K, int Np, int Kp, int transposed) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, plane = (size_t)Np * Kp;
     if (i >= plane) return;
     const int n = (int)(i / Kp), k = (int)(i - (size_t)n * Kp);
-    const float a = n < N && k < K ? W[(size_t)n * K + k] : 0.f;
+    const float a = n < N && k < K ? (transposed ? W[(size_t)k * N + n] : W[(size_t)n * K + k]) : 0.f;
     const __bf16 h0 = (__bf16)a;
     const float r1 = a - (float)h0;
     const __bf16 h1 = (__bf16)r1;
@@ -36,11 +37,11 @@ size_t split_weights_count(int N, int K) {
     return (size_t)s6_np(N) * ((K + S6_KPAD - 1) / S6_KPAD * S6_KPAD);
 }
 
-void launch_split_weights(const float* W, unsigned short* out, int N, int K, hipStream_t s) {
+void launch_split_weights(const float* W, unsigned short* out, int N, int K, hipStream_t s, bool transposed) {
     const int Np = s6_np(N), Kp = (K + S6_KPAD - 1) / S6_KPAD * S6_KPAD;
     const size_t plane = (size_t)Np * Kp;
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, W,
-                       reinterpret_cast<__bf16*>(out), N, K, Np, Kp);
+                       reinterpret_cast<__bf16*>(out), N, K, Np, Kp, transposed ? 1 : 0);
 }
 
 // Heuristic tile (shapes nobody warmed up): the biggest per-wave pw6 tile that still fills the chip.

@@ -302,7 +302,7 @@ MTCNN_PRELU = {"pnet": [("prelu1", 10), ("prelu2", 16), ("prelu3", 32)],
                "onet": [("prelu1", 32), ("prelu2", 64), ("prelu3", 64), ("prelu4", 128), ("prelu5", 256)]}
 
 
-def seeded_mtcnn_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
+def seeded_mtcnn_state_dict(seed: int = 0, head_bias=None) -> Dict[str, np.ndarray]:
     """Random-init MTCNN weights under facenet-pytorch's state_dict names (``pnet.conv1.weight`` ...).
 
     The face-probability heads get a negative face-vs-background bias so that a random cascade lets a few
@@ -311,7 +311,12 @@ def seeded_mtcnn_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
     """
     rs = np.random.RandomState(seed + 2000)
     sd: Dict[str, np.ndarray] = {}
-    head_bias = {"pnet.conv4_1": (-0.9, 1.0), "rnet.dense5_1": (2.4, 1.5), "onet.dense6_1": (0.8, 1.5)}   # (mean, std) of the face-vs-background logit
+    # (mean, std) of the face-vs-background logit per stage.  The default lets ~20 % of the P-Net cells and nearly every
+    # R-Net candidate through: a stress cascade for the parity tests (hundreds of windows per crop reach every stage).
+    # MTCNN_SELECTIVE is the funnel of a trained cascade on a crop with one face (a fraction of a percent of the
+    # P-Net cells, a minority of the R-Net candidates): what bench.py times next to the stress figure.
+    if head_bias is None:
+        head_bias = {"pnet.conv4_1": (-0.9, 1.0), "rnet.dense5_1": (2.4, 1.5), "onet.dense6_1": (0.8, 1.5)}
     for net in ("pnet", "rnet", "onet"):
         for name, co, ci, k in MTCNN_CONVS[net]:
             q = f"{net}.{name}"
@@ -332,6 +337,9 @@ def seeded_mtcnn_state_dict(seed: int = 0) -> Dict[str, np.ndarray]:
     for q in ("pnet.conv4_2", "rnet.dense5_2", "onet.dense6_2"):  # box regression: small offsets
         sd[q + ".weight"] *= 0.15
     return sd
+
+
+MTCNN_SELECTIVE = {"pnet.conv4_1": (-3.2, 1.0), "rnet.dense5_1": (-0.4, 1.5), "onet.dense6_1": (0.6, 1.5)}
 
 
 def load_mtcnn_checkpoints(directory: str) -> Dict[str, np.ndarray]:
