@@ -144,6 +144,14 @@ int dfd_resize_bgr(dfd_handle* h, const uint8_t* bgr, int height, int width, int
 int dfd_preprocess_face_quality(dfd_handle* h, const uint8_t* bgr, int height, int width,
                                 int stride, uint8_t* out);
 
+/* One test-time-augmentation copy of a face crop, reference deepfake_detection.py:419-433:
+ * cv2.flip(img, 1) when `flip`, cv2.convertScaleAbs(img, alpha=brightness, beta=0), then cv2.warpAffine(img,
+ * cv2.getRotationMatrix2D((w/2, h/2), angle_deg, 1.0), (w, h)) with OpenCV's fixed-point bilinear sampling.
+ * out: height*width*3, packed.  The random draws (flip probability .5, brightness 0.9..1.1, angle -3..3 degrees)
+ * and the averaging of the per-copy probabilities stay on the host (DeepfakeDetector.analyze_face_with_tta). */
+int dfd_tta_augment(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride, int flip, double brightness,
+                    double angle_deg, uint8_t* out);
+
 /* crop (reference backend_server.py:160-161 / deepfake_detection.py:612) -> optional CLAHE ->
  * BGR->RGB, bilinear 224x224 (align_corners=False), /255, ImageNet normalise (reference
  * deepfake_detection.py:376,382-389; the MTCNN re-crop at :377 is bypassed).
@@ -181,6 +189,16 @@ int dfd_last_detection_count(const dfd_handle* h);
  * "<source>.head", "prob", "boxes" (per prior) or "rows" (DetectionOutput: score,x1,y1,x2,y2). */
 int dfd_ssd_tap(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
                 const char* name, float* out, size_t capacity, size_t* count);
+
+/* ---- Haar cascade fallback -------------------------------------------------------------
+ * _detect_haar, reference face_detection.py:108-123: cv2.CascadeClassifier.detectMultiScale(gray, scaleFactor,
+ * minNeighbors, minSize=(min_size, min_size)) for a stump cascade with upright HAAR features packed into the blob
+ * (haar.load_cascade_xml reads OpenCV's XML; weights.pack_all(..., haar=...)).  The reference uses this path
+ * whenever its SSD files are missing.  Boxes are the grouped rectangles in OpenCV's order; n_candidates (may be
+ * NULL) receives the number of windows that passed the cascade before grouping. */
+int dfd_has_haar(const dfd_handle* h);
+int dfd_detect_faces_haar(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride, float scale_factor,
+                          int min_neighbors, int min_size, int32_t* xywh_out, int max_out, int* n_out, int* n_candidates);
 
 /* ---- MTCNN align/crop -------------------------------------------------
  * The reference runs facenet-pytorch's MTCNN(select_largest=False, post_process=False) on every

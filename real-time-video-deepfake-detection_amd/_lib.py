@@ -53,6 +53,8 @@ SIGNATURES = {
     "dfd_b0_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_size_t,
                               C.POINTER(C.c_size_t)]),
     "dfd_resize_bgr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dfd_tta_augment": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                  C.c_void_p]),
     "dfd_preprocess_face_quality": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dfd_preprocess_crops": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                        C.c_int, C.c_void_p]),
@@ -65,6 +67,9 @@ SIGNATURES = {
     "dfd_last_detection_count": (C.c_int, [C.c_void_p]),
     "dfd_ssd_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p,
                               C.c_size_t, C.POINTER(C.c_size_t)]),
+    "dfd_has_haar": (C.c_int, [C.c_void_p]),
+    "dfd_detect_faces_haar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dfd_has_mtcnn": (C.c_int, [C.c_void_p]),
     "dfd_mtcnn_align": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_int)]),
@@ -326,6 +331,14 @@ class Handle:
         self._check(self._lib.dfd_preprocess_face_quality(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0], _ptr(out)))
         return out
 
+    def tta_augment(self, face, flip: bool, brightness: float, angle_deg: float) -> np.ndarray:
+        """cv2.flip / convertScaleAbs / warpAffine chain of the reference's test-time augmentation, on the device"""
+        a = self._as_bgr(face)
+        out = np.empty_like(a)
+        self._check(self._lib.dfd_tta_augment(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0], int(bool(flip)),
+                                              float(brightness), float(angle_deg), _ptr(out)))
+        return out
+
     def preprocess_crops(self, frame, boxes, apply_clahe: bool = True) -> np.ndarray:
         a, b = self._as_bgr(frame), self._as_boxes(boxes)
         out = np.empty((b.shape[0], 3, 224, 224), np.float32)
@@ -389,6 +402,21 @@ class Handle:
                                                float(confidence_threshold), _ptr(boxes), _ptr(conf), max_out, C.byref(n)))
         out = [tuple(int(v) for v in boxes[i]) for i in range(n.value)]
         return (out, conf[: n.value].copy()) if with_conf else out
+
+    @property
+    def has_haar(self) -> bool:
+        return bool(self._lib.dfd_has_haar(self._p))
+
+    def detect_faces_haar(self, frame, scale_factor: float = 1.1, min_neighbors: int = 5, min_size: int = 30,
+                          max_out: int = 256, with_candidates: bool = False):
+        """cv2 detectMultiScale on the blob's Haar cascade -> [(x, y, w, h), ...] (reference face_detection.py:108-123)"""
+        a = self._as_bgr(frame)
+        boxes = np.zeros((max_out, 4), np.int32)
+        n, nc = C.c_int(), C.c_int()
+        self._check(self._lib.dfd_detect_faces_haar(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0], float(scale_factor),
+                                                    int(min_neighbors), int(min_size), _ptr(boxes), max_out, C.byref(n), C.byref(nc)))
+        out = [tuple(int(v) for v in boxes[i]) for i in range(n.value)]
+        return (out, nc.value) if with_candidates else out
 
     def analyze_frame(self, frame, full_forensics: bool, stream_id: int = 0, confidence_threshold: float = 0.5,
                       max_faces: int = 16, apply_clahe: bool = True):

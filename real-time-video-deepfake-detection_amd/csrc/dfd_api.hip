@@ -65,6 +65,7 @@ int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, in
     if ((rc = color_tables_init(h))) return rc;
     if ((rc = ssd_init(h))) return rc;
     if ((rc = mtcnn_init(h))) return rc;
+    if ((rc = haar_init(h))) return rc;
 
     const B0Plan& P = h->b0;
     const size_t nb = (size_t)max_batch;
@@ -88,6 +89,7 @@ void destroy_impl(dfd_handle* h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     comm_destroy(h);
+    haar_destroy(h);
     forensic_destroy(h);
     ssd_destroy(h);
     mtcnn_destroy(h);

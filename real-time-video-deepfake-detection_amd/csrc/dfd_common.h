@@ -24,6 +24,9 @@ struct SsdState;        // ssd_api.hip
 int ssd_init(dfd_handle* h);
 void ssd_destroy(dfd_handle* h);
 int ssd_warmup(dfd_handle* h, int n_frames);   // detector forward on n synthetic 300x300 inputs (tile measurement)
+struct HaarState;       // haar_api.hip: Haar cascade fallback detector
+int haar_init(dfd_handle* h);
+void haar_destroy(dfd_handle* h);
 struct CommState;       // comm_api.hip: RCCL communicator of the vote exchange
 void comm_destroy(dfd_handle* h);
 struct S6Table;         // gemm_split.hip: measured split-GEMM tiles of this handle
@@ -103,6 +106,7 @@ struct dfd_handle {
     dfd::FreqState* freq = nullptr;           // compute_frequency_features tables + scratch
     dfd::SsdState* ssd = nullptr;             // detector plan + workspace (null: blob has no detector)
     dfd::MtcnnState* mtcnn = nullptr;         // MTCNN cascade (null: blob has none)
+    dfd::HaarState* haar = nullptr;           // Haar cascade (null: blob has none)
     dfd::CommState* comm = nullptr;           // vote exchange (null until dfd_comm_init)
     bool use_mtcnn = true;                    // classify paths align each crop with the cascade when the blob has one
     bool fuse_stem = true;               // stem conv computed inside block 0's depthwise kernel

@@ -1,5 +1,7 @@
 // C ABI entry points of the per-face pre-processing path (include/dfd_hip.h).
 #include "b0_kernels.h"
+#include <cmath>
+
 #include "dfd_common.h"
 
 using namespace dfd;
@@ -223,6 +225,32 @@ int analyze_frame_resident(dfd_handle* h, int stream_id, int hh, int ww, int str
 }  // namespace dfd
 
 extern "C" {
+
+// One test-time-augmentation copy of a face crop (reference deepfake_detection.py:419-433).
+int dfd_tta_augment(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride, int flip, double brightness, double angle_deg,
+                    uint8_t* out) {
+    if (!h) return DFD_ERR_ARG;
+    if (!out) return fail(h, DFD_ERR_ARG, "tta_augment: null output");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    int rc = upload_frame(h, bgr, hh, ww, stride);
+    if (rc) return rc;
+    if ((rc = ensure(h, &h->u8_out, (size_t)hh * ww * 3))) return rc;
+    // cv2.getRotationMatrix2D((w/2, h/2), angle, 1.0), then warpAffine's inversion (imgwarp.cpp), all in double
+    const double cx = ww / 2.0, cy = hh / 2.0;
+    const double a = std::cos(angle_deg * M_PI / 180.0), b = std::sin(angle_deg * M_PI / 180.0);
+    double M[6] = {a, b, (1.0 - a) * cx - b * cy, -b, a, b * cx + (1.0 - a) * cy};
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0.0 ? 1.0 / D : 0.0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    launch_tta_augment((const uint8_t*)h->frame_buf.p, hh, ww, stride, flip ? 1 : 0, (float)brightness, M, (uint8_t*)h->u8_out.p,
+                       h->stream);
+    DFD_HIP_TRY(h, hipMemcpyAsync(out, h->u8_out.p, (size_t)hh * ww * 3, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DFD_OK;
+}
 
 int dfd_resize_bgr(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride, int dh, int dw, uint8_t* out) {
     if (!h) return DFD_ERR_ARG;

@@ -21,6 +21,10 @@ struct CropDesc {
 void launch_resize_bgr(const uint8_t* src, int n, int sh, int sw, size_t sstride, size_t simg,
                        uint8_t* dst, int dh, int dw, hipStream_t s);
 // single-channel cv2.resize(INTER_LINEAR) and u8 -> float (x scale)
+// test-time augmentation of a face crop (flip, brightness, small rotation) as the reference builds it with cv2;
+// mi = the inverted 2x3 affine matrix (warpAffine's internal form)
+void launch_tta_augment(const uint8_t* src, int h, int w, int stride, int flip, float alpha, const double mi[6], uint8_t* dst,
+                        hipStream_t s);
 void launch_resize_gray(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw, hipStream_t s);
 void u8_to_float(const uint8_t* src, float* dst, int n, float scale, hipStream_t s);
 void launch_clahe(const uint8_t* frame, size_t fstride, const CropDesc* crops_dev, int n, uint8_t* lab,

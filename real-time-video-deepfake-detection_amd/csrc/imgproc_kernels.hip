@@ -269,4 +269,47 @@ void launch_crop_norm(const uint8_t* frame, size_t fstride, const uint8_t* scrat
                        scratch, crops_dev, out_nchw, from_scratch ? 1 : 0);
 }
 
+// ------------------------------------------------------------------- test-time augmentation
+// One augmented copy of a face crop as reference deepfake_detection.py:419-433 builds it with cv2:
+//   cv2.flip(img, 1) (optional) -> cv2.convertScaleAbs(img, alpha=brightness, beta=0) -> cv2.warpAffine(img,
+//   getRotationMatrix2D((w/2, h/2), angle, 1.0), (w, h))   [INTER_LINEAR, BORDER_CONSTANT 0]
+// composed per destination pixel.  warpAffine as OpenCV computes it: the INVERSE matrix Mi in double, fixed-point
+// source coordinates (10 fractional bits, 5 kept for interpolation: X = (round((Mi[1]*y + Mi[2]) * 1024) + 16 +
+// round(Mi[0]*x * 1024)) >> 5), bilinear weights (32 - fx)(32 - fy) * 32 of 32768, result (sum + 16384) >> 15,
+// samples outside the image = 0.  convertScaleAbs on 8-bit data: saturate(rint(|v * (float)alpha|)).
+__global__ __launch_bounds__(256) void tta_augment_kernel(const uint8_t* __restrict__ src, int h, int w, int stride, int flip, float alpha,
+                                                          double m0, double m1, double m2, double m3, double m4, double m5,
+                                                          uint8_t* __restrict__ dst) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int X0 = (int)rint((m1 * y + m2) * 1024.0) + 16, Y0 = (int)rint((m4 * y + m5) * 1024.0) + 16;
+    const int X = (X0 + (int)rint(m0 * x * 1024.0)) >> 5, Y = (Y0 + (int)rint(m3 * x * 1024.0)) >> 5;
+    const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+    const int wgt[4] = {(32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32};
+    int acc[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int yy = sy + (k >> 1), xx = sx + (k & 1);
+        if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
+            const uint8_t* p = src + (size_t)yy * stride + 3 * (flip ? w - 1 - xx : xx);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = fabsf((float)p[c] * alpha);
+                int q = (int)rintf(v);
+                q = q > 255 ? 255 : q;
+                acc[c] += q * wgt[k];
+            }
+        }
+    }
+    uint8_t* o = dst + ((size_t)y * w + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (uint8_t)((acc[c] + (1 << 14)) >> 15);
+}
+
+void launch_tta_augment(const uint8_t* src, int h, int w, int stride, int flip, float alpha, const double mi[6], uint8_t* dst,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(tta_augment_kernel, dim3((w + 255) / 256, h), dim3(256), 0, s, src, h, w, stride, flip, alpha, mi[0], mi[1],
+                       mi[2], mi[3], mi[4], mi[5], dst);
+}
+
 }  // namespace dfd

@@ -72,8 +72,6 @@ class DeepfakeDetector:
         self.detection_threshold = detection_threshold
         self.face_weight = face_weight                  # stored, never used - as in the reference
         self.forensic_weight = forensic_weight
-        if use_tta and num_tta_augmentations > 1:
-            log.info("TTA is not implemented on the HIP path; using a single prediction per face")
         self.temporal_tracker = TemporalTracker(window_size=60, high_confidence_threshold=0.6, voting_window=10,
                                                 detection_threshold=detection_threshold)
         self.frame_count = 0
@@ -152,6 +150,34 @@ class DeepfakeDetector:
         self.last_frame_forensic_result = result
         return result
 
+    def _single_prediction(self, face_region):
+        """sigmoid(model(...)) of an already quality-preprocessed crop, or None (reference :372-406)"""
+        h, w = face_region.shape[:2]
+        with self._lock:
+            logit = self.handle.classify_crops(face_region, [(0, 0, w, h)], apply_clahe=False)[0, 0]
+        return None if np.isnan(logit) else _sigmoid32(logit)
+
+    def analyze_face_with_tta(self, face_region):
+        """reference :408-443: the original plus num_tta_augmentations - 1 randomly augmented copies (horizontal flip
+        with probability 1/2, brightness x U(0.9, 1.1), rotation by U(-3, 3) degrees about the centre), each through
+        `_single_prediction`, averaged.  The draws come from Python's `random` in the reference's order."""
+        import random
+
+        predictions = []
+        pred = self._single_prediction(face_region)
+        if pred is not None:
+            predictions.append(pred)
+        for _ in range(self.num_tta_augmentations - 1):
+            flip = random.random() > 0.5
+            brightness = random.uniform(0.9, 1.1)
+            angle = random.uniform(-3, 3)
+            with self._lock:
+                aug = self.handle.tta_augment(face_region, flip, brightness, angle)
+            pred = self._single_prediction(aug)
+            if pred is not None:
+                predictions.append(pred)
+        return float(np.mean(predictions)) if predictions else None
+
     def analyze_face(self, face_region):
         """(fake_prob, fake_prob, None) or (None, None, None) (reference :517-550)."""
         try:
@@ -159,6 +185,14 @@ class DeepfakeDetector:
             if face.ndim != 3 or face.shape[2] != 3 or face.shape[0] < 1 or face.shape[1] < 1:
                 return None, None, None
             h, w = face.shape[:2]
+            if self.use_tta and self.num_tta_augmentations > 1:               # reference :524-527
+                with self._lock:
+                    pre = self.handle.preprocess_face_quality(face)
+                raw = self.analyze_face_with_tta(pre)
+                if raw is None:
+                    return None, None, None
+                p = self._heuristics_hw(self.apply_calibration(raw), h, w)
+                return p, p, None
             with self._lock:
                 logit = self.handle.classify_crops(face, [(0, 0, w, h)], apply_clahe=True)[0, 0]
             p = self._finish_face(logit, h, w)
@@ -206,8 +240,10 @@ class DeepfakeDetector:
         face_results: List[dict] = []
         confidence_level = self.temporal_tracker.get_confidence_level()
         if len(faces) > 0:
+            tta = self.use_tta and self.num_tta_augmentations > 1
             for (x, y, w, h), logit in zip(faces, logits):
-                fake_prob = self._finish_face(logit, h, w)
+                # with TTA every face goes through analyze_face (augmented copies), as the reference does (:614)
+                fake_prob = self.analyze_face(frame[y:y + h, x:x + w])[0] if tta else self._finish_face(logit, h, w)
                 if fake_prob is None:                                        # reference :616-617
                     continue
                 self.temporal_tracker.update(fake_prob)

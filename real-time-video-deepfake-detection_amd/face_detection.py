@@ -1,9 +1,8 @@
 """Host mirror of the reference's ``face_detection.py`` over the HIP SSD detector.
 
-Same functions, arguments and return conventions as reference face_detection.py:37-188.  The
-DNN branch is the only detector here (`dfd_detect_faces`); the reference's Haar cascade is a
-CPU-only fallback for missing weight files and is out of scope, so where the
-reference would fall back to Haar after an exception this module returns ``[]`` - the neutral
+Same functions, arguments and return conventions as reference face_detection.py:37-188: the DNN
+branch (`dfd_detect_faces`) when the handle carries SSD weights, else - and after a DNN failure - the
+Haar cascade (`dfd_detect_faces_haar`, `haar.py`) when the handle carries one, else ``[]``, the neutral
 value the reference itself ends with (face_detection.py:63-68).
 """
 from __future__ import annotations
@@ -30,12 +29,23 @@ def detect_bounding_box(frame, confidence_threshold: float = 0.5, *, handle: Opt
         if frame.ndim != 3 or frame.shape[2] != 3:
             return []
         h = handle or runtime.default_handle()
-        if not h.has_detector:                      # no detector weights were configured (runtime.py)
-            return []
-        return h.detect_faces(frame, confidence_threshold)
+        if not h.has_detector:                      # no SSD weights (runtime.py): the reference's Haar fallback, or []
+            return _detect_haar(frame, h) if h.has_haar else []
+        try:
+            return h.detect_faces(frame, confidence_threshold)
+        except DfdError as e:                       # reference :58-66: DNN failure -> Haar retry
+            log.warning("DNN face detection failed (%s); trying the Haar cascade", e)
+            return _detect_haar(frame, h) if h.has_haar else []
     except (DfdError, ValueError, TypeError) as e:
         log.warning("face detection failed: %s", e)
         return []
+
+
+def _detect_haar(frame, handle: Handle) -> List[Box]:
+    """reference :108-123: detectMultiScale(gray, scaleFactor=1.1, minNeighbors=5, minSize=(30, 30))"""
+    from . import haar
+
+    return haar.detect_faces_haar(frame, handle)
 
 
 def draw_bounding_boxes(frame, faces, color=(0, 255, 0), thickness: int = 2):

@@ -11,6 +11,8 @@ Weights (the reference tree ships none):
               the handle is built without one, `detect_bounding_box` returns [] and every frame is analysed in
               'frame_only' mode (where the reference, whose model files are missing too, face_detection.py:22-34,
               falls back to a Haar cascade - not built here, DESIGN.md section 8);
+  Haar        ``$DFD_HAAR_CASCADE``: OpenCV's haarcascade_frontalface_default.xml (reference face_detection.py:12) - the
+              detector the reference falls back to; used here when there are no SSD weights or the SSD call fails;
   MTCNN       ``$DFD_MTCNN_WEIGHTS``: directory with pnet.pt / rnet.pt / onet.pt (facenet-pytorch's files); without it
               the align stage is left out.
 ``DFD_SYNTHETIC_WEIGHTS=1`` (benchmarks, demos) substitutes seeded random-init detector and MTCNN weights of the same
@@ -110,7 +112,14 @@ def default_handle() -> Handle:
                     log.warning("DFD_SYNTHETIC_WEIGHTS=1: random-init MTCNN cascade - alignments are meaningless")
                 else:
                     log.warning("no MTCNN weights ($DFD_MTCNN_WEIGHTS): the align stage is left out")
-            _default = Handle(W.pack_all(default_state_dict(), ssd, mt, ssd_arch=ssd_arch), device=device_index(),
+            hc = None
+            cascade = os.environ.get("DFD_HAAR_CASCADE")
+            if cascade:
+                from . import haar
+
+                hc = haar.load_cascade_xml(cascade)
+                log.info("loaded Haar cascade %s (fallback detector)", cascade)
+            _default = Handle(W.pack_all(default_state_dict(), ssd, mt, ssd_arch=ssd_arch, haar=hc), device=device_index(),
                               max_batch=int(os.environ.get("DFD_MAX_BATCH", "16")))
         return _default
 

@@ -449,9 +449,10 @@ def pack_mtcnn_tensors(sd: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
 
 
 def pack_all(b0_sd: Mapping[str, np.ndarray], ssd_sd: Mapping[str, np.ndarray] = None,
-             mtcnn_sd: Mapping[str, np.ndarray] = None, ssd_arch=None) -> bytes:
-    """One blob for `dfd_create`: classifier + colour tables (+ detector, + MTCNN cascade when given).
-    `ssd_arch`: the detector topology `ssd_sd` belongs to (default: the built-in `ssd_arch` module)."""
+             mtcnn_sd: Mapping[str, np.ndarray] = None, ssd_arch=None, haar: Mapping[str, np.ndarray] = None) -> bytes:
+    """One blob for `dfd_create`: classifier + colour tables (+ detector, + MTCNN cascade, + Haar cascade when given).
+    `ssd_arch`: the detector topology `ssd_sd` belongs to (default: the built-in `ssd_arch` module);
+    `haar`: the arrays of `haar.load_cascade_xml` (the reference's fallback detector)."""
     from . import luts
 
     t = pack_b0_tensors(b0_sd)
@@ -460,6 +461,8 @@ def pack_all(b0_sd: Mapping[str, np.ndarray], ssd_sd: Mapping[str, np.ndarray] =
         t.update(pack_ssd_tensors(ssd_sd, ssd_arch))
     if mtcnn_sd is not None:
         t.update(pack_mtcnn_tensors(mtcnn_sd))
+    if haar is not None:
+        t.update({k: np.asarray(v, np.float32) for k, v in haar.items()})
     return serialize(t)
 
 
