@@ -339,7 +339,7 @@ def seeded_mtcnn_state_dict(seed: int = 0, head_bias=None) -> Dict[str, np.ndarr
     return sd
 
 
-MTCNN_SELECTIVE = {"pnet.conv4_1": (-3.2, 1.0), "rnet.dense5_1": (-0.4, 1.5), "onet.dense6_1": (0.6, 1.5)}
+MTCNN_SELECTIVE = {"pnet.conv4_1": (-2.4, 1.0), "rnet.dense5_1": (0.6, 1.5), "onet.dense6_1": (1.2, 1.5)}   # ~10 P-Net candidates per crop, 3 of 4 bench crops keep a face
 
 
 def load_mtcnn_checkpoints(directory: str) -> Dict[str, np.ndarray]:
