@@ -186,6 +186,33 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, w
             "note": f"{nfr} x 1080p frames from pinned host memory per call, batches of 32, upload of batch k+1 on a second "
                     "stream during batch k; 6.22 MB per frame over PCIe Gen5 x16 (63 GB/s spec)"}
         h.host_free(pinned)
+    # per-request latency of the server flow from JPEG bytes: entropy decode on the host + IDCT / colour on
+    # the device (dfd_analyze_jpeg) against host decode (Pillow) + raw upload (dfd_analyze_frame)
+    if world == 1:
+        import io
+
+        from PIL import Image
+
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(frames[0][..., ::-1])).save(buf, format="JPEG", quality=85)
+        data = buf.getvalue()
+
+        def t_ms(fn, reps=8):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        def host_path():
+            fr = np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))[..., ::-1])
+            h.analyze_frame(fr, True, stream_id=990, max_faces=1)
+
+        res["request_1080p_jpeg"] = {"jpeg_bytes": len(data),
+                                     "device_decode_ms": round(t_ms(lambda: h.analyze_jpeg(data, True, stream_id=991, max_faces=1)), 2),
+                                     "host_decode_ms": round(t_ms(host_path), 2),
+                                     "note": "one /analyze request body: forensics (full) + detect + faces[0] classify; quality-85 4:2:0 "
+                                             "JPEG of a random-texture 1080p frame (worst case for entropy coding)"}
     res["detect_classify_forensics_bf16"]["arithmetic"] = (
         "configs[3]: classifier activations stored as bf16 (fp32 accumulate, fp32-exact weights); detector, CLAHE and "
         "forensic kernels unchanged (integer / fp32: box indices must stay bit-exact); vote-equality gate: "
