@@ -115,48 +115,82 @@ def bgr2hsv_u8(bgr: np.ndarray) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------- Lab
-_LAB_SHIFT = 12
-_GAMMA_SHIFT = 3
+# OpenCV modules/imgproc/src/color_lab.cpp (4.x): RGB2Lab_b and Lab2RGBinteger with their tables as initLabTabs()
+# builds them.  OpenCV computes the tables in softfloat (IEEE binary32, round to nearest even: numpy float32 gives the
+# same +,-,*,/ bit for bit) and the two gamma curves in softdouble; where it calls its own pow / cbrt routines numpy's
+# are used (last-ulp differences possible, each rounded to an integer table entry afterwards).
+_LAB_SHIFT = 12                     # lab_shift
+_GAMMA_SHIFT = 3                    # gamma_shift
 _LAB_SHIFT2 = _LAB_SHIFT + _GAMMA_SHIFT
-_CBRT_TAB = 256 * 3 // 2 * (1 << _GAMMA_SHIFT)
+_CBRT_TAB = 256 * 3 // 2 * (1 << _GAMMA_SHIFT)          # LAB_CBRT_TAB_SIZE_B
 _D65 = (0.950456, 1.0, 1.088754)
 _RGB2XYZ = (0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227)
 _XYZ2RGB = (3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311)
-_INV_BITS = 14                      # fixed-point scale of the Lab->BGR path
-_INV_ONE = 1 << _INV_BITS
-_AB_MIN = -8145                     # smallest f(x)/f(z) the 8-bit Lab cube can produce, in 2^-14 units
-_AB_TAB = _INV_ONE * 9 // 4         # 36864 entries
+_BASE_SHIFT = 14                    # Lab2RGBinteger::base_shift
+_BASE = 1 << _BASE_SHIFT            # BASE == LAB_BASE
+_INV_GAMMA_SHIFT = 12               # inv_gamma_shift
+_INV_GAMMA_TAB = 1 << _INV_GAMMA_SHIFT                  # INV_GAMMA_TAB_SIZE
+_INV_SHIFT = _LAB_SHIFT + (_BASE_SHIFT - _INV_GAMMA_SHIFT)   # Lab2RGBinteger::shift == 14
+_AB_MIN = -8145                     # minABvalue
+_AB_TAB = _BASE * 9 // 4            # 36864 entries of abToXZ_b
+
+_f32 = np.float32
+
+
+def _cdiv(a, b):
+    """C integer division (truncation toward zero) for numpy int64 arrays, b > 0."""
+    a = np.asarray(a, np.int64)
+    return np.where(a >= 0, a // b, -((-a) // b))
+
+
+def _fma32(a, b, c):
+    """softfloat mulAdd on binary32 values: the product of two float32 is exact in float64."""
+    return (np.asarray(a, np.float64) * np.float64(b) + np.float64(c)).astype(np.float32)
 
 
 def lab_tables() -> dict:
-    """Every LUT of the 8-bit BGR<->Lab paths, built from the defining formulas in float64."""
+    """Every LUT of the 8-bit BGR<->Lab paths (initLabTabs, RGB2Lab_b / Lab2RGBinteger constructors)."""
     t = {}
-    x = np.arange(256, dtype=np.float64) / 255.0
-    lin = np.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
-    t["gamma"] = np.clip(np.rint(255.0 * (1 << _GAMMA_SHIFT) * lin), 0, 65535).astype(np.int32)
-    y = np.arange(_CBRT_TAB, dtype=np.float64) / (255.0 * (1 << _GAMMA_SHIFT))
-    f = np.where(y < 0.008856, y * 7.787 + 16.0 / 116.0, np.cbrt(y))
-    t["cbrt"] = np.clip(np.rint((1 << _LAB_SHIFT2) * f), 0, 65535).astype(np.int32)
+    # sRGBGammaTab_b[i] = cvRound(255*(1<<gamma_shift) * applyGamma(i/255)); applyGamma evaluates in double
+    x = (np.arange(256, dtype=_f32) / _f32(255)).astype(np.float64)
+    lin = np.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4).astype(_f32)
+    t["gamma"] = np.rint(_f32(255 * (1 << _GAMMA_SHIFT)) * lin).astype(np.int32)
+    # LabCbrtTab_b[i] = cvRound((1<<lab_shift2) * (x < 216/24389 ? mulAdd(x, 841/108, 16/116) : cbrt(x))), x = i/(255*8)
+    y = (_f32(1) / _f32(255 * (1 << _GAMMA_SHIFT))) * np.arange(_CBRT_TAB, dtype=_f32)
+    lthresh, lscale, lbias = _f32(216) / _f32(24389), _f32(841) / _f32(108), _f32(16) / _f32(116)
+    f = np.where(y < lthresh, _fma32(y, lscale, lbias), np.cbrt(y.astype(np.float64)).astype(_f32)).astype(_f32)
+    t["cbrt"] = np.rint(_f32(1 << _LAB_SHIFT2) * f).astype(np.int32)
+    # RGB2Lab_b: coeffs[i*3+j] = cvRound((1<<lab_shift) * sRGB2XYZ_D65[i*3+j] / D65[i]) in double
     t["fwd_coef"] = np.array([int(np.rint((1 << _LAB_SHIFT) * _RGB2XYZ[i * 3 + j] / _D65[i]))
                               for i in range(3) for j in range(3)], np.int32)      # rows X,Y,Z ; cols R,G,B
-    # inverse path
-    L = np.arange(256, dtype=np.float64) * 100.0 / 255.0
-    fy = (L + 16.0) / 116.0
-    yy = np.where(L <= 8.0, L / 903.3, fy ** 3)
-    fy = np.where(L <= 8.0, 7.787 * yy + 16.0 / 116.0, fy)
-    t["L_fy"] = np.rint(fy * _INV_ONE).astype(np.int32)
-    t["L_y"] = np.rint(yy * _INV_ONE).astype(np.int32)
-    ab = np.arange(256, dtype=np.float64) - 128.0
-    t["a_div"] = np.rint(ab / 500.0 * _INV_ONE).astype(np.int32)
-    t["b_div"] = np.rint(ab / 200.0 * _INV_ONE).astype(np.int32)
-    fv = (np.arange(_AB_TAB, dtype=np.float64) + _AB_MIN) / _INV_ONE
-    xz = np.where(fv <= 6.0 / 29.0, (fv - 16.0 / 116.0) / 7.787, fv ** 3)
-    t["ab_xz"] = np.rint(xz * _INV_ONE).astype(np.int32)
+    # ---- inverse path ----
+    # LabToYF_b: L (0..255 for 0..100) -> y and f(y), both scaled by BASE
+    i = np.arange(256)
+    fi = i.astype(_f32)
+    y_lo = np.rint((fi * _f32(_BASE * 20 * 9)) / _f32(17 * 29 * 29 * 29))        # y = L*100/255 / (29/3)^3
+    # softfloat(i*BASE*20*9): the int product is below 2^24 for i <= 20, so int->float is exact and == fi * const
+    fy_lo = np.rint(_f32(_BASE) * (_f32(16) / _f32(116) + (fi * _f32(5)) / _f32(3 * 17 * 29)))
+    fy = (i * 100 * _BASE).astype(_f32) / _f32(255 * 116) + _f32(16 * _BASE) / _f32(116)
+    y_hi = np.rint(fy * fy * fy / _f32(_BASE * _BASE))
+    dark = i <= 20                                            # 8 * 255 / 100 == 20.4
+    t["L_y"] = np.where(dark, y_lo, y_hi).astype(np.int32)
+    t["L_fy"] = np.where(dark, fy_lo, np.rint(fy)).astype(np.int32)
+    # process(): adiv = ((5*aa*53687 + (1 << 7)) >> 13) - 128*BASE/500;  bdiv = ((bb*41943 + (1 << 4)) >> 9) - 128*BASE/200 + 1
+    ab = np.arange(256, dtype=np.int64)
+    t["a_div"] = (((5 * ab * 53687 + (1 << 7)) >> 13) - 128 * _BASE // 500).astype(np.int32)
+    t["b_div"] = (((ab * 41943 + (1 << 4)) >> 9) - 128 * _BASE // 200 + 1).astype(np.int32)
+    # abToXZ_b (initLUTforABXZ), C int arithmetic: i <= 3390 (6/29*BASE): i*108/841 - BASE*16/116*108/841, else i*i/BASE*i/BASE
+    v = np.arange(_AB_TAB, dtype=np.int64) + _AB_MIN
+    lin_part = _cdiv(v * 108, 841) - (_BASE * 16 // 116 * 108 // 841)
+    cube_part = _cdiv(_cdiv(v * v, _BASE) * v, _BASE)
+    t["ab_xz"] = np.where(v <= 3390, lin_part, cube_part).astype(np.int32)
+    # Lab2RGBinteger(): coeffs = cvRound((1<<lab_shift) * XYZ2sRGB_D65[i + j*3]... * whitePt[col]) in double
     t["inv_coef"] = np.array([int(np.rint((1 << _LAB_SHIFT) * _XYZ2RGB[i * 3 + j] * _D65[j]))
                               for i in range(3) for j in range(3)], np.int32)      # rows R,G,B ; cols X,Y,Z
-    v = np.arange(_INV_ONE + 1, dtype=np.float64) / _INV_ONE
-    g = np.where(v <= 0.0031308, v * 12.92, 1.055 * v ** (1.0 / 2.4) - 0.055)
-    t["inv_gamma"] = np.clip(np.rint(g * 255.0), 0, 255).astype(np.int32)
+    # sRGBInvGammaTab_b[i] = cvRound(255 * applyInvGamma(i / INV_GAMMA_TAB_SIZE)); applyInvGamma evaluates in double
+    xv = ((_f32(1) / _f32(_INV_GAMMA_TAB)) * np.arange(_INV_GAMMA_TAB, dtype=_f32)).astype(np.float64)
+    g = np.where(xv <= 0.0031308, xv * 12.92, (xv ** (1.0 / 2.4)) * 1.055 - 0.055).astype(_f32)
+    t["inv_gamma"] = np.rint(_f32(255) * g).astype(np.int32)
     return t
 
 
@@ -183,19 +217,22 @@ def bgr2lab_u8(bgr: np.ndarray, t=None) -> np.ndarray:
 
 
 def lab2bgr_u8(lab: np.ndarray, t=None) -> np.ndarray:
-    """8-bit Lab->BGR, 14-bit integer/LUT formulation modelled on OpenCV's Lab2RGBinteger."""
+    """8-bit Lab->BGR: OpenCV's Lab2RGBinteger::process (color_lab.cpp), sRGB branch.  y and f(y) from LabToYF_b,
+    f(x) = f(y) + adiv, f(z) = f(y) - bdiv, x / z from abToXZ_b, 12-bit matrix, descale by `shift` (14) to a
+    12-bit linear value, sRGBInvGammaTab_b."""
     t = t or lab_tables()
     c = t["inv_coef"].astype(np.int64)
     fy = t["L_fy"][lab[..., 0]].astype(np.int64)
     y = t["L_y"][lab[..., 0]].astype(np.int64)
     fx = fy + t["a_div"][lab[..., 1]]
     fz = fy - t["b_div"][lab[..., 2]]
-    x = t["ab_xz"][np.clip(fx - _AB_MIN, 0, _AB_TAB - 1)].astype(np.int64)
-    z = t["ab_xz"][np.clip(fz - _AB_MIN, 0, _AB_TAB - 1)].astype(np.int64)
+    assert fx.min() >= _AB_MIN and fz.min() >= _AB_MIN and max(fx.max(), fz.max()) < _AB_TAB + _AB_MIN   # OpenCV indexes unchecked
+    x = t["ab_xz"][fx - _AB_MIN].astype(np.int64)
+    z = t["ab_xz"][fz - _AB_MIN].astype(np.int64)
     out = []
     for row in (2, 1, 0):                                     # B, G, R
-        lin = _descale(c[row * 3] * x + c[row * 3 + 1] * y + c[row * 3 + 2] * z, _LAB_SHIFT)
-        out.append(t["inv_gamma"][np.clip(lin, 0, _INV_ONE)])
+        lin = _descale(c[row * 3] * x + c[row * 3 + 1] * y + c[row * 3 + 2] * z, _INV_SHIFT)
+        out.append(t["inv_gamma"][np.clip(lin, 0, _INV_GAMMA_TAB - 1)])
     return np.stack(out, axis=-1).astype(np.uint8)
 
 

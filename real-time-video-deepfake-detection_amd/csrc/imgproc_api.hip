@@ -32,7 +32,7 @@ int color_tables_init(dfd_handle* h) {
     const Want wants[] = {{"lut.gamma", 256, &T.gamma},       {"lut.cbrt", 3072, &T.cbrt},
                           {"lut.L_fy", 256, &T.L_fy},         {"lut.L_y", 256, &T.L_y},
                           {"lut.a_div", 256, &T.a_div},       {"lut.b_div", 256, &T.b_div},
-                          {"lut.ab_xz", 36864, &T.ab_xz},     {"lut.inv_gamma", 16385, &T.inv_gamma},
+                          {"lut.ab_xz", 36864, &T.ab_xz},     {"lut.inv_gamma", 4096, &T.inv_gamma},
                           {"lut.hsv_sdiv", 256, &T.hsv_sdiv}, {"lut.hsv_hdiv", 256, &T.hsv_hdiv}};
     if (h->tensors.find("lut.gamma") == h->tensors.end()) return DFD_OK;   // blob without tables
     std::vector<float> tmp;

@@ -105,13 +105,15 @@ __device__ __forceinline__ void bgr2lab(const ColorTables& T, int b, int g, int 
 }
 
 __device__ __forceinline__ void lab2bgr(const ColorTables& T, int L, int A, int B, int& b, int& g, int& r) {
-    const int AB_MIN = -8145, AB_TAB = 36864, ONE = 1 << 14;
+    // OpenCV Lab2RGBinteger::process: LabToYF_b, adiv / bdiv, abToXZ_b (indexed from minABvalue), 12-bit matrix descaled by
+    // lab_shift + base_shift - inv_gamma_shift = 14 to a 12-bit linear value, sRGBInvGammaTab_b
+    const int AB_MIN = -8145, AB_TAB = 36864, TAB = 1 << 12;
     const long long fy = T.L_fy[L], y = T.L_y[L];
     const long long x = T.ab_xz[clampi((int)(fy + T.a_div[A]) - AB_MIN, 0, AB_TAB - 1)];
     const long long z = T.ab_xz[clampi((int)(fy - T.b_div[B]) - AB_MIN, 0, AB_TAB - 1)];
-    r = T.inv_gamma[clampi(descale(T.inv[0] * x + T.inv[1] * y + T.inv[2] * z, 12), 0, ONE)];
-    g = T.inv_gamma[clampi(descale(T.inv[3] * x + T.inv[4] * y + T.inv[5] * z, 12), 0, ONE)];
-    b = T.inv_gamma[clampi(descale(T.inv[6] * x + T.inv[7] * y + T.inv[8] * z, 12), 0, ONE)];
+    r = T.inv_gamma[clampi(descale(T.inv[0] * x + T.inv[1] * y + T.inv[2] * z, 14), 0, TAB - 1)];
+    g = T.inv_gamma[clampi(descale(T.inv[3] * x + T.inv[4] * y + T.inv[5] * z, 14), 0, TAB - 1)];
+    b = T.inv_gamma[clampi(descale(T.inv[6] * x + T.inv[7] * y + T.inv[8] * z, 14), 0, TAB - 1)];
 }
 
 // ------------------------------------------------------------------------------ CLAHE

@@ -54,6 +54,25 @@ def test_lab_roundtrip_and_anchors():
     assert d.mean() < 1.0 and np.percentile(d, 99) <= 8 and d.max() <= 32
 
 
+def test_lab2rgb_integer_table_anchors():
+    """Facts OpenCV's color_lab.cpp states about its own Lab2RGBinteger tables (source comments and constants): the a/b
+    offsets reach down to exactly minABvalue = -8145 over the 8-bit cube, abToXZ_b spans [-1335, 88231] over
+    LAB_BASE*9/4 entries, f(y) starts at BASE*16/116, the inverse gamma table has 2^12 entries ending at 255."""
+    t = R.lab_tables()
+    fx = t["L_fy"][:, None].astype(int) + t["a_div"][None, :]
+    fz = t["L_fy"][:, None].astype(int) - t["b_div"][None, :]
+    assert min(fx.min(), fz.min()) == -8145 and max(fx.max(), fz.max()) < 36864 - 8145
+    assert len(t["ab_xz"]) == 36864 and t["ab_xz"].min() == -1335 and t["ab_xz"].max() == 88231
+    assert t["L_fy"][0] == 2260 and t["L_fy"][255] == 16384 and t["L_y"][0] == 0 and t["L_y"][255] == 16384
+    assert np.all(np.diff(t["L_y"]) > 0) and np.all(np.diff(t["ab_xz"]) >= 0)
+    assert len(t["inv_gamma"]) == 4096 and t["inv_gamma"][0] == 0 and t["inv_gamma"][-1] == 255
+    assert t["a_div"][128] == 0 and t["b_div"][128] == 1          # the "+1" of bdiv is OpenCV's, "not a typo" there
+    # greys survive the 8-bit round trip within one level
+    g = np.arange(256, dtype=np.uint8)
+    grey = np.stack([g, g, g], -1)[None]
+    assert np.abs(R.lab2bgr_u8(R.bgr2lab_u8(grey, t), t).astype(int) - grey).max() <= 1
+
+
 def test_clahe_properties():
     rs = np.random.RandomState(2)
     flat = np.full((64, 64), 90, np.uint8)
