@@ -268,6 +268,8 @@ def detect_face(sd, rgb: np.ndarray, taps: dict | None = None) -> np.ndarray:
             boxes = boxes[valid]
             reg, prob = rnet(sd, data)
             score = prob[:, 1].numpy()
+            if taps is not None:
+                taps["rnet.prob"] = score.copy()
             ipass = score > np.float32(THRESHOLDS[1])
             boxes = np.concatenate([boxes[ipass, :4], score[ipass, None]], 1)
             mv = reg.numpy()[ipass]
@@ -280,6 +282,8 @@ def detect_face(sd, rgb: np.ndarray, taps: dict | None = None) -> np.ndarray:
             boxes = boxes[valid]
             reg, _points, prob = onet(sd, data)
             score = prob[:, 1].numpy()
+            if taps is not None:
+                taps["onet.prob"] = score.copy()
             ipass = score > np.float32(THRESHOLDS[2])
             boxes = np.concatenate([boxes[ipass, :4], score[ipass, None]], 1)
             boxes = bbreg(boxes, reg.numpy()[ipass])

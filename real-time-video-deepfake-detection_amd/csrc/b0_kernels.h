@@ -9,7 +9,7 @@ namespace dfd {
 // activation storage: float, or bf16_t when the handle runs with "bf16_activations" (kernel_util.h)
 typedef __bf16 bf16_t;
 
-enum Act { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
+enum Act { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_PRELU = 3 };   // PRELU: bias points at [N bias][N slope]
 
 // stem: 3x3 stride-2 conv, NCHW (n,3,224,224) -> NHWC (n,112,112,32), folded BN + swish.
 template <typename XT>

@@ -109,12 +109,13 @@ __device__ __forceinline__ void s6_epilogue(const v4f (&acc)[MT][NT], const int 
                                             const float* __restrict__ bias, const XT* __restrict__ R,
                                             XT* __restrict__ Y, int M, int N, int act, int res_first) {
     if ((N & 3) == 0) {                                  // uniform
-        v4f bv[NT], rv[MT][NT];
+        v4f bv[NT], rv[MT][NT], sv[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n = nbase + nt * 16;
             const int nc = n < N ? n : 0;
             bv[nt] = ldg4(bias + nc);
+            sv[nt] = act == ACT_PRELU ? ldg4(bias + N + nc) : (v4f){0.f, 0.f, 0.f, 0.f};      // slopes follow the bias
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int mc = m[mt] < M ? m[mt] : M - 1;
@@ -131,6 +132,9 @@ __device__ __forceinline__ void s6_epilogue(const v4f (&acc)[MT][NT], const int 
                 if (act == ACT_SWISH) v = swish4(v);
                 else if (act == ACT_RELU) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                } else if (act == ACT_PRELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * sv[nt][r];
                 }
                 if (!res_first) v += rv[mt][nt];
                 if (n < N && m[mt] < M) st4(Y + (size_t)m[mt] * N + n, v);
@@ -163,6 +167,9 @@ __device__ __forceinline__ void s6_epilogue(const v4f (&acc)[MT][NT], const int 
             if (act == ACT_SWISH) v = swish4(v);
             else if (act == ACT_RELU) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            } else if (act == ACT_PRELU) {
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < N) v[r] = v[r] >= 0.f ? v[r] : v[r] * bias[N + n + r];
             }
             if (!res_first) v += rv;
             XT* yp = Y + (size_t)m[mt] * N + n;

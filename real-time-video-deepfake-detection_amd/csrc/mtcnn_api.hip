@@ -17,8 +17,8 @@
 namespace dfd {
 
 struct MtConv { const float *w, *b, *a; int co, ci, k; };
-struct MtDense { const float *w, *b, *a; int out, in; };
-struct MtGemmConv { const float *w, *b, *a; int co, ci, k; };       // [co][ky][kx][ci], channels padded to 32 / 64
+struct MtDense { const float *w, *b, *a; int out, in; const float* ba = nullptr; };      // ba: [out bias][out slope] (GEMM epilogue)
+struct MtGemmConv { const float *w, *b, *a; int co, ci, k; const float* ba = nullptr; };   // [co][ky][kx][ci], channels padded to 32 / 64
 
 struct MtcnnState {
     bool ready = false;
@@ -29,7 +29,7 @@ struct MtcnnState {
     MtDense o5, o61, o62, o63;
     MtConv r1p;                           // R-Net conv1 with 32 output channels (4 zero filters)
     MtGemmConv r2g, r3g, o2g, o3g, o4g;
-    DevBuf in, a0, a1, z, prob, reg, win, coef, bnd, tmp, face, d_lv, d_items, d_pre;
+    DevBuf in, a0, a1, z, prob, reg, win, coef, bnd, tmp, face, d_lv, d_items, d_pre, bs;
 };
 
 void mtcnn_destroy(dfd_handle* h) {
@@ -76,70 +76,119 @@ MtGemmConv mt_gemm_conv(dfd_handle* h, const std::string& q, int co, int ci, int
     return c;
 }
 
-// valid k x k conv of `n` maps [ih][iw][ci] on the split-precision MFMA GEMM (fp32-exact products), then PReLU
+// valid k x k conv of `n` maps [ih][iw][ci] on the split-precision MFMA GEMM (fp32-exact products), PReLU in its epilogue
 int gemm_conv_prelu(dfd_handle* h, const MtGemmConv& c, const float* x, float* y, int n, int ih, int iw) {
     ConvGeom g;
     g.H = ih; g.W = iw; g.Ho = ih - c.k + 1; g.Wo = iw - c.k + 1; g.Cin = c.ci; g.ksize = c.k; g.stride = 1; g.pad = 0; g.dil = 1;
     const int K = c.k * c.k * c.ci;
     const unsigned short* w3 = split_weights(h, c.w, c.co, K);
     if (!w3) return DFD_ERR_HIP;
-    if (!launch_conv_gemm_split<float>(h->gemm, x, w3, c.b, nullptr, y, n, g, c.co, ACT_NONE, false, 3, h->stream))
+    if (!launch_conv_gemm_split<float>(h->gemm, x, w3, c.ba, nullptr, y, n, g, c.co, ACT_PRELU, false, 3, h->stream))
         return fail(h, DFD_ERR_STATE, "mtcnn: conv shape not supported by the GEMM kernel");
-    launch_mt_prelu(y, c.a, (long long)n * g.Ho * g.Wo * c.co, c.co, h->stream);
+    return DFD_OK;
+}
+
+// y[n][out] = prelu(x[n][in] . w[in][out] + b) on the same GEMM (the two wide layers: R-Net dense4, O-Net dense5)
+int gemm_dense_prelu(dfd_handle* h, const MtDense& d, const float* x, float* y, int n) {
+    const unsigned short* w3 = split_weights(h, d.w, d.out, d.in, true);        // stored [in][out]
+    if (!w3) return DFD_ERR_HIP;
+    if (!launch_pointwise_split<float>(h->gemm, x, w3, d.ba, nullptr, nullptr, y, n, d.in, d.out, 1, ACT_PRELU, 3, h->stream))
+        return fail(h, DFD_ERR_STATE, "mtcnn: dense shape not supported by the GEMM kernel");
     return DFD_OK;
 }
 
 struct Box { float x1, y1, x2, y2, score, r[4]; };
 
-// torchvision.ops.nms: descending score (stable), suppress IoU > thr, areas without the +1
-std::vector<int> nms_iou(const std::vector<Box>& b, float thr) {
-    std::vector<int> order(b.size());
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int i, int j) { return b[i].score > b[j].score; });
-    std::vector<char> dead(b.size(), 0);
+// Greedy NMS over boxes already in processing order (structure of arrays: the inner loop is branch-free and
+// vectorises).  PLUS1 = false: torchvision.ops.nms - suppress IoU > thr, areas without the +1;
+// PLUS1 = true: the package's nms_numpy(method="Min") - suppress inter / min(area) > thr, +1 on every extent.
+struct SortedBoxes {
+    std::vector<float> x1, y1, x2, y2, area;
+    std::vector<unsigned char> dead;
+    void resize(size_t n) { x1.resize(n); y1.resize(n); x2.resize(n); y2.resize(n); area.resize(n); dead.assign(n, 0); }
+};
+
+template <bool PLUS1>
+std::vector<int> greedy_nms(const std::vector<Box>& b, const std::vector<int>& order, float thr) {
+    const size_t n = order.size();
+    SortedBoxes S;
+    S.resize(n);
+    const float one = PLUS1 ? 1.f : 0.f;
+    for (size_t k = 0; k < n; ++k) {
+        const Box& q = b[order[k]];
+        S.x1[k] = q.x1; S.y1[k] = q.y1; S.x2[k] = q.x2; S.y2[k] = q.y2;
+        S.area[k] = (q.x2 - q.x1 + one) * (q.y2 - q.y1 + one);
+    }
     std::vector<int> keep;
-    for (size_t oi = 0; oi < order.size(); ++oi) {
-        const int i = order[oi];
+    const float *X1 = S.x1.data(), *Y1 = S.y1.data(), *X2 = S.x2.data(), *Y2 = S.y2.data(), *A = S.area.data();
+    unsigned char* dead = S.dead.data();
+    for (size_t i = 0; i < n; ++i) {
         if (dead[i]) continue;
-        keep.push_back(i);
-        const float ai = (b[i].x2 - b[i].x1) * (b[i].y2 - b[i].y1);
-        for (size_t oj = oi + 1; oj < order.size(); ++oj) {
-            const int j = order[oj];
-            if (dead[j]) continue;
-            const float xx1 = std::max(b[i].x1, b[j].x1), yy1 = std::max(b[i].y1, b[j].y1);
-            const float xx2 = std::min(b[i].x2, b[j].x2), yy2 = std::min(b[i].y2, b[j].y2);
-            const float inter = std::max(0.f, xx2 - xx1) * std::max(0.f, yy2 - yy1);
-            const float aj = (b[j].x2 - b[j].x1) * (b[j].y2 - b[j].y1);
-            const float iou = inter / (ai + aj - inter);
-            if (iou > thr) dead[j] = 1;
+        keep.push_back(order[i]);
+        const float ix1 = X1[i], iy1 = Y1[i], ix2 = X2[i], iy2 = Y2[i], ai = A[i];
+        for (size_t j = i + 1; j < n; ++j) {
+            const float xx1 = std::max(ix1, X1[j]), yy1 = std::max(iy1, Y1[j]);
+            const float xx2 = std::min(ix2, X2[j]), yy2 = std::min(iy2, Y2[j]);
+            const float w = std::max(0.f, xx2 - xx1 + one), hgt = std::max(0.f, yy2 - yy1 + one);
+            const float inter = w * hgt;
+            const float o = PLUS1 ? inter / std::min(ai, A[j]) : inter / (ai + A[j] - inter);
+            dead[j] |= (unsigned char)(PLUS1 ? !(o <= thr) : (o > thr));      // NaN: dropped by 'Min', kept by torchvision
         }
     }
     return keep;
 }
 
-// nms_numpy(method='Min'): ascending stable argsort, take from the end; +1 areas; keep o <= thr
+// torchvision.ops.nms: descending score (stable)
+std::vector<int> nms_iou(const std::vector<Box>& b, float thr) {
+    std::vector<int> order(b.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int i, int j) { return b[i].score > b[j].score; });
+    return greedy_nms<false>(b, order, thr);
+}
+
+// nms_numpy(method='Min'): ascending stable argsort, taken from the end (among equal scores the later box first)
 std::vector<int> nms_min(const std::vector<Box>& b, float thr) {
-    std::vector<int> idx(b.size());
-    std::iota(idx.begin(), idx.end(), 0);
-    std::stable_sort(idx.begin(), idx.end(), [&](int i, int j) { return b[i].score < b[j].score; });
-    std::vector<int> pick;
-    while (!idx.empty()) {
-        const int i = idx.back();
-        pick.push_back(i);
-        idx.pop_back();
-        const float ai = (b[i].x2 - b[i].x1 + 1.f) * (b[i].y2 - b[i].y1 + 1.f);
-        std::vector<int> rest;
-        for (int j : idx) {
-            const float xx1 = std::max(b[i].x1, b[j].x1), yy1 = std::max(b[i].y1, b[j].y1);
-            const float xx2 = std::min(b[i].x2, b[j].x2), yy2 = std::min(b[i].y2, b[j].y2);
-            const float w = std::max(0.f, xx2 - xx1 + 1.f), hgt = std::max(0.f, yy2 - yy1 + 1.f);
-            const float aj = (b[j].x2 - b[j].x1 + 1.f) * (b[j].y2 - b[j].y1 + 1.f);
-            const float o = (w * hgt) / std::min(ai, aj);
-            if (o <= thr) rest.push_back(j);
-        }
-        idx.swap(rest);
+    std::vector<int> order(b.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int i, int j) { return b[i].score < b[j].score; });
+    std::reverse(order.begin(), order.end());
+    return greedy_nms<true>(b, order, thr);
+}
+
+// nms_iou for the candidates of ONE P-Net level, which sit on the level's cell grid: equal-sized boxes (12 / scale,
+// +-1 from the floors) spaced 2 / scale apart can only reach IoU > 0.5 within two cells of each other (scale <= 0.6:
+// overlap width < (11 - 2 dx) / scale + 2 must exceed 2/3 (11 / scale - 1)^2 / (11 / scale + 1)), so every candidate is
+// tested against the kept boxes of its 9 x 9 cell neighbourhood only - same tests, same order, same result as the
+// all-pairs loop, in O(n) instead of O(kept x n).  cell[k] = y * ow + x of candidate k.
+std::vector<int> nms_iou_level(const std::vector<Box>& b, const std::vector<int>& cell, int oh, int ow, float thr,
+                               std::vector<int>* grid) {
+    constexpr int R = 4;
+    std::vector<int> order(b.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int i, int j) { return b[i].score > b[j].score; });
+    grid->assign((size_t)oh * ow, -1);                       // cell -> index of the KEPT candidate there
+    std::vector<int> keep;
+    for (int i : order) {
+        const int cy = cell[i] / ow, cx = cell[i] % ow;
+        const Box& q = b[i];
+        const float aq = (q.x2 - q.x1) * (q.y2 - q.y1);
+        bool dead = false;
+        for (int y = std::max(cy - R, 0); y <= std::min(cy + R, oh - 1) && !dead; ++y)
+            for (int x = std::max(cx - R, 0); x <= std::min(cx + R, ow - 1); ++x) {
+                const int k = (*grid)[(size_t)y * ow + x];
+                if (k < 0) continue;
+                const Box& p = b[k];
+                const float xx1 = std::max(p.x1, q.x1), yy1 = std::max(p.y1, q.y1);
+                const float xx2 = std::min(p.x2, q.x2), yy2 = std::min(p.y2, q.y2);
+                const float inter = std::max(0.f, xx2 - xx1) * std::max(0.f, yy2 - yy1);
+                const float ap = (p.x2 - p.x1) * (p.y2 - p.y1);
+                if (inter / (ap + aq - inter) > thr) { dead = true; break; }
+            }
+        if (dead) continue;
+        (*grid)[cell[i]] = i;
+        keep.push_back(i);
     }
-    return pick;
+    return keep;
 }
 
 void bbreg(Box& b) {
@@ -305,13 +354,14 @@ struct Cascade {
             if ((rc = ensure(h, &S->reg, pre_r.back() * 4))) return rc;
             float *in = (float*)S->in.p, *a0 = (float*)S->a0.p, *a1 = (float*)S->a1.p;
             launch_mt_area_resize_ragged((const MtLevel*)S->d_lv.p, pre_at(0), nl, pre_in.back(), in, s);
-            launch_mt_conv_ragged(in, S->p1.w, S->p1.b, S->p1.a, a0, item_at(0), pre_at(1), nl, pre_c1.back(), 3, 10, 3, s);
+            // P-Net: register-blocked convolutions; conv3 evaluates both 1x1 heads and the softmax from its registers
+            // (prob [cell], reg [cell][4]; the 32-channel map is never stored)
+            const MtPnetHeads heads{S->p41.w, S->p41.b, S->p42.w, S->p42.b, (float*)S->prob.p, (float*)S->reg.p};
+            bool ok = launch_mt_convpx_ragged(in, S->p1.w, S->p1.b, S->p1.a, a0, item_at(0), pre_at(1), nl, pre_c1.back(), 3, 10, 3, nullptr, s);
             launch_mt_maxpool_ragged(a0, a1, item_at(1), pre_at(2), nl, pre_p.back(), 10, 2, 2, s);
-            launch_mt_conv_ragged(a1, S->p2.w, S->p2.b, S->p2.a, a0, item_at(2), pre_at(3), nl, pre_c2.back(), 10, 16, 3, s);
-            launch_mt_conv_ragged(a0, S->p3.w, S->p3.b, S->p3.a, a1, item_at(3), pre_at(4), nl, pre_c3.back(), 16, 32, 3, s);
-            launch_mt_conv_ragged(a1, S->p41.w, S->p41.b, nullptr, (float*)S->z.p, item_at(4), pre_at(5), nl, pre_z.back(), 32, 2, 1, s);
-            launch_mt_softmax_face((const float*)S->z.p, (float*)S->prob.p, cells, s);
-            launch_mt_conv_ragged(a1, S->p42.w, S->p42.b, nullptr, (float*)S->reg.p, item_at(5), pre_at(6), nl, pre_r.back(), 32, 4, 1, s);
+            ok = ok && launch_mt_convpx_ragged(a1, S->p2.w, S->p2.b, S->p2.a, a0, item_at(2), pre_at(3), nl, pre_c2.back(), 10, 16, 3, nullptr, s);
+            ok = ok && launch_mt_convpx_ragged(a0, S->p3.w, S->p3.b, S->p3.a, nullptr, item_at(3), pre_at(4), nl, pre_c3.back(), 16, 32, 3, &heads, s);
+            if (!ok) return fail(h, DFD_ERR_STATE, "mtcnn: no P-Net kernel instance for this layer shape");
             DFD_HIP_TRY(h, hipGetLastError());
             prob.resize(cells);
             DFD_HIP_TRY(h, hipMemcpyAsync(prob.data(), S->prob.p, cells * 4, hipMemcpyDeviceToHost, s));
@@ -319,6 +369,7 @@ struct Cascade {
         }
         // host: generateBoundingBox per level, per-scale NMS, cross-scale NMS, regression, rerec - per crop
         std::vector<std::vector<Box>> all(n);
+        std::vector<int> grid;
         int level_in_crop = 0, prev_crop = -1;
         for (const Level& L : levels) {
             level_in_crop = L.crop == prev_crop ? level_in_crop + 1 : 0;
@@ -336,6 +387,7 @@ struct Cascade {
                 }
             }
             std::vector<Box> bs;
+            std::vector<int> cell;
             const float fs = (float)L.scale;
             for (int y = 0; y < L.oh; ++y)
                 for (int x = 0; x < L.ow; ++x) {
@@ -349,8 +401,9 @@ struct Cascade {
                     b.score = p;
                     for (int r = 0; r < 4; ++r) b.r[r] = R[((size_t)y * L.ow + x) * 4 + r];
                     bs.push_back(b);
+                    cell.push_back(y * L.ow + x);
                 }
-            for (int i : nms_iou(bs, 0.5f)) all[L.crop].push_back(bs[i]);
+            for (int i : nms_iou_level(bs, cell, L.oh, L.ow, 0.5f, &grid)) all[L.crop].push_back(bs[i]);
         }
         for (int c = 0; c < n; ++c) {
             for (int i : nms_iou(all[c], 0.7f)) {
@@ -388,24 +441,24 @@ struct Cascade {
             float *in = (float*)S->in.p, *a0 = (float*)S->a0.p, *a1 = (float*)S->a1.p;
             launch_mt_area_resize_multi(wd, m, sz, sz, in, s);
             if (!onet) {
-                launch_mt_conv(in, S->r1p.w, S->r1p.b, S->r1p.a, a0, m, 24, 24, 3, 32, 3, s);      // 22, 32 ch (28 + 4 zero)
+                launch_mt_convpx(in, S->r1p.w, S->r1p.b, S->r1p.a, a0, m, 24, 24, 3, 32, 3, s);    // 22, 32 ch (28 + 4 zero)
                 launch_mt_maxpool(a0, a1, m, 22, 22, 32, 3, 2, s);                                  // 11
                 if ((rc = gemm_conv_prelu(h, S->r2g, a1, a0, m, 11, 11))) return rc;                // 9, 64 ch (48 + 16 zero)
                 launch_mt_maxpool(a0, a1, m, 9, 9, 64, 3, 2, s);                                    // 4
                 if ((rc = gemm_conv_prelu(h, S->r3g, a1, a0, m, 4, 4))) return rc;                  // 3 -> [m][3][3][64]
-                launch_mt_dense(a0, S->r4.w, S->r4.b, S->r4.a, a1, m, 576, 128, s);
+                if ((rc = gemm_dense_prelu(h, S->r4, a0, a1, m))) return rc;                        // 576 -> 128
                 launch_mt_dense(a1, S->r51.w, S->r51.b, nullptr, a0, m, 128, 2, s);
                 launch_mt_softmax_face(a0, (float*)S->prob.p, m, s);
                 launch_mt_dense(a1, S->r52.w, S->r52.b, nullptr, (float*)S->reg.p, m, 128, 4, s);
             } else {
-                launch_mt_conv(in, S->o1.w, S->o1.b, S->o1.a, a0, m, 48, 48, 3, 32, 3, s);         // 46
+                launch_mt_convpx(in, S->o1.w, S->o1.b, S->o1.a, a0, m, 48, 48, 3, 32, 3, s);       // 46
                 launch_mt_maxpool(a0, a1, m, 46, 46, 32, 3, 2, s);                                  // 23
                 if ((rc = gemm_conv_prelu(h, S->o2g, a1, a0, m, 23, 23))) return rc;                // 21
                 launch_mt_maxpool(a0, a1, m, 21, 21, 64, 3, 2, s);                                  // 10
                 if ((rc = gemm_conv_prelu(h, S->o3g, a1, a0, m, 10, 10))) return rc;                // 8
                 launch_mt_maxpool(a0, a1, m, 8, 8, 64, 2, 2, s);                                    // 4
                 if ((rc = gemm_conv_prelu(h, S->o4g, a1, a0, m, 4, 4))) return rc;                  // 3 -> [m][3][3][128]
-                launch_mt_dense(a0, S->o5.w, S->o5.b, S->o5.a, a1, m, 1152, 256, s);
+                if ((rc = gemm_dense_prelu(h, S->o5, a0, a1, m))) return rc;                        // 1152 -> 256
                 launch_mt_dense(a1, S->o61.w, S->o61.b, nullptr, a0, m, 256, 2, s);
                 launch_mt_softmax_face(a0, (float*)S->prob.p, m, s);
                 launch_mt_dense(a1, S->o62.w, S->o62.b, nullptr, (float*)S->reg.p, m, 256, 4, s);
@@ -526,6 +579,23 @@ int mtcnn_init(dfd_handle* h) {
     S->o3g = mt_gemm_conv(h, "onet.conv3", 64, 64, 3, &ok);
     S->o4g = mt_gemm_conv(h, "onet.conv4", 128, 64, 2, &ok);
     if (!ok) return DFD_ERR_BLOB;
+    // [bias | slope] pairs for the GEMM epilogue's PReLU
+    struct Pair { const float *b, *a; int n; const float** out; };
+    const Pair pairs[] = {{S->r2g.b, S->r2g.a, S->r2g.co, &S->r2g.ba}, {S->r3g.b, S->r3g.a, S->r3g.co, &S->r3g.ba},
+                          {S->o2g.b, S->o2g.a, S->o2g.co, &S->o2g.ba}, {S->o3g.b, S->o3g.a, S->o3g.co, &S->o3g.ba},
+                          {S->o4g.b, S->o4g.a, S->o4g.co, &S->o4g.ba}, {S->r4.b, S->r4.a, S->r4.out, &S->r4.ba},
+                          {S->o5.b, S->o5.a, S->o5.out, &S->o5.ba}};
+    size_t floats = 0;
+    for (const Pair& p : pairs) floats += 2 * (size_t)p.n;
+    int rc = ensure(h, &S->bs, floats * 4);
+    if (rc) return rc;
+    float* dst = (float*)S->bs.p;
+    for (const Pair& p : pairs) {
+        DFD_HIP_TRY(h, hipMemcpyAsync(dst, p.b, (size_t)p.n * 4, hipMemcpyDeviceToDevice, h->stream));
+        DFD_HIP_TRY(h, hipMemcpyAsync(dst + p.n, p.a, (size_t)p.n * 4, hipMemcpyDeviceToDevice, h->stream));
+        *p.out = dst;
+        dst += 2 * p.n;
+    }
     S->ready = true;
     return DFD_OK;
 }

@@ -35,6 +35,14 @@ void launch_mt_area_resize_ragged(const MtLevel* lv_dev, const long long* pre_de
 void launch_mt_conv_ragged(const float* x, const float* w, const float* b, const float* slope, float* y,
                            const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co, int k,
                            hipStream_t s);
+// register-blocked variants (thread per output pixel, weights in LDS); false = no instance for that shape.
+// With `heads` (P-Net conv3) the 1x1 heads + softmax run in the same launch: prob [cell], reg [cell][4]; y is not written.
+struct MtPnetHeads { const float *w41, *b41, *w42, *b42; float *prob, *reg; };
+bool launch_mt_convpx_ragged(const float* x, const float* w, const float* b, const float* slope, float* y,
+                             const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co, int k,
+                             const MtPnetHeads* heads, hipStream_t s);
+bool launch_mt_convpx(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int ih, int iw,
+                      int ci, int co, int k, hipStream_t s);
 void launch_mt_maxpool_ragged(const float* x, float* y, const MtItem* items_dev, const long long* pre_dev, int n, long long total,
                               int c, int k, int st, hipStream_t s);
 void launch_mt_area_resize_multi(const MtSrcWindow* win_dev, int n, int oh, int ow, float* dst, hipStream_t s);

@@ -249,6 +249,174 @@ void launch_mt_conv_ragged(const float* x, const float* w, const float* b, const
                        pre_dev, n, ci, co, k);
 }
 
+// Register-blocked valid convolution, one thread per output pixel (P pixels per thread, all CO channels of each in
+// registers), weights [ci][ky][kx][co] staged once per block in LDS and read as wave-uniform broadcasts.  Replaces the
+// thread-per-output-element kernels above for the layers that carry the cascade's arithmetic (P-Net on every pyramid
+// level of every crop; the 3 -> 32 first convolution of R-/O-Net on every candidate window): those issue two loads
+// per FMA, this one CI*K*K activation loads per CI*K*K*CO FMAs.  Every output still accumulates its products as
+// fmaf in (ci, ky, kx) order, then + bias, then PReLU: bit-identical to mt_conv_kernel / mt_conv_ragged_kernel.
+//   items != null: ragged launch (pre = running totals of output ELEMENTS, as for the kernels above);
+//   items == null: `n` maps of ih x iw.
+//   HEADS (P-Net conv3, CO = 32): the two 1x1 heads and the softmax are evaluated from the registers - the launch
+//   writes prob [cell] and reg [cell][4] and never stores the 32-channel map.
+template <int CI, int CO, int K, int P, bool HEADS>
+__global__ __launch_bounds__(256) void mt_convpx_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, const float* __restrict__ slope,
+                                                        float* __restrict__ y, const MtItem* __restrict__ items,
+                                                        const long long* __restrict__ pre, int n, int ih_u, int iw_u,
+                                                        const float* __restrict__ w41, const float* __restrict__ b41,
+                                                        const float* __restrict__ w42, const float* __restrict__ b42,
+                                                        float* __restrict__ prob, float* __restrict__ reg) {
+    constexpr int CC = CI % 2 == 0 ? 2 : 1;                  // channels per activation load
+    constexpr int NW = CI * K * K * CO;
+    __shared__ __attribute__((aligned(16))) float sw[NW + (HEADS ? CO * 6 + 8 : 0)];
+    for (int i = threadIdx.x; i < NW; i += 256) sw[i] = w[i];
+    if (HEADS) {
+        for (int i = threadIdx.x; i < CO * 2; i += 256) sw[NW + i] = w41[i];
+        for (int i = threadIdx.x; i < CO * 4; i += 256) sw[NW + CO * 2 + i] = w42[i];
+        if (threadIdx.x < 2) sw[NW + CO * 6 + threadIdx.x] = b41[threadIdx.x];
+        if (threadIdx.x < 4) sw[NW + CO * 6 + 2 + threadIdx.x] = b42[threadIdx.x];
+    }
+    __syncthreads();
+    const int oh_u = ih_u - K + 1, ow_u = iw_u - K + 1;
+    const long long npix = items ? pre[n] / CO : (long long)n * oh_u * ow_u;
+    const long long G = (long long)gridDim.x * 256, g = (long long)blockIdx.x * 256 + threadIdx.x;
+    const float* xp[P];
+    long long opix[P];                                       // output pixel index in the arena (element offset / CO)
+    int iw[P];
+    bool ok[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const long long pix = g + p * G;
+        ok[p] = pix < npix;
+        const long long q = ok[p] ? pix : 0;
+        if (items) {
+            const int i = mt_find(pre, n, q * CO);
+            const MtItem it = items[i];
+            const long long r = q - pre[i] / CO;
+            const int ow = it.iw - K + 1;
+            const int oy = (int)(r / ow), ox = (int)(r % ow);
+            iw[p] = it.iw;
+            xp[p] = x + it.in_off + ((size_t)oy * it.iw + ox) * CI;
+            opix[p] = it.out_off / CO + r;
+        } else {
+            const long long per = (long long)oh_u * ow_u;
+            const long long i = q / per;
+            const int r = (int)(q % per), oy = r / ow_u, ox = r % ow_u;
+            iw[p] = iw_u;
+            xp[p] = x + ((i * ih_u + oy) * iw_u + ox) * CI;
+            opix[p] = q;
+        }
+    }
+    float acc[P][CO];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[p][o] = 0.f;
+#pragma unroll 1
+    for (int c0 = 0; c0 < CI; c0 += CC) {
+        float xv[K][K][P][CC];
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const float* q = xp[p] + ((size_t)ky * iw[p] + kx) * CI + c0;
+                    if (CC == 2) {
+                        const float2 v = *reinterpret_cast<const float2*>(q);
+                        xv[ky][kx][p][0] = v.x;
+                        xv[ky][kx][p][CC - 1] = v.y;
+                    } else {
+                        xv[ky][kx][p][0] = *q;
+                    }
+                }
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const float* wr = sw + (((c0 + cc) * K + ky) * K + kx) * CO;
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) {
+                        const float wv = wr[o];
+#pragma unroll
+                        for (int p = 0; p < P; ++p) acc[p][o] = fmaf(xv[ky][kx][p][cc], wv, acc[p][o]);
+                    }
+                }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            float v = acc[p][o] + b[o];
+            if (slope) v = v >= 0.f ? v : v * slope[o];
+            acc[p][o] = v;
+        }
+        if (!ok[p]) continue;
+        if (HEADS) {
+            const float* h41 = sw + NW;
+            const float* h42 = sw + NW + CO * 2;
+            float z[2] = {0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) z[j] = fmaf(acc[p][c], h41[c * 2 + j], z[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r4[j] = fmaf(acc[p][c], h42[c * 4 + j], r4[j]);
+            }
+            const float z0 = z[0] + sw[NW + CO * 6], z1 = z[1] + sw[NW + CO * 6 + 1];
+            const float m = fmaxf(z0, z1);
+            const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+            prob[opix[p]] = e1 / (e0 + e1);
+            float4 rv;
+            rv.x = r4[0] + sw[NW + CO * 6 + 2]; rv.y = r4[1] + sw[NW + CO * 6 + 3];
+            rv.z = r4[2] + sw[NW + CO * 6 + 4]; rv.w = r4[3] + sw[NW + CO * 6 + 5];
+            *reinterpret_cast<float4*>(reg + opix[p] * 4) = rv;
+        } else {
+            float* yp = y + opix[p] * CO;
+            if (CO % 4 == 0) {
+#pragma unroll
+                for (int o = 0; o < CO; o += 4)
+                    *reinterpret_cast<float4*>(yp + o) = make_float4(acc[p][o], acc[p][o + 1], acc[p][o + 2], acc[p][o + 3]);
+            } else {
+#pragma unroll
+                for (int o = 0; o < CO; o += 2) *reinterpret_cast<float2*>(yp + o) = make_float2(acc[p][o], acc[p][o + 1]);
+            }
+        }
+    }
+}
+
+template <int CI, int CO, int K, int P, bool HEADS>
+static void convpx_launch(const float* x, const float* w, const float* b, const float* slope, float* y, const MtItem* items,
+                          const long long* pre, int n, long long npix, int ih, int iw, const MtPnetHeads* hd, hipStream_t s) {
+    if (npix <= 0) return;
+    const long long threads = (npix + P - 1) / P;
+    hipLaunchKernelGGL((mt_convpx_kernel<CI, CO, K, P, HEADS>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, w, b,
+                       slope, y, items, pre, n, ih, iw, hd ? hd->w41 : nullptr, hd ? hd->b41 : nullptr, hd ? hd->w42 : nullptr,
+                       hd ? hd->b42 : nullptr, hd ? hd->prob : nullptr, hd ? hd->reg : nullptr);
+}
+
+bool launch_mt_convpx_ragged(const float* x, const float* w, const float* b, const float* slope, float* y,
+                             const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co, int k,
+                             const MtPnetHeads* heads, hipStream_t s) {
+    const long long npix = total / co;
+    if (ci == 3 && co == 10 && k == 3 && !heads) convpx_launch<3, 10, 3, 4, false>(x, w, b, slope, y, items_dev, pre_dev, n, npix, 0, 0, nullptr, s);
+    else if (ci == 10 && co == 16 && k == 3 && !heads) convpx_launch<10, 16, 3, 4, false>(x, w, b, slope, y, items_dev, pre_dev, n, npix, 0, 0, nullptr, s);
+    else if (ci == 16 && co == 32 && k == 3 && heads) convpx_launch<16, 32, 3, 4, true>(x, w, b, slope, y, items_dev, pre_dev, n, npix, 0, 0, heads, s);
+    else return false;
+    return true;
+}
+
+bool launch_mt_convpx(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int ih, int iw,
+                      int ci, int co, int k, hipStream_t s) {
+    const long long npix = (long long)n * (ih - k + 1) * (iw - k + 1);
+    if (ci == 3 && co == 32 && k == 3) convpx_launch<3, 32, 3, 4, false>(x, w, b, slope, y, nullptr, nullptr, n, npix, ih, iw, nullptr, s);
+    else return false;
+    return true;
+}
+
 __global__ __launch_bounds__(256) void mt_maxpool_ragged_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 const MtItem* __restrict__ items, const long long* __restrict__ pre,
                                                                 int n, int c, int k, int st) {

@@ -90,3 +90,39 @@ def test_classify_crops_with_alignment(pkg, mt_handle, sd, seeded_sd):
     finally:
         mt_handle.set_option("mtcnn", 1)
     assert not np.isnan(plain).any() and np.abs(plain[ok] - got[ok]).max() > 1e-3     # a different crop reaches B0
+
+
+def test_selective_cascade_batch(pkg, seeded_sd):
+    """The funnel of a trained cascade (weights.MTCNN_SELECTIVE: most pyramid cells and windows rejected) through the
+    batched crop path: which crops keep a face, and their logits, equal the oracle's per-crop run.  A window whose
+    R-/O-Net probability lies within 1e-4 of 0.7 may fall either way (the wide dense layers run on the split-precision
+    GEMM, another summation order than the oracle's): such crops are reported and skipped, not hidden."""
+    W = pkg.weights
+    sel = W.seeded_mtcnn_state_dict(0, W.MTCNN_SELECTIVE)
+    tsel = W.to_torch(sel)
+    h = pkg._lib.Handle(W.pack_all(seeded_sd, W.seeded_ssd_state_dict(0), sel), device=0, max_batch=16)
+    try:
+        frame = np.random.default_rng(7).integers(50, 200, (2, 1080, 1920, 3), dtype=np.uint8)[0]     # the bench's frame 0
+        boxes = np.array([[200, 150, 320, 400], [900, 300, 256, 256], [1400, 500, 400, 480], [600, 700, 224, 224],
+                          [100, 600, 300, 300], [1200, 80, 280, 330]], np.int32)
+        got = h.classify_crops(frame, boxes, apply_clahe=True).reshape(-1)
+        b0 = W.to_torch(seeded_sd)
+        found_want, ambiguous = [], []
+        for k, (x, y, w, hh) in enumerate(boxes):
+            crop = imgproc_ref.preprocess_face_quality(frame[y:y + hh, x:x + w])
+            taps = {}
+            face = M.mtcnn_forward(tsel, np.ascontiguousarray(crop[..., ::-1]), taps)
+            probs = np.concatenate([np.asarray(taps.get(n, []), np.float32).reshape(-1) for n in ("rnet.prob", "onet.prob")])
+            if probs.size and np.abs(probs - 0.7).min() <= 1e-4:
+                ambiguous.append(k)
+            found_want.append(face is not None)
+            if face is not None and k not in ambiguous:
+                face_bgr = np.ascontiguousarray(face.transpose(1, 2, 0)[..., ::-1]).astype(np.uint8)
+                want = float(b0_ref.forward(b0, torch.from_numpy(imgproc_ref.crop_resize_normalize(face_bgr)[None])).reshape(-1)[0])
+                assert abs(got[k] - want) <= 1e-3, (k, got[k], want)
+        keep = [k for k in range(len(boxes)) if k not in ambiguous]
+        assert len(keep) >= 4, f"threshold-ambiguous crops {ambiguous}: pick another seed"
+        assert [bool(~np.isnan(got[k])) for k in keep] == [found_want[k] for k in keep], (got, found_want, ambiguous)
+        assert any(found_want) and not all(found_want)          # the funnel both passes and rejects crops
+    finally:
+        h.close()
