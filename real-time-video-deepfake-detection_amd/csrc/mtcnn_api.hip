@@ -441,8 +441,8 @@ struct Cascade {
             float *in = (float*)S->in.p, *a0 = (float*)S->a0.p, *a1 = (float*)S->a1.p;
             launch_mt_area_resize_multi(wd, m, sz, sz, in, s);
             if (!onet) {
-                launch_mt_convpx(in, S->r1p.w, S->r1p.b, S->r1p.a, a0, m, 24, 24, 3, 32, 3, s);    // 22, 32 ch (28 + 4 zero)
-                launch_mt_maxpool(a0, a1, m, 22, 22, 32, 3, 2, s);                                  // 11
+                // conv1 (22, 32 ch = 28 + 4 zero) + PReLU + pool (11) in one launch
+                if (!launch_mt_conv1_pool(in, S->r1p.w, S->r1p.b, S->r1p.a, a1, m, 24, 24, 32, s)) return fail(h, DFD_ERR_STATE, "mtcnn: conv1+pool shape");
                 if ((rc = gemm_conv_prelu(h, S->r2g, a1, a0, m, 11, 11))) return rc;                // 9, 64 ch (48 + 16 zero)
                 launch_mt_maxpool(a0, a1, m, 9, 9, 64, 3, 2, s);                                    // 4
                 if ((rc = gemm_conv_prelu(h, S->r3g, a1, a0, m, 4, 4))) return rc;                  // 3 -> [m][3][3][64]
@@ -451,8 +451,8 @@ struct Cascade {
                 launch_mt_softmax_face(a0, (float*)S->prob.p, m, s);
                 launch_mt_dense(a1, S->r52.w, S->r52.b, nullptr, (float*)S->reg.p, m, 128, 4, s);
             } else {
-                launch_mt_convpx(in, S->o1.w, S->o1.b, S->o1.a, a0, m, 48, 48, 3, 32, 3, s);       // 46
-                launch_mt_maxpool(a0, a1, m, 46, 46, 32, 3, 2, s);                                  // 23
+                // conv1 (46) + PReLU + pool (23) in one launch
+                if (!launch_mt_conv1_pool(in, S->o1.w, S->o1.b, S->o1.a, a1, m, 48, 48, 32, s)) return fail(h, DFD_ERR_STATE, "mtcnn: conv1+pool shape");
                 if ((rc = gemm_conv_prelu(h, S->o2g, a1, a0, m, 23, 23))) return rc;                // 21
                 launch_mt_maxpool(a0, a1, m, 21, 21, 64, 3, 2, s);                                  // 10
                 if ((rc = gemm_conv_prelu(h, S->o3g, a1, a0, m, 10, 10))) return rc;                // 8

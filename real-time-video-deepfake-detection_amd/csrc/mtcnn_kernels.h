@@ -43,6 +43,9 @@ bool launch_mt_convpx_ragged(const float* x, const float* w, const float* b, con
                              const MtPnetHeads* heads, hipStream_t s);
 bool launch_mt_convpx(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int ih, int iw,
                       int ci, int co, int k, hipStream_t s);
+// conv 3x3 (3 -> 32) + bias + PReLU + MaxPool2d(3, 2, ceil_mode=True) of `n` maps [ih][iw][3] -> [ph][pw][32]
+bool launch_mt_conv1_pool(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int ih, int iw,
+                          int co, hipStream_t s);
 void launch_mt_maxpool_ragged(const float* x, float* y, const MtItem* items_dev, const long long* pre_dev, int n, long long total,
                               int c, int k, int st, hipStream_t s);
 void launch_mt_area_resize_multi(const MtSrcWindow* win_dev, int n, int oh, int ow, float* dst, hipStream_t s);

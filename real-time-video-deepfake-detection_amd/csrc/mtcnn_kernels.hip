@@ -12,6 +12,8 @@
 //   mt_pil_pass       one pass of Pillow's 8-bit fixed-point Image.resize (coefficients from the host)
 #include "mtcnn_kernels.h"
 
+#include <cstdlib>
+
 namespace dfd {
 
 __global__ __launch_bounds__(256) void mt_area_resize_kernel(const uint8_t* __restrict__ src, size_t stride,
@@ -386,6 +388,151 @@ __global__ __launch_bounds__(256) void mt_convpx_kernel(const float* __restrict_
             }
         }
     }
+}
+
+// Scalar (wave-uniform) operand loads under program control: 16 consecutive floats of a kernel-argument array into
+// SGPRs.  Plain C++ reads of uniform addresses also become s_load, but hipcc hoists all of a loop's invariant ones to
+// the top and then spills hundreds of SGPR values lane by lane (v_readlane): here the load is issued one group ahead of
+// its use and the wait names the registers it releases.
+typedef float sf16 __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int BYTE_OFF>
+__device__ __forceinline__ sf16 sload16(const float* p) {
+    sf16 v;
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(p), "n"(BYTE_OFF));
+    return v;
+}
+__device__ __forceinline__ sf16 sload16s(const float* p, int byte_off) {      // offset in an SGPR: usable from an unrolled loop
+    sf16 v;
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(p), "s"(byte_off));
+    return v;
+}
+__device__ __forceinline__ void swait1(sf16& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
+__device__ __forceinline__ void swait2(sf16& a, sf16& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+
+// First layer of R-Net / O-Net with its pooling: conv 3x3 (3 -> 32) + bias + PReLU + MaxPool2d(3, 2, ceil_mode) in one
+// launch.  A thread owns one pooled column of one window and walks down the convolution rows: per row it evaluates the
+// three convolution pixels of its pooling window (all 32 channels in registers, products accumulated as fmaf in
+// (ci, ky, kx) order like mt_conv_kernel: the same bits), keeps their maximum, and folds rows 2p, 2p+1, 2p+2 into pooled
+// row p.  The 46x46x32 (22x22x32) map is never stored: 8.5 GB of writes and as many reads per 25k windows gone, for
+// 1.5x the convolution arithmetic (columns 2p+2 / 2p are evaluated by both neighbours).  Weights, bias and slopes are
+// SGPR operands (sload16, one tap ahead): no LDS or VGPR traffic for them.
+// blockIdx.y = channel half: 16 of the 32 output channels per thread (3 waves per SIMD without spills)
+__global__ __launch_bounds__(256, 3) void mt_conv1_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ b, const float* __restrict__ slope,
+                                                               float* __restrict__ y, int n, int ih, int iw, int ph, int pw) {
+    constexpr int CO = 32, CH = 16;
+    const int half = blockIdx.y;
+    w += half * CH;
+    b += half * CH;
+    slope += half * CH;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long tc = min(t, (long long)n * pw - 1);     // surplus threads of the last block redo its last column
+    const int px = (int)(tc % pw);
+    const long long i = tc / pw;
+    const int oh = ih - 2, ow = iw - 2;
+    const float* xi = x + (size_t)i * ih * iw * 3;
+    float* yo = y + ((size_t)i * ph * pw + px) * CO + half * CH;
+    int col[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) col[j] = min(2 * px + j, iw - 1) * 3;
+    const bool v1 = 2 * px + 1 < ow, v2 = 2 * px + 2 < ow;
+    float rows[3][5][3], nxt[5][3];                        // input rows y, y+1, y+2 (x 5 columns x RGB) and y+3 in flight
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            rows[1][j][c] = xi[col[j] + c];
+            rows[2][j][c] = xi[(size_t)iw * 3 + col[j] + c];
+            nxt[j][c] = xi[(size_t)2 * iw * 3 + col[j] + c];
+        }
+    float m[CH];
+#pragma unroll
+    for (int o = 0; o < CH; ++o) m[o] = 0.f;
+#pragma unroll 1
+    for (int yy = 0; yy < oh; ++yy) {
+        sf16 wn = sload16<0>(w);
+        // the row needed by the NEXT iteration is requested now: a whole row of arithmetic hides its latency (the SQ
+        // counters of the version that loaded row y+2 at the top of iteration y showed 69 % of the wave cycles waiting)
+        const size_t rn = (size_t)min(yy + 3, ih - 1) * iw * 3;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rows[0][j][c] = rows[1][j][c];
+                rows[1][j][c] = rows[2][j][c];
+                rows[2][j][c] = nxt[j][c];
+                nxt[j][c] = xi[rn + col[j] + c];
+            }
+        float acc[3][CH];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int o = 0; o < CH; ++o) acc[p][o] = 0.f;
+        // one tap per step: the 16 weights of this thread's channel half as SGPR operands, the next tap's in flight
+        // meanwhile.  The compiler must never spill an in-flight group - a spill right after the asm would copy registers
+        // the load has not written yet (tests/test_build_isa.py checks the row loop's ISA for v_writelane).
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int c = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+            swait1(wn);
+            const sf16 wc = wn;
+            if (tap + 1 < 27) wn = sload16s(w, (tap + 1) * 128);
+            // two output channels per instruction: v_pk_fma_f32 with the SGPR weight pair as one operand (each half an IEEE fma)
+#pragma unroll
+            for (int o = 0; o < CH; o += 2)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const float xv = rows[ky][p + kx][c];
+                    const v2f x2 = {xv, xv};
+                    v2f a = {acc[p][o], acc[p][o + 1]};
+                    a = __builtin_elementwise_fma(x2, (v2f){wc[o], wc[o + 1]}, a);
+                    acc[p][o] = a.x; acc[p][o + 1] = a.y;
+                }
+        }
+        const bool even = (yy & 1) == 0;
+        sf16 bv = sload16<0>(b), sv = sload16<0>(slope);
+        swait2(bv, sv);
+#pragma unroll
+        for (int o = 0; o < CH; ++o) {
+            float v0 = acc[0][o] + bv[o], u1 = acc[1][o] + bv[o], u2 = acc[2][o] + bv[o];
+            v0 = v0 >= 0.f ? v0 : v0 * sv[o];
+            u1 = u1 >= 0.f ? u1 : u1 * sv[o];
+            u2 = u2 >= 0.f ? u2 : u2 * sv[o];
+            float h = v0;
+            if (v1) h = fmaxf(h, u1);
+            if (v2) h = fmaxf(h, u2);
+            const float full = fmaxf(m[o], h);              // odd row: second row of the window; even row: its third
+            acc[0][o] = full;
+            m[o] = even ? h : full;                         // an even row also opens pooled row yy / 2
+        }
+        if (even && yy > 0 && t == tc) {
+            float* yp = yo + (size_t)(yy / 2 - 1) * pw * CO;
+#pragma unroll
+            for (int o = 0; o < CH; o += 4)
+                *reinterpret_cast<float4*>(yp + o) = make_float4(acc[0][o], acc[0][o + 1], acc[0][o + 2], acc[0][o + 3]);
+        }
+    }
+    // the clipped last window (ceil mode): rows 2(ph-1) .. oh-1 are in m
+    if (t == tc) {
+        float* yp = yo + (size_t)(ph - 1) * pw * CO;
+#pragma unroll
+        for (int o = 0; o < CH; o += 4) *reinterpret_cast<float4*>(yp + o) = make_float4(m[o], m[o + 1], m[o + 2], m[o + 3]);
+    }
+}
+
+bool launch_mt_conv1_pool(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int ih, int iw,
+                          int co, hipStream_t s) {
+    const int oh = ih - 2, ow = iw - 2, ph = mt_pool_out(oh, 3, 2), pw = mt_pool_out(ow, 3, 2);
+    // the row walk above assumes the last pooled row / column is a clipped window that starts inside the map
+    if (co != 32 || !slope || oh < 3 || ow < 3 || 2 * (ph - 1) > oh - 1 || 2 * (ph - 1) + 2 < oh - 1 || 2 * (pw - 1) > ow - 1 ||
+        2 * (pw - 1) + 2 < ow - 1)
+        return false;
+    const long long threads = (long long)n * pw;
+    if (threads <= 0) return true;
+    hipLaunchKernelGGL(mt_conv1_pool_kernel, dim3((unsigned)((threads + 255) / 256), 2), dim3(256), 0, s, x, w, b, slope, y, n, ih,
+                       iw, ph, pw);
+    return true;
 }
 
 template <int CI, int CO, int K, int P, bool HEADS>

@@ -1,0 +1,37 @@
+"""Build-time checks on the generated gfx950 ISA (no GPU needed: hipcc cross-compiles).
+
+mt_conv1_pool_kernel feeds its weights to v_pk_fma_f32 as SGPR operands loaded by inline-asm s_load_dwordx16 one step
+ahead of their use.  The compiler does not know those registers are still being written until the following s_waitcnt,
+so an SGPR spill (v_writelane_b32) placed between the two would save stale values - the failure showed up on the GPU
+as a handful of R-Net windows with slightly wrong features.  The kernel is written to stay below the SGPR budget; this
+test keeps it there."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "real-time-video-deepfake-detection_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_conv1_pool_kernel_has_no_sgpr_spills():
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "mtcnn_kernels.s")
+        subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "--cuda-device-only", "-S",
+                        os.path.join(CSRC, "mtcnn_kernels.hip"), "-o", out], check=True, cwd=CSRC)
+        lines = open(out).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3dfd20mt_conv1_pool_kernel") and ":" in l)
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    body = lines[start:end]
+    ops = [m.group(1) for l in body for m in [re.match(r"\s+([a-z_0-9]+)", l)] if m]
+    assert ops.count("s_load_dwordx16") >= 29 and ops.count("v_pk_fma_f32") == 27 * 24        # SGPR operands, packed FMAs
+    # spills of loop-invariant pointers before the row loop are harmless; none may follow the first asm load
+    first_load = next(i for i, l in enumerate(body) if "s_load_dwordx16" in l)
+    assert not any("v_writelane_b32" in l for l in body[first_load:]), "SGPR spill inside mt_conv1_pool_kernel's row loop"
+    meta = "\n".join(lines[end:end + 80])
+    assert int(re.search(r"; Occupancy: (\d+)", meta).group(1)) >= 3
