@@ -8,7 +8,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <atomic>
 #include <numeric>
+#include <thread>
 
 #include "b0_kernels.h"
 #include "dfd_common.h"
@@ -95,6 +97,26 @@ int gemm_dense_prelu(dfd_handle* h, const MtDense& d, const float* x, float* y, 
     if (!launch_pointwise_split<float>(h->gemm, x, w3, d.ba, nullptr, nullptr, y, n, d.in, d.out, 1, ACT_PRELU, 3, h->stream))
         return fail(h, DFD_ERR_STATE, "mtcnn: dense shape not supported by the GEMM kernel");
     return DFD_OK;
+}
+
+// The box bookkeeping of independent crops / pyramid levels on a few host threads when there is enough of it (a dense
+// cascade hands thousands of candidates per crop to the O(kept x n) NMS loops); `fn(i)` must only write slot i.
+template <typename F>
+void parallel_for(int count, size_t work, F fn) {
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nt = std::min(std::min(count, 8), std::max(hw / 2, 1));
+    if (nt <= 1 || work < 200000) {
+        for (int i = 0; i < count; ++i) fn(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    auto run = [&] {
+        for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(run);
+    run();
+    for (auto& th : pool) th.join();
 }
 
 struct Box { float x1, y1, x2, y2, score, r[4]; };
@@ -267,6 +289,15 @@ struct Cascade {
 
     bool want(const std::string& nm) const { return tap_name && nm == tap_name; }
 
+    std::chrono::steady_clock::time_point t_mark = std::chrono::steady_clock::now();
+    void mark(const char* what) {                          // DFD_MT_VERBOSE=2: wall time of each phase
+        static const bool on = getenv("DFD_MT_VERBOSE") && atoi(getenv("DFD_MT_VERBOSE")) >= 2;
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[dfd]   %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_mark).count());
+        t_mark = now;
+    }
+
     template <typename T>
     int upload(DevBuf* buf, const std::vector<T>& v) {
         int rc = ensure(h, buf, std::max<size_t>(v.size() * sizeof(T), 16));
@@ -328,6 +359,7 @@ struct Cascade {
                 minl *= 0.709;
             }
         }
+        mark("s1 host: pyramid tables");
         out->assign(n, {});
         const int nl = (int)levels.size();
         std::vector<float> prob, reg;
@@ -367,27 +399,34 @@ struct Cascade {
             DFD_HIP_TRY(h, hipMemcpyAsync(prob.data(), S->prob.p, cells * 4, hipMemcpyDeviceToHost, s));
             if ((rc = download(S->reg.p, (size_t)cells * 4, &reg))) return rc;
         }
+        mark("s1 gpu: P-Net + download");
         // host: generateBoundingBox per level, per-scale NMS, cross-scale NMS, regression, rerec - per crop
         std::vector<std::vector<Box>> all(n);
-        std::vector<int> grid;
         int level_in_crop = 0, prev_crop = -1;
-        for (const Level& L : levels) {
+        for (const Level& L : levels) {                      // parity taps (crop 0 only)
             level_in_crop = L.crop == prev_crop ? level_in_crop + 1 : 0;
             prev_crop = L.crop;
+            if (L.crop != 0 || !tap_name) continue;
             const float* P = prob.data() + L.cell_off;
             const float* R = reg.data() + L.cell_off * 4;
-            if (L.crop == 0) {
-                if (want("pnet.prob." + std::to_string(level_in_crop))) {
-                    tap->assign(P, P + (size_t)std::max(L.oh, 0) * std::max(L.ow, 0));
-                    tap_dims[0] = L.oh; tap_dims[1] = L.ow; tap_dims[2] = 1;
-                }
-                if (want("pnet.reg." + std::to_string(level_in_crop))) {
-                    tap->assign(R, R + (size_t)std::max(L.oh, 0) * std::max(L.ow, 0) * 4);
-                    tap_dims[0] = L.oh; tap_dims[1] = L.ow; tap_dims[2] = 4;
-                }
+            if (want("pnet.prob." + std::to_string(level_in_crop))) {
+                tap->assign(P, P + (size_t)std::max(L.oh, 0) * std::max(L.ow, 0));
+                tap_dims[0] = L.oh; tap_dims[1] = L.ow; tap_dims[2] = 1;
             }
+            if (want("pnet.reg." + std::to_string(level_in_crop))) {
+                tap->assign(R, R + (size_t)std::max(L.oh, 0) * std::max(L.ow, 0) * 4);
+                tap_dims[0] = L.oh; tap_dims[1] = L.ow; tap_dims[2] = 4;
+            }
+        }
+        std::vector<std::vector<Box>> kept(levels.size());
+        size_t cand = 0;                                     // threads only when the funnel lets many cells through
+        for (float p : prob) cand += p >= 0.6f;
+        parallel_for((int)levels.size(), cand * 100, [&](int li) {
+            const Level& L = levels[li];
+            const float* P = prob.data() + L.cell_off;
+            const float* R = reg.data() + L.cell_off * 4;
             std::vector<Box> bs;
-            std::vector<int> cell;
+            std::vector<int> cell, grid;
             const float fs = (float)L.scale;
             for (int y = 0; y < L.oh; ++y)
                 for (int x = 0; x < L.ow; ++x) {
@@ -403,9 +442,13 @@ struct Cascade {
                     bs.push_back(b);
                     cell.push_back(y * L.ow + x);
                 }
-            for (int i : nms_iou_level(bs, cell, L.oh, L.ow, 0.5f, &grid)) all[L.crop].push_back(bs[i]);
-        }
-        for (int c = 0; c < n; ++c) {
+            for (int i : nms_iou_level(bs, cell, L.oh, L.ow, 0.5f, &grid)) kept[li].push_back(bs[i]);
+        });
+        size_t pairs = 0;
+        for (size_t li = 0; li < levels.size(); ++li) all[levels[li].crop].insert(all[levels[li].crop].end(), kept[li].begin(), kept[li].end());
+        for (int c = 0; c < n; ++c) pairs += all[c].size() * all[c].size();
+        mark("s1 host: scan + level NMS");
+        parallel_for(n, pairs, [&](int c) {
             for (int i : nms_iou(all[c], 0.7f)) {
                 Box b = all[c][i];
                 const float regw = b.x2 - b.x1, regh = b.y2 - b.y1;
@@ -414,7 +457,8 @@ struct Cascade {
                 rerec(b);
                 (*out)[c].push_back(b);
             }
-        }
+        });
+        mark("s1 host: cross-level NMS");
         tap_boxes("stage1", (*out)[0]);
         return DFD_OK;
     }
@@ -499,10 +543,27 @@ struct Cascade {
                     live[c].push_back(b);
                 }
             std::vector<float> prob, reg;
+            mark("host: windows");
             if (!wins.empty() && (rc = refine(stage == 3, wins, &prob, &reg))) return rc;
-            size_t k = 0;
+            mark("gpu: refine + download");
+            std::vector<size_t> first(n + 1, 0);
+            size_t pairs = 0;
             for (int c = 0; c < n; ++c) {
-                const size_t first = k;
+                first[c + 1] = first[c] + live[c].size();
+                pairs += live[c].size() * live[c].size();
+            }
+            if (!live[0].empty()) {
+                if (want(stage == 2 ? "rnet.prob" : "onet.prob")) {
+                    tap->assign(prob.begin(), prob.begin() + first[1]);
+                    tap_dims[0] = (int)first[1]; tap_dims[1] = 1; tap_dims[2] = 1;
+                }
+                if (want(stage == 2 ? "rnet.reg" : "onet.reg")) {
+                    tap->assign(reg.begin(), reg.begin() + first[1] * 4);
+                    tap_dims[0] = (int)first[1]; tap_dims[1] = 4; tap_dims[2] = 1;
+                }
+            }
+            parallel_for(n, pairs, [&](int c) {
+                size_t k = first[c];
                 std::vector<Box> pass;
                 for (const Box& lb : live[c]) {
                     if (prob[k] > 0.7f) {                        // thresholds[1] = thresholds[2] = 0.7, strict
@@ -513,16 +574,6 @@ struct Cascade {
                     }
                     ++k;
                 }
-                if (c == 0 && !live[0].empty()) {
-                    if (want(stage == 2 ? "rnet.prob" : "onet.prob")) {
-                        tap->assign(prob.begin() + first, prob.begin() + k);
-                        tap_dims[0] = (int)(k - first); tap_dims[1] = 1; tap_dims[2] = 1;
-                    }
-                    if (want(stage == 2 ? "rnet.reg" : "onet.reg")) {
-                        tap->assign(reg.begin() + first * 4, reg.begin() + k * 4);
-                        tap_dims[0] = (int)(k - first); tap_dims[1] = 4; tap_dims[2] = 1;
-                    }
-                }
                 boxes[c].clear();
                 if (stage == 2) {
                     for (int i : nms_iou(pass, 0.7f)) { Box b = pass[i]; bbreg(b); rerec(b); boxes[c].push_back(b); }
@@ -530,7 +581,8 @@ struct Cascade {
                     for (Box& b : pass) bbreg(b);
                     for (int i : nms_min(pass, 0.7f)) boxes[c].push_back(pass[i]);
                 }
-            }
+            });
+            mark("host: threshold + NMS");
             tap_boxes(stage == 2 ? "stage2" : "stage3", boxes[0]);
             if (verbose) {
                 size_t tot = 0;
