@@ -31,10 +31,13 @@ struct MtcnnState {
     MtDense o5, o61, o62, o63;
     MtConv r1p;                           // R-Net conv1 with 32 output channels (4 zero filters)
     MtGemmConv r2g, r3g, o2g, o3g, o4g;
-    DevBuf in, a0, a1, z, prob, reg, win, coef, bnd, tmp, face, d_lv, d_items, d_pre, bs;
+    DevBuf in, a0, a1, z, prob, reg, win, coef, bnd, tmp, face, d_lv, d_items, d_pre, bs, cand;
+    void* pin = nullptr;                  // pinned host staging for the candidate download
+    size_t pin_cap = 0;
 };
 
 void mtcnn_destroy(dfd_handle* h) {
+    if (h->mtcnn && h->mtcnn->pin) (void)hipHostFree(h->mtcnn->pin);
     delete h->mtcnn;
     h->mtcnn = nullptr;
 }
@@ -363,6 +366,7 @@ struct Cascade {
         out->assign(n, {});
         const int nl = (int)levels.size();
         std::vector<float> prob, reg;
+        std::vector<MtCand> cands;
         if (nl) {
             // descriptors: one upload each (pageable source: staged before the call returns)
             if ((rc = upload(&S->d_lv, lv))) return rc;
@@ -388,16 +392,45 @@ struct Cascade {
             launch_mt_area_resize_ragged((const MtLevel*)S->d_lv.p, pre_at(0), nl, pre_in.back(), in, s);
             // P-Net: register-blocked convolutions; conv3 evaluates both 1x1 heads and the softmax from its registers
             // (prob [cell], reg [cell][4]; the 32-channel map is never stored)
-            const MtPnetHeads heads{S->p41.w, S->p41.b, S->p42.w, S->p42.b, (float*)S->prob.p, (float*)S->reg.p};
+            // 16 bytes of counter, then the records
+            if ((rc = ensure(h, &S->cand, 16 + (size_t)cells * sizeof(MtCand)))) return rc;
+            unsigned* d_count = (unsigned*)S->cand.p;
+            MtCand* d_cand = (MtCand*)((char*)S->cand.p + 16);
+            DFD_HIP_TRY(h, hipMemsetAsync(d_count, 0, 16, s));
+            const MtPnetHeads heads{S->p41.w, S->p41.b, S->p42.w, S->p42.b, (float*)S->prob.p, (float*)S->reg.p,
+                                    d_cand, d_count, (unsigned)cells, 0.6f};                  // thresholds[0], >=, float32
             bool ok = launch_mt_convpx_ragged(in, S->p1.w, S->p1.b, S->p1.a, a0, item_at(0), pre_at(1), nl, pre_c1.back(), 3, 10, 3, nullptr, s);
             launch_mt_maxpool_ragged(a0, a1, item_at(1), pre_at(2), nl, pre_p.back(), 10, 2, 2, s);
             ok = ok && launch_mt_convpx_ragged(a1, S->p2.w, S->p2.b, S->p2.a, a0, item_at(2), pre_at(3), nl, pre_c2.back(), 10, 16, 3, nullptr, s);
             ok = ok && launch_mt_convpx_ragged(a0, S->p3.w, S->p3.b, S->p3.a, nullptr, item_at(3), pre_at(4), nl, pre_c3.back(), 16, 32, 3, &heads, s);
             if (!ok) return fail(h, DFD_ERR_STATE, "mtcnn: no P-Net kernel instance for this layer shape");
             DFD_HIP_TRY(h, hipGetLastError());
-            prob.resize(cells);
-            DFD_HIP_TRY(h, hipMemcpyAsync(prob.data(), S->prob.p, cells * 4, hipMemcpyDeviceToHost, s));
-            if ((rc = download(S->reg.p, (size_t)cells * 4, &reg))) return rc;
+            // the candidates (cells at or above the threshold), not the maps: count first, then that many records,
+            // both through pinned memory; the atomic append order is restored to (level, y, x) by sorting on the cell
+            if (!S->pin) {
+                DFD_HIP_TRY(h, hipHostMalloc(&S->pin, 1 << 20, hipHostMallocDefault));
+                S->pin_cap = 1 << 20;
+            }
+            DFD_HIP_TRY(h, hipMemcpyAsync(S->pin, d_count, 4, hipMemcpyDeviceToHost, s));
+            DFD_HIP_TRY(h, hipStreamSynchronize(s));
+            const size_t nc = std::min<size_t>(*(const unsigned*)S->pin, (size_t)cells);
+            if (nc * sizeof(MtCand) > S->pin_cap) {
+                (void)hipHostFree(S->pin);
+                S->pin = nullptr;
+                S->pin_cap = (nc * sizeof(MtCand) + (1 << 20)) & ~(size_t)((1 << 20) - 1);
+                DFD_HIP_TRY(h, hipHostMalloc(&S->pin, S->pin_cap, hipHostMallocDefault));
+            }
+            if (nc) {
+                DFD_HIP_TRY(h, hipMemcpyAsync(S->pin, d_cand, nc * sizeof(MtCand), hipMemcpyDeviceToHost, s));
+                DFD_HIP_TRY(h, hipStreamSynchronize(s));
+            }
+            cands.assign((const MtCand*)S->pin, (const MtCand*)S->pin + nc);
+            std::sort(cands.begin(), cands.end(), [](const MtCand& a, const MtCand& b) { return a.cell < b.cell; });
+            if (tap_name) {                                   // parity taps read whole maps
+                prob.resize(cells);
+                DFD_HIP_TRY(h, hipMemcpyAsync(prob.data(), S->prob.p, cells * 4, hipMemcpyDeviceToHost, s));
+                if ((rc = download(S->reg.p, (size_t)cells * 4, &reg))) return rc;
+            }
         }
         mark("s1 gpu: P-Net + download");
         // host: generateBoundingBox per level, per-scale NMS, cross-scale NMS, regression, rerec - per crop
@@ -419,29 +452,33 @@ struct Cascade {
             }
         }
         std::vector<std::vector<Box>> kept(levels.size());
-        size_t cand = 0;                                     // threads only when the funnel lets many cells through
-        for (float p : prob) cand += p >= 0.6f;
-        parallel_for((int)levels.size(), cand * 100, [&](int li) {
+        // first candidate of each level in the cell-sorted list (levels own consecutive cell ranges)
+        std::vector<size_t> lfirst(levels.size() + 1, cands.size());
+        {
+            size_t k = 0;
+            for (size_t li = 0; li < levels.size(); ++li) {
+                while (k < cands.size() && (long long)cands[k].cell < levels[li].cell_off) ++k;
+                lfirst[li] = k;
+            }
+        }
+        parallel_for((int)levels.size(), cands.size() * 100, [&](int li) {
             const Level& L = levels[li];
-            const float* P = prob.data() + L.cell_off;
-            const float* R = reg.data() + L.cell_off * 4;
             std::vector<Box> bs;
             std::vector<int> cell, grid;
             const float fs = (float)L.scale;
-            for (int y = 0; y < L.oh; ++y)
-                for (int x = 0; x < L.ow; ++x) {
-                    const float p = P[(size_t)y * L.ow + x];
-                    if (!(p >= 0.6f)) continue;                   // cells with prob >= thresholds[0], (y, x) order; float32
-                    Box b{};
-                    b.x1 = std::floor((2.f * (float)x + 1.f) / fs);
-                    b.y1 = std::floor((2.f * (float)y + 1.f) / fs);
-                    b.x2 = std::floor((2.f * (float)x + 12.f) / fs);
-                    b.y2 = std::floor((2.f * (float)y + 12.f) / fs);
-                    b.score = p;
-                    for (int r = 0; r < 4; ++r) b.r[r] = R[((size_t)y * L.ow + x) * 4 + r];
-                    bs.push_back(b);
-                    cell.push_back(y * L.ow + x);
-                }
+            for (size_t k = lfirst[li]; k < lfirst[li + 1]; ++k) {          // (y, x) order within the level
+                const MtCand& q = cands[k];
+                const int rel = (int)((long long)q.cell - L.cell_off), y = rel / L.ow, x = rel % L.ow;
+                Box b{};
+                b.x1 = std::floor((2.f * (float)x + 1.f) / fs);
+                b.y1 = std::floor((2.f * (float)y + 1.f) / fs);
+                b.x2 = std::floor((2.f * (float)x + 12.f) / fs);
+                b.y2 = std::floor((2.f * (float)y + 12.f) / fs);
+                b.score = q.p;
+                for (int r = 0; r < 4; ++r) b.r[r] = q.r[r];
+                bs.push_back(b);
+                cell.push_back(rel);
+            }
             for (int i : nms_iou_level(bs, cell, L.oh, L.ow, 0.5f, &grid)) kept[li].push_back(bs[i]);
         });
         size_t pairs = 0;
@@ -666,13 +703,15 @@ int mtcnn_align_batch_device(dfd_handle* h, const MtImage* imgs, int n, uint8_t*
     int rc = c.run(&boxes);
     if (rc) return rc;
     hipStream_t s = h->stream;
-    // selection + extract_face geometry on the host; all resize coefficient tables in one upload
-    struct Job { int x1, y1, cw, ch, kx, ky; size_t cx, bx, cy, by, tmp; };
-    std::vector<Job> jobs(n);
+    // selection + extract_face geometry on the host; all resize coefficient tables and the job list in one upload each,
+    // all crops resampled by two launches
+    std::vector<MtFaceJob> jobs(n);
     std::vector<int> tables;
     size_t tmp_bytes = 0;
     for (int i = 0; i < n; ++i) {
         found[i] = 0;
+        MtFaceJob& j = jobs[i];
+        j = MtFaceJob{imgs[i].src, (long long)imgs[i].stride, 0, 0, 160, 160, 0, 0, 0, 0, 0, 0, 0, 0};
         if (boxes[i].empty()) continue;
         // select_boxes(method="probability"): np.argsort(probs)[::-1][0] = the LAST of the ascending stable order
         int best = 0;
@@ -684,45 +723,29 @@ int mtcnn_align_batch_device(dfd_handle* h, const MtImage* imgs, int n, uint8_t*
         const int x1 = (int)std::max(b.x1, 0.f), y1 = (int)std::max(b.y1, 0.f);
         const int x2 = (int)std::min(b.x2, (float)imgs[i].w), y2 = (int)std::min(b.y2, (float)imgs[i].h);
         if (x2 <= x1 || y2 <= y1) continue;
-        Job j{x1, y1, x2 - x1, y2 - y1, 0, 0, 0, 0, 0, 0, tmp_bytes};
+        j.x1 = x1; j.y1 = y1; j.cw = x2 - x1; j.ch = y2 - y1;
+        j.tmp_off = (long long)tmp_bytes;
         std::vector<int> coeff, bounds;
-        if (j.cw != 160) {
+        if (j.cw != 160) {                                   // crop.resize((160, 160), BILINEAR): horizontal pass into tmp [ch][160][3]
             pil_coeffs(j.cw, 160, &coeff, &bounds, &j.kx);
-            j.cx = tables.size(); tables.insert(tables.end(), coeff.begin(), coeff.end());
-            j.bx = tables.size(); tables.insert(tables.end(), bounds.begin(), bounds.end());
-            tmp_bytes += ((size_t)j.ch * 160 * 3 + 255) & ~(size_t)255;
+            j.cx = (int)tables.size(); tables.insert(tables.end(), coeff.begin(), coeff.end());
+            j.bx = (int)tables.size(); tables.insert(tables.end(), bounds.begin(), bounds.end());
+            if (j.ch != 160) tmp_bytes += ((size_t)j.ch * 160 * 3 + 255) & ~(size_t)255;
         }
-        if (j.ch != 160) {
+        if (j.ch != 160) {                                   // ... vertical pass into the face slot
             pil_coeffs(j.ch, 160, &coeff, &bounds, &j.ky);
-            j.cy = tables.size(); tables.insert(tables.end(), coeff.begin(), coeff.end());
-            j.by = tables.size(); tables.insert(tables.end(), bounds.begin(), bounds.end());
+            j.cy = (int)tables.size(); tables.insert(tables.end(), coeff.begin(), coeff.end());
+            j.by = (int)tables.size(); tables.insert(tables.end(), bounds.begin(), bounds.end());
         }
-        jobs[i] = j;
+        j.found = 1;
         found[i] = 1;
     }
     if ((rc = c.upload(&S->coef, tables))) return rc;
+    if ((rc = c.upload(&S->bnd, jobs))) return rc;
     if ((rc = ensure(h, &S->tmp, std::max<size_t>(tmp_bytes, 16)))) return rc;
-    const int* T = (const int*)S->coef.p;
-    for (int i = 0; i < n; ++i) {
-        uint8_t* face = faces_out + (size_t)i * 160 * 160 * 3;
-        if (!found[i]) { DFD_HIP_TRY(h, hipMemsetAsync(face, 0, 160 * 160 * 3, s)); continue; }
-        const Job& j = jobs[i];
-        // crop.resize((160, 160), BILINEAR): horizontal pass into tmp [ch][160][3], vertical pass into the face slot
-        const uint8_t* src = imgs[i].src;
-        size_t sstride = imgs[i].stride;
-        int sx = j.x1, sy = j.y1;
-        if (j.cw != 160) {
-            uint8_t* dst = j.ch == 160 ? face : (uint8_t*)S->tmp.p + j.tmp;
-            launch_mt_pil_pass(src, sstride, sx, sy, j.cw, j.ch, T + j.cx, T + j.bx, j.kx, 160, 0, dst, s);
-            src = dst; sstride = 160 * 3; sx = 0; sy = 0;
-        }
-        if (j.ch != 160) launch_mt_pil_pass(src, sstride, sx, sy, 160, j.ch, T + j.cy, T + j.by, j.ky, 160, 1, face, s);
-        else if (j.cw == 160)                                // already 160 x 160: plain copy of the window
-            DFD_HIP_TRY(h, hipMemcpy2DAsync(face, 160 * 3, imgs[i].src + (size_t)j.y1 * imgs[i].stride + (size_t)j.x1 * 3,
-                                            imgs[i].stride, 160 * 3, 160, hipMemcpyDeviceToDevice, s));
-    }
+    launch_mt_extract_faces((const MtFaceJob*)S->bnd.p, n, (const int*)S->coef.p, faces_out, (uint8_t*)S->tmp.p, s);
     DFD_HIP_TRY(h, hipGetLastError());
-    DFD_HIP_TRY(h, hipStreamSynchronize(s));          // `tables` (host) feeds the copy above
+    DFD_HIP_TRY(h, hipStreamSynchronize(s));          // `tables` / `jobs` (host) feed the copies above
     return DFD_OK;
 }
 

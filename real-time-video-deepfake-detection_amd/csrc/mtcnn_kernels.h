@@ -37,7 +37,17 @@ void launch_mt_conv_ragged(const float* x, const float* w, const float* b, const
                            hipStream_t s);
 // register-blocked variants (thread per output pixel, weights in LDS); false = no instance for that shape.
 // With `heads` (P-Net conv3) the 1x1 heads + softmax run in the same launch: prob [cell], reg [cell][4]; y is not written.
-struct MtPnetHeads { const float *w41, *b41, *w42, *b42; float *prob, *reg; };
+// a P-Net cell whose face probability reaches the stage-1 threshold: appended (unordered, atomic counter) by the conv3
+// launch so that the host downloads candidates instead of whole probability / regression maps
+struct MtCand { unsigned cell; float p; float r[4]; };
+struct MtPnetHeads {
+    const float *w41, *b41, *w42, *b42;
+    float *prob, *reg;
+    MtCand* cand;            // [cand_cap]
+    unsigned* cand_count;    // zeroed by the caller; may exceed cand_cap (then only cand_cap records were written)
+    unsigned cand_cap;
+    float thr;
+};
 bool launch_mt_convpx_ragged(const float* x, const float* w, const float* b, const float* slope, float* y,
                              const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co, int k,
                              const MtPnetHeads* heads, hipStream_t s);
@@ -51,6 +61,11 @@ void launch_mt_maxpool_ragged(const float* x, float* y, const MtItem* items_dev,
 void launch_mt_area_resize_multi(const MtSrcWindow* win_dev, int n, int oh, int ow, float* dst, hipStream_t s);
 // in-place PReLU over NHWC data with `c` channels
 void launch_mt_prelu(float* x, const float* slope, long long n, int c, hipStream_t s);
+// extract_face of every crop of a step: window (x1, y1, cw x ch) of the image at src -> 160 x 160 x 3 (Pillow bilinear,
+// horizontal then vertical pass; coefficient / bounds tables at the given int offsets of one table array); found = 0:
+// the slot is zero-filled.  tmp_off: byte offset of the crop's [ch][160][3] intermediate.
+struct MtFaceJob { const uint8_t* src; long long stride; int x1, y1, cw, ch, kx, ky, cx, bx, cy, by; long long tmp_off; int found; };
+void launch_mt_extract_faces(const MtFaceJob* jobs_dev, int n, const int* tables_dev, uint8_t* faces, uint8_t* tmp, hipStream_t s);
 void launch_mt_face_chw(const uint8_t* bgr, float* out, int hw, hipStream_t s);
 
 }  // namespace dfd

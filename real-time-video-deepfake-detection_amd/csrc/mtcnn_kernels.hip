@@ -169,6 +169,62 @@ void launch_mt_pil_pass(const uint8_t* src, size_t stride, int x0, int y0, int s
                        bounds_dev, ksize, out, vertical, dst);
 }
 
+// extract_face for all crops of a step in two launches (blockIdx.y = crop): the horizontal pass of every crop whose
+// window is not 160 wide, then the vertical pass / plain copy / zero fill that completes each 160x160x3 face slot.
+// Per element the arithmetic is mt_pil_pass_kernel's.
+__device__ __forceinline__ uint8_t pil_tap_sum(const uint8_t* __restrict__ p, size_t step, const int* __restrict__ kk, int cnt) {
+    int ss = 1 << 21;
+    for (int k = 0; k < cnt; ++k) ss += kk[k] * (int)p[(size_t)k * step];
+    int v = ss >> 22;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+__global__ __launch_bounds__(256) void mt_extract_h_kernel(const MtFaceJob* __restrict__ jobs, const int* __restrict__ tables,
+                                                           uint8_t* __restrict__ faces, uint8_t* __restrict__ tmp) {
+    const MtFaceJob j = jobs[blockIdx.y];
+    if (!j.found || j.cw == 160) return;
+    uint8_t* dst = j.ch == 160 ? faces + (size_t)blockIdx.y * 160 * 160 * 3 : tmp + j.tmp_off;
+    const int total = j.ch * 160 * 3;
+    const int* coeff = tables + j.cx;
+    const int* bounds = tables + j.bx;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const int c = t % 3, col = (t / 3) % 160, row = t / 3 / 160;
+        const int xmin = bounds[2 * col], cnt = bounds[2 * col + 1];
+        dst[t] = pil_tap_sum(j.src + (size_t)(j.y1 + row) * j.stride + (size_t)(j.x1 + xmin) * 3 + c, 3, coeff + (size_t)col * j.kx, cnt);
+    }
+}
+
+__global__ __launch_bounds__(256) void mt_extract_v_kernel(const MtFaceJob* __restrict__ jobs, const int* __restrict__ tables,
+                                                           uint8_t* __restrict__ faces, const uint8_t* __restrict__ tmp) {
+    const MtFaceJob j = jobs[blockIdx.y];
+    uint8_t* dst = faces + (size_t)blockIdx.y * 160 * 160 * 3;
+    const int total = 160 * 160 * 3;
+    if (j.found && j.ch == 160 && j.cw != 160) return;                      // completed by the horizontal pass
+    const bool resized = j.cw != 160;                                       // the vertical pass reads tmp [ch][160][3]
+    const uint8_t* src = resized ? tmp + j.tmp_off : j.src + (size_t)j.y1 * j.stride + (size_t)j.x1 * 3;
+    const size_t sstride = resized ? 160 * 3 : (size_t)j.stride;
+    const int* coeff = tables + j.cy;
+    const int* bounds = tables + j.by;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        const int c = t % 3, col = (t / 3) % 160, row = t / 3 / 160;
+        uint8_t v = 0;
+        if (j.found) {
+            if (j.ch == 160) v = src[(size_t)row * sstride + (size_t)col * 3 + c];                 // 160 x 160 window: copy
+            else {
+                const int ymin = bounds[2 * row], cnt = bounds[2 * row + 1];
+                v = pil_tap_sum(src + (size_t)ymin * sstride + (size_t)col * 3 + c, sstride, coeff + (size_t)row * j.ky, cnt);
+            }
+        }
+        dst[t] = v;
+    }
+}
+
+void launch_mt_extract_faces(const MtFaceJob* jobs_dev, int n, const int* tables_dev, uint8_t* faces, uint8_t* tmp, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(mt_extract_h_kernel, dim3(64, n), dim3(256), 0, s, jobs_dev, tables_dev, faces, tmp);
+    hipLaunchKernelGGL(mt_extract_v_kernel, dim3(64, n), dim3(256), 0, s, jobs_dev, tables_dev, faces, tmp);
+}
+
 // u8 BGR [n][hw][3] -> float RGB CHW (0..255), the tensor MTCNN.forward returns with post_process=False
 __global__ __launch_bounds__(256) void mt_face_chw_kernel(const uint8_t* __restrict__ bgr, float* __restrict__ out, int hw) {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -196,29 +252,35 @@ __device__ __forceinline__ int mt_find(const long long* __restrict__ pre, int n,
     return lo;
 }
 
+// one thread per output pixel (three channel sums share the window walk and the index arithmetic; the sums are exact
+// integers below 2^24, so their order is free); pre = running totals of output ELEMENTS (pixels x 3)
 __global__ __launch_bounds__(256) void mt_area_resize_ragged_kernel(const MtLevel* __restrict__ lv,
                                                                     const long long* __restrict__ pre, int n,
                                                                     float* __restrict__ dst) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= pre[n]) return;
-    const int i = mt_find(pre, n, t);
+    if (t * 3 >= pre[n]) return;
+    const int i = mt_find(pre, n, t * 3);
     const MtLevel L = lv[i];
-    const long long r = t - pre[i];
-    const int c = (int)(r % 3), ox = (int)((r / 3) % L.ow), oy = (int)(r / 3 / L.ow);
+    const long long r = t - pre[i] / 3;
+    const int ox = (int)(r % L.ow), oy = (int)(r / L.ow);
     const int y0 = (int)(((long long)oy * L.h) / L.oh), y1 = (int)((((long long)oy + 1) * L.h + L.oh - 1) / L.oh);
     const int x0 = (int)(((long long)ox * L.w) / L.ow), x1 = (int)((((long long)ox + 1) * L.w + L.ow - 1) / L.ow);
-    const uint8_t* p = L.src + (2 - c);
-    float sum = 0.f;
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) sum += (float)p[(size_t)y * L.stride + (size_t)x * 3];
-    const float mean = sum / (float)((y1 - y0) * (x1 - x0));
-    dst[L.out_off + r] = (mean - 127.5f) * 0.0078125f;
+    int sb = 0, sg = 0, sr = 0;
+    for (int y = y0; y < y1; ++y) {
+        const uint8_t* p = L.src + (size_t)y * L.stride + (size_t)x0 * 3;
+        for (int x = x0; x < x1; ++x, p += 3) { sb += p[0]; sg += p[1]; sr += p[2]; }
+    }
+    const float area = (float)((y1 - y0) * (x1 - x0));
+    float* d = dst + L.out_off + r * 3;                      // RGB order
+    d[0] = ((float)sr / area - 127.5f) * 0.0078125f;
+    d[1] = ((float)sg / area - 127.5f) * 0.0078125f;
+    d[2] = ((float)sb / area - 127.5f) * 0.0078125f;
 }
 
 void launch_mt_area_resize_ragged(const MtLevel* lv_dev, const long long* pre_dev, int n, long long total, float* dst,
                                   hipStream_t s) {
     if (total <= 0) return;
-    hipLaunchKernelGGL(mt_area_resize_ragged_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, lv_dev, pre_dev, n, dst);
+    hipLaunchKernelGGL(mt_area_resize_ragged_kernel, dim3((unsigned)((total / 3 + 255) / 256)), dim3(256), 0, s, lv_dev, pre_dev, n, dst);
 }
 
 __global__ __launch_bounds__(256) void mt_conv_ragged_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -268,7 +330,9 @@ __global__ __launch_bounds__(256) void mt_convpx_kernel(const float* __restrict_
                                                         const long long* __restrict__ pre, int n, int ih_u, int iw_u,
                                                         const float* __restrict__ w41, const float* __restrict__ b41,
                                                         const float* __restrict__ w42, const float* __restrict__ b42,
-                                                        float* __restrict__ prob, float* __restrict__ reg) {
+                                                        float* __restrict__ prob, float* __restrict__ reg,
+                                                        MtCand* __restrict__ cand, unsigned* __restrict__ cand_count,
+                                                        unsigned cand_cap, float thr) {
     constexpr int CC = CI % 2 == 0 ? 2 : 1;                  // channels per activation load
     constexpr int NW = CI * K * K * CO;
     __shared__ __attribute__((aligned(16))) float sw[NW + (HEADS ? CO * 6 + 8 : 0)];
@@ -371,11 +435,16 @@ __global__ __launch_bounds__(256) void mt_convpx_kernel(const float* __restrict_
             const float z0 = z[0] + sw[NW + CO * 6], z1 = z[1] + sw[NW + CO * 6 + 1];
             const float m = fmaxf(z0, z1);
             const float e0 = expf(z0 - m), e1 = expf(z1 - m);
-            prob[opix[p]] = e1 / (e0 + e1);
+            const float pf = e1 / (e0 + e1);
+            prob[opix[p]] = pf;
             float4 rv;
             rv.x = r4[0] + sw[NW + CO * 6 + 2]; rv.y = r4[1] + sw[NW + CO * 6 + 3];
             rv.z = r4[2] + sw[NW + CO * 6 + 4]; rv.w = r4[3] + sw[NW + CO * 6 + 5];
             *reinterpret_cast<float4*>(reg + opix[p] * 4) = rv;
+            if (cand && pf >= thr) {
+                const unsigned slot = atomicAdd(cand_count, 1u);
+                if (slot < cand_cap) cand[slot] = MtCand{(unsigned)opix[p], pf, {rv.x, rv.y, rv.z, rv.w}};
+            }
         } else {
             float* yp = y + opix[p] * CO;
             if (CO % 4 == 0) {
@@ -542,7 +611,8 @@ static void convpx_launch(const float* x, const float* w, const float* b, const 
     const long long threads = (npix + P - 1) / P;
     hipLaunchKernelGGL((mt_convpx_kernel<CI, CO, K, P, HEADS>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, w, b,
                        slope, y, items, pre, n, ih, iw, hd ? hd->w41 : nullptr, hd ? hd->b41 : nullptr, hd ? hd->w42 : nullptr,
-                       hd ? hd->b42 : nullptr, hd ? hd->prob : nullptr, hd ? hd->reg : nullptr);
+                       hd ? hd->b42 : nullptr, hd ? hd->prob : nullptr, hd ? hd->reg : nullptr, hd ? hd->cand : nullptr,
+                       hd ? hd->cand_count : nullptr, hd ? hd->cand_cap : 0u, hd ? hd->thr : 0.f);
 }
 
 bool launch_mt_convpx_ragged(const float* x, const float* w, const float* b, const float* slope, float* y,
@@ -594,24 +664,26 @@ void launch_mt_maxpool_ragged(const float* x, float* y, const MtItem* items_dev,
 // windows that live in different images (the crops of a step): per-window source pointer and stride
 __global__ __launch_bounds__(256) void mt_area_resize_multi_kernel(const MtSrcWindow* __restrict__ win, int n, int oh, int ow,
                                                                    float* __restrict__ dst) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)n * oh * ow * 3;
-    if (t >= total) return;
-    const int c = (int)(t % 3);
-    const int ox = (int)((t / 3) % ow), oy = (int)((t / 3 / ow) % oh), i = (int)(t / 3 / ow / oh);
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;          // one output pixel (three exact integer sums)
+    if (t >= (long long)n * oh * ow) return;
+    const int ox = (int)(t % ow), oy = (int)((t / ow) % oh), i = (int)(t / ow / oh);
     const MtSrcWindow w = win[i];
     const int y0 = (int)(((long long)oy * w.h) / oh), y1 = (int)((((long long)oy + 1) * w.h + oh - 1) / oh);
     const int x0 = (int)(((long long)ox * w.w) / ow), x1 = (int)((((long long)ox + 1) * w.w + ow - 1) / ow);
-    const uint8_t* p = w.src + (size_t)w.y * w.stride + (size_t)w.x * 3 + (2 - c);
-    float sum = 0.f;
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) sum += (float)p[(size_t)y * w.stride + (size_t)x * 3];
-    const float mean = sum / (float)((y1 - y0) * (x1 - x0));
-    dst[t] = (mean - 127.5f) * 0.0078125f;
+    int sb = 0, sg = 0, sr = 0;
+    for (int y = y0; y < y1; ++y) {
+        const uint8_t* p = w.src + (size_t)(w.y + y) * w.stride + (size_t)(w.x + x0) * 3;
+        for (int x = x0; x < x1; ++x, p += 3) { sb += p[0]; sg += p[1]; sr += p[2]; }
+    }
+    const float area = (float)((y1 - y0) * (x1 - x0));
+    float* d = dst + t * 3;
+    d[0] = ((float)sr / area - 127.5f) * 0.0078125f;
+    d[1] = ((float)sg / area - 127.5f) * 0.0078125f;
+    d[2] = ((float)sb / area - 127.5f) * 0.0078125f;
 }
 
 void launch_mt_area_resize_multi(const MtSrcWindow* win_dev, int n, int oh, int ow, float* dst, hipStream_t s) {
-    const long long total = (long long)n * oh * ow * 3;
+    const long long total = (long long)n * oh * ow;
     if (total <= 0) return;
     hipLaunchKernelGGL(mt_area_resize_multi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, win_dev, n, oh, ow, dst);
 }
