@@ -225,8 +225,8 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, w
 
 def e2e_mtcnn(frames, boxes, K):
     """The same path with the reference's MTCNN align/crop between CLAHE and the 224x224 resize (row A5), on a
-    handle whose blob carries the (seeded) cascade.  One cascade per crop with host-side box bookkeeping between
-    its three stages: a latency figure, not yet a batched throughput path."""
+    handle whose blob carries the (seeded) cascade: all crops of a call go through the three stages together, box
+    bookkeeping between the stages on the library's host side."""
     import rtdfd_amd as pkg
 
     W = pkg.weights
@@ -257,9 +257,9 @@ def e2e_mtcnn(frames, boxes, K):
         out[key] = {"frames_per_s": round(n / dt, 1), "ms_per_crop": round(dt / (n * K) * 1e3, 3),
                     "crops_with_a_face": int((~np.isnan(flat)).sum()), "crops": int(flat.size), "frames_per_call": n}
     n = 8
-    out["workload"] = (f"{n} x 1080p frames, {K} forced boxes each; seeded random-init cascade: 'mtcnn_on' = stress cascade "
-                       "(~20 % of the P-Net cells and ~99 % of the R-Net candidates pass: hundreds of windows per crop reach "
-                       "O-Net), 'mtcnn_on_selective' = the funnel of a trained cascade (weights.MTCNN_SELECTIVE)")
+    out["workload"] = (f"1080p frames, {K} forced boxes each, frames_per_call as listed; seeded random-init cascade: 'mtcnn_on' = "
+                       "stress cascade (~20 % of the P-Net cells and ~99 % of the R-Net candidates pass: hundreds of windows per "
+                       "crop reach O-Net), 'mtcnn_on_selective*' = the funnel of a trained cascade (weights.MTCNN_SELECTIVE)")
     for h, fd in handles.values():
         fd.free()
         h.close()

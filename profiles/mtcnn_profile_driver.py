@@ -14,9 +14,13 @@ fd = h.alloc(frames.nbytes).upload(frames)
 h.analyze_batch_device(fd.ptr, NF, 1080, 1920, forced_boxes=boxes, max_faces=4)
 h.sync()
 t0 = time.perf_counter()
-for _ in range(5):
+its = []
+for _ in range(int(os.environ.get("MT_ITERS", "5"))):
+    t1 = time.perf_counter()
     res = h.analyze_batch_device(fd.ptr, NF, 1080, 1920, forced_boxes=boxes, max_faces=4)
+    its.append(round((time.perf_counter() - t1) * 1e3, 2))
 h.sync()
-dt = (time.perf_counter() - t0) / 5
+dt = (time.perf_counter() - t0) / len(its)
+print("per call ms", its)
 flat = np.concatenate([np.asarray(l).reshape(-1) for l in res[1]])
 print(f"wall per call {dt*1e3:.2f} ms for {4*NF} crops ({dt/(4*NF)*1e3:.3f} ms/crop); crops with a face {int((~np.isnan(flat)).sum())}/{4*NF}")
