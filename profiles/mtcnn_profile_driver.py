@@ -11,6 +11,8 @@ NF = int(os.environ.get("MT_FRAMES", "8"))
 frames = np.random.default_rng(7).integers(50, 200, (NF, 1080, 1920, 3), dtype=np.uint8)
 boxes = [[(200, 150, 320, 400), (900, 300, 256, 256), (1400, 500, 400, 480), (600, 700, 224, 224)]] * NF
 fd = h.alloc(frames.nbytes).upload(frames)
+if os.environ.get('MT_OFF') == '1':
+    h.set_option('mtcnn', 0)
 h.analyze_batch_device(fd.ptr, NF, 1080, 1920, forced_boxes=boxes, max_faces=4)
 h.sync()
 t0 = time.perf_counter()

@@ -103,6 +103,7 @@ void destroy_impl(dfd_handle* h) {
         if (h->slot_free[i]) hipEventDestroy(h->slot_free[i]);
     }
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
+    if (h->mailbox) hipHostFree(h->mailbox);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);

@@ -86,6 +86,9 @@ struct dfd_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // dfd_analyze_frames_host: copy stream + two staging slots (uploads overlap the previous batch's compute)
+    // pinned mailbox for the small host<->device transfers of the batch path (mailbox_* below)
+    char* mailbox = nullptr;
+    size_t mailbox_cap = 0, mailbox_head = 0;
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr};
     dfd::DevBuf stage[2];
@@ -140,6 +143,14 @@ int fail(dfd_handle* h, int code, const char* fmt, ...);
 
 // grows `b` to at least `bytes` (frees and re-allocates; contents are not preserved)
 int ensure(dfd_handle* h, DevBuf* b, size_t bytes);
+// Small transfers on the compute stream without the DMA engines: descriptors, detection rows and logits are a few KB,
+// but as hipMemcpyAsync they queue on the same SDMA engine as the 200-400 MB frame upload of the next batch and the
+// batch in flight stalls until that upload has finished (measured: 32-frame batches ran at upload + compute, not at
+// max(upload, compute)).  A copy kernel moves them through a pinned, device-visible mailbox instead.
+//   mailbox_h2d: `src` is copied into the mailbox before the call returns (reusable at once); the device copy is enqueued.
+//   mailbox_d2h: enqueues the copy and returns the host address that holds the data once the stream is synchronised.
+int mailbox_h2d(dfd_handle* h, void* dst_dev, const void* src, size_t bytes);
+const void* mailbox_d2h(dfd_handle* h, const void* src_dev, size_t bytes);
 // builds h->color from the "lut.*" tensors of the blob (imgproc_api.hip)
 int color_tables_init(dfd_handle* h);
 

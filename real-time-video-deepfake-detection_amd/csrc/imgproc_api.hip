@@ -1,12 +1,61 @@
 // C ABI entry points of the per-face pre-processing path (include/dfd_hip.h).
 #include "b0_kernels.h"
+#include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include "dfd_common.h"
 
 using namespace dfd;
 
 namespace dfd {
+
+__global__ __launch_bounds__(256) void mailbox_copy_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+static char* mailbox_alloc(dfd_handle* h, size_t bytes) {
+    constexpr size_t kCap = 8u << 20;
+    if (!h->mailbox) {
+        if (hipHostMalloc((void**)&h->mailbox, kCap, hipHostMallocDefault) != hipSuccess) return nullptr;
+        h->mailbox_cap = kCap;
+    }
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes > h->mailbox_cap) return nullptr;
+    // bump allocation; every entry point synchronises the stream before it returns, so a wrap-around only meets regions
+    // of earlier calls (a single call moves far less than the capacity through the mailbox)
+    if (h->mailbox_head + bytes > h->mailbox_cap) h->mailbox_head = 0;
+    char* p = h->mailbox + h->mailbox_head;
+    h->mailbox_head += bytes;
+    return p;
+}
+
+static void mailbox_launch(dfd_handle* h, void* dst, const void* src, size_t bytes) {
+    const size_t words = (bytes + 3) / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 256);
+    hipLaunchKernelGGL(mailbox_copy_kernel, dim3(blocks), dim3(256), 0, h->stream, (unsigned*)dst, (const unsigned*)src, words);
+}
+
+int mailbox_h2d(dfd_handle* h, void* dst_dev, const void* src, size_t bytes) {
+    if (!bytes) return DFD_OK;
+    char* p = mailbox_alloc(h, bytes);
+    if (!p) {                                               // larger than the mailbox: the DMA path
+        DFD_HIP_TRY(h, hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, h->stream));
+        DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return DFD_OK;
+    }
+    memcpy(p, src, bytes);
+    mailbox_launch(h, dst_dev, p, bytes);
+    DFD_HIP_TRY(h, hipGetLastError());
+    return DFD_OK;
+}
+
+const void* mailbox_d2h(dfd_handle* h, const void* src_dev, size_t bytes) {
+    char* p = mailbox_alloc(h, bytes ? bytes : 4);
+    if (!p) return nullptr;
+    if (bytes) mailbox_launch(h, p, src_dev, bytes);
+    return p;
+}
 
 int ensure(dfd_handle* h, DevBuf* b, size_t bytes) {
     if (bytes <= b->cap) return DFD_OK;
@@ -95,8 +144,7 @@ int stage_crops(dfd_handle* h, int hh, int ww, const int32_t* xywh, int n, size_
     }
     int rc;
     if ((rc = ensure(h, &h->desc_buf, n * sizeof(CropDesc)))) return rc;
-    DFD_HIP_TRY(h, hipMemcpyAsync(h->desc_buf.p, d.data(), n * sizeof(CropDesc), hipMemcpyHostToDevice, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));   // `d` is a stack temporary
+    if ((rc = mailbox_h2d(h, h->desc_buf.p, d.data(), n * sizeof(CropDesc)))) return rc;      // `d` is copied before the call returns
     *total = off;
     *max_pixels = mp;
     return DFD_OK;
@@ -138,8 +186,7 @@ int preprocess_on_device(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww
         if ((rc = mtcnn_align_batch_device(h, imgs.data(), n, (uint8_t*)h->face_batch.p, nullptr, h->crop_valid.data(), nullptr,
                                            nullptr, nullptr)))
             return rc;
-        DFD_HIP_TRY(h, hipMemcpyAsync(h->desc_buf.p, fd.data(), n * sizeof(CropDesc), hipMemcpyHostToDevice, h->stream));
-        DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if ((rc = mailbox_h2d(h, h->desc_buf.p, fd.data(), n * sizeof(CropDesc)))) return rc;
         launch_crop_norm((const uint8_t*)h->face_batch.p, 160 * 3, nullptr, dd, n, h->in_nchw, false, h->stream);
         DFD_HIP_TRY(h, hipGetLastError());
         return DFD_OK;

@@ -55,10 +55,11 @@ int dfd_analyze_batch_device(dfd_handle* h, const uint8_t* frames_dev, int n, in
         if ((rc = preprocess_run(h, frames_dev, hh, ww, stride, boxes.data() + (size_t)start * 4, m, apply_clahe, offs.data() + start)))
             return rc;
         if ((rc = b0_forward(h, h->in_nchw, m, h->logits, nullptr, nullptr))) return rc;
-        DFD_HIP_TRY(h, hipMemcpyAsync(logits.data() + start, h->logits, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
+        const float* lg = (const float*)mailbox_d2h(h, h->logits, (size_t)m * 4);
+        if (!lg) return fail(h, DFD_ERR_HIP, "analyze_batch: mailbox allocation failed");
+        DFD_HIP_TRY(h, hipGetLastError());
         DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
-        for (int i = 0; i < m; ++i)
-            if (!h->crop_valid[i]) logits[start + i] = NAN;      // MTCNN found no face in this crop
+        for (int i = 0; i < m; ++i) logits[start + i] = h->crop_valid[i] ? lg[i] : NAN;      // NaN: MTCNN found no face in this crop
     }
     int k = 0;
     for (int f = 0; f < n; ++f)

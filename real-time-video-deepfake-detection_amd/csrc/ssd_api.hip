@@ -433,13 +433,14 @@ int detect_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, in
     if ((rc = ensure(h, &h->ssd->in_u8, (size_t)n * SSD_IN * SSD_IN * 3))) return rc;
     launch_resize_bgr(frames_dev, n, hh, ww, stride, frame_bytes, (uint8_t*)h->ssd->in_u8.p, SSD_IN, SSD_IN, h->stream);
     if ((rc = ssd_forward(h, (const uint8_t*)h->ssd->in_u8.p, n, nullptr, nullptr, 0, nullptr))) return rc;
-    std::vector<float> rows((size_t)n * SSD_KEEP * 5);
-    std::vector<int> cnt(n);
-    DFD_HIP_TRY(h, hipMemcpyAsync(cnt.data(), h->ssd->count.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipMemcpyAsync(rows.data(), h->ssd->rows.p, rows.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    // DetectionOutput rows and counts through the mailbox (dfd_common.h): not behind the next batch's frame upload
+    const int* cnt = (const int*)mailbox_d2h(h, h->ssd->count.p, (size_t)n * 4);
+    const float* rows = (const float*)mailbox_d2h(h, h->ssd->rows.p, (size_t)n * SSD_KEEP * 5 * 4);
+    if (!cnt || !rows) return fail(h, DFD_ERR_HIP, "detect_batch: mailbox allocation failed");
+    DFD_HIP_TRY(h, hipGetLastError());
     DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (int f = 0; f < n; ++f)
-        n_out[f] = ssd_postprocess(rows.data() + (size_t)f * SSD_KEEP * 5, cnt[f], hh, ww, conf_thr,
+        n_out[f] = ssd_postprocess(rows + (size_t)f * SSD_KEEP * 5, cnt[f], hh, ww, conf_thr,
                                    xywh_out + (size_t)f * max_faces * 4, nullptr, max_faces);
     return DFD_OK;
 }
