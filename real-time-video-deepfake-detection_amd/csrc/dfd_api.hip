@@ -104,6 +104,7 @@ void destroy_impl(dfd_handle* h) {
     }
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
     if (h->mailbox) hipHostFree(h->mailbox);
+    for (char* p : h->mailbox_old) hipHostFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);

@@ -89,6 +89,7 @@ struct dfd_handle {
     // pinned mailbox for the small host<->device transfers of the batch path (mailbox_* below)
     char* mailbox = nullptr;
     size_t mailbox_cap = 0, mailbox_head = 0;
+    std::vector<char*> mailbox_old;
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr};
     dfd::DevBuf stage[2];

@@ -211,10 +211,11 @@ int forensics_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh,
     ForensicState& F = *h->forensic;
     launch_resize_bgr(frames_dev, n, hh, ww, stride, frame_bytes, F.buf.rs, 256, 256, h->stream);
     launch_forensics(F.buf, n, true, h->color, F.twiddle, h->stream);
-    std::vector<double> st((size_t)n * FORENSIC_STATS), noise((size_t)n * 64), ela((size_t)n * 64);
-    DFD_HIP_TRY(h, hipMemcpyAsync(st.data(), F.buf.stats, st.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipMemcpyAsync(noise.data(), F.buf.stats_noise, noise.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipMemcpyAsync(ela.data(), F.buf.stats_ela, ela.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    // a few KB per frame, through the mailbox (dfd_common.h) rather than the DMA engines
+    const double* st = (const double*)mailbox_d2h(h, F.buf.stats, (size_t)n * FORENSIC_STATS * 8);
+    const double* noise = (const double*)mailbox_d2h(h, F.buf.stats_noise, (size_t)n * 64 * 8);
+    const double* ela = (const double*)mailbox_d2h(h, F.buf.stats_ela, (size_t)n * 64 * 8);
+    if (!st || !noise || !ela) return fail(h, DFD_ERR_HIP, "forensics: mailbox allocation failed");
     DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
     DFD_HIP_TRY(h, hipGetLastError());
     const double w[6] = {0.25, 0.20, 0.20, 0.15, 0.10, 0.10};
@@ -261,15 +262,15 @@ int dfd_forensic_signals_device(dfd_handle* h, const uint8_t* frames_dev, int n,
     if ((rc = ensure(h, &F.pair_idx, (size_t)n * 4))) return rc;
     if ((rc = ensure(h, &F.pair_part, (size_t)n * 256 * 8))) return rc;
     const int stride = ww * 3;
-    DFD_HIP_TRY(h, hipMemcpyAsync(F.pair_idx.p, prev_index, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    if ((rc = mailbox_h2d(h, F.pair_idx.p, prev_index, (size_t)n * 4))) return rc;
     launch_resize_bgr(frames_dev, n, hh, ww, stride, (size_t)hh * stride, F.buf.rs, 256, 256, h->stream);
     launch_forensics(F.buf, n, true, h->color, F.twiddle, h->stream);
     launch_absdiff_pairs(F.buf.gray, (const int*)F.pair_idx.p, (double*)F.pair_part.p, n, h->stream);
-    std::vector<double> st((size_t)n * FORENSIC_STATS), noise((size_t)n * 64), ela((size_t)n * 64), part((size_t)n * 256);
-    DFD_HIP_TRY(h, hipMemcpyAsync(st.data(), F.buf.stats, st.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipMemcpyAsync(noise.data(), F.buf.stats_noise, noise.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipMemcpyAsync(ela.data(), F.buf.stats_ela, ela.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipMemcpyAsync(part.data(), F.pair_part.p, part.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    const double* st = (const double*)mailbox_d2h(h, F.buf.stats, (size_t)n * FORENSIC_STATS * 8);
+    const double* noise = (const double*)mailbox_d2h(h, F.buf.stats_noise, (size_t)n * 64 * 8);
+    const double* ela = (const double*)mailbox_d2h(h, F.buf.stats_ela, (size_t)n * 64 * 8);
+    const double* part = (const double*)mailbox_d2h(h, F.pair_part.p, (size_t)n * 256 * 8);
+    if (!st || !noise || !ela || !part) return fail(h, DFD_ERR_HIP, "forensics: mailbox allocation failed");
     DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
     DFD_HIP_TRY(h, hipGetLastError());
     for (int f = 0; f < n; ++f) {

@@ -16,14 +16,19 @@ __global__ __launch_bounds__(256) void mailbox_copy_kernel(unsigned* __restrict_
 
 static char* mailbox_alloc(dfd_handle* h, size_t bytes) {
     constexpr size_t kCap = 8u << 20;
-    if (!h->mailbox) {
-        if (hipHostMalloc((void**)&h->mailbox, kCap, hipHostMallocDefault) != hipSuccess) return nullptr;
-        h->mailbox_cap = kCap;
-    }
     bytes = (bytes + 255) & ~(size_t)255;
-    if (bytes > h->mailbox_cap) return nullptr;
     // bump allocation; every entry point synchronises the stream before it returns, so a wrap-around only meets regions
-    // of earlier calls (a single call moves far less than the capacity through the mailbox)
+    // of earlier calls.  A call that needs more than the current block gets a new, larger one (the old blocks stay
+    // alive until the handle is destroyed: pointers handed out earlier in the same call remain valid).
+    if (!h->mailbox || bytes > h->mailbox_cap / 8) {       // a call makes at most a handful of requests
+        const size_t cap = std::max(kCap, bytes * 16);
+        char* p = nullptr;
+        if (hipHostMalloc((void**)&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (h->mailbox) h->mailbox_old.push_back(h->mailbox);
+        h->mailbox = p;
+        h->mailbox_cap = cap;
+        h->mailbox_head = 0;
+    }
     if (h->mailbox_head + bytes > h->mailbox_cap) h->mailbox_head = 0;
     char* p = h->mailbox + h->mailbox_head;
     h->mailbox_head += bytes;
