@@ -32,12 +32,9 @@ struct MtcnnState {
     MtConv r1p;                           // R-Net conv1 with 32 output channels (4 zero filters)
     MtGemmConv r2g, r3g, o2g, o3g, o4g;
     DevBuf in, a0, a1, z, prob, reg, win, coef, bnd, tmp, face, d_lv, d_items, d_pre, bs, cand;
-    void* pin = nullptr;                  // pinned host staging for the candidate download
-    size_t pin_cap = 0;
 };
 
 void mtcnn_destroy(dfd_handle* h) {
-    if (h->mtcnn && h->mtcnn->pin) (void)hipHostFree(h->mtcnn->pin);
     delete h->mtcnn;
     h->mtcnn = nullptr;
 }
@@ -301,18 +298,21 @@ struct Cascade {
         t_mark = now;
     }
 
+    // descriptor tables and result rows are small: through the handle's mailbox (dfd_common.h), not the DMA queues
     template <typename T>
     int upload(DevBuf* buf, const std::vector<T>& v) {
         int rc = ensure(h, buf, std::max<size_t>(v.size() * sizeof(T), 16));
         if (rc) return rc;
-        if (!v.empty()) DFD_HIP_TRY(h, hipMemcpyAsync(buf->p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
-        return DFD_OK;
+        return v.empty() ? DFD_OK : mailbox_h2d(h, buf->p, v.data(), v.size() * sizeof(T));
     }
     int download(const void* dev, size_t floats, std::vector<float>* out) {
         out->resize(floats);
         if (!floats) return DFD_OK;
-        DFD_HIP_TRY(h, hipMemcpyAsync(out->data(), dev, floats * 4, hipMemcpyDeviceToHost, h->stream));
+        const float* p = (const float*)mailbox_d2h(h, dev, floats * 4);
+        if (!p) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
+        DFD_HIP_TRY(h, hipGetLastError());
         DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::copy(p, p + floats, out->begin());
         return DFD_OK;
     }
     void tap_boxes(const std::string& name, const std::vector<Box>& b) {
@@ -405,26 +405,18 @@ struct Cascade {
             ok = ok && launch_mt_convpx_ragged(a0, S->p3.w, S->p3.b, S->p3.a, nullptr, item_at(3), pre_at(4), nl, pre_c3.back(), 16, 32, 3, &heads, s);
             if (!ok) return fail(h, DFD_ERR_STATE, "mtcnn: no P-Net kernel instance for this layer shape");
             DFD_HIP_TRY(h, hipGetLastError());
-            // the candidates (cells at or above the threshold), not the maps: count first, then that many records,
-            // both through pinned memory; the atomic append order is restored to (level, y, x) by sorting on the cell
-            if (!S->pin) {
-                DFD_HIP_TRY(h, hipHostMalloc(&S->pin, 1 << 20, hipHostMallocDefault));
-                S->pin_cap = 1 << 20;
-            }
-            DFD_HIP_TRY(h, hipMemcpyAsync(S->pin, d_count, 4, hipMemcpyDeviceToHost, s));
+            // the candidates (cells at or above the threshold), not the maps: count first, then that many records, both
+            // through the mailbox; the atomic append order is restored to (level, y, x) by sorting on the cell
+            const unsigned* pc = (const unsigned*)mailbox_d2h(h, d_count, 4);
+            if (!pc) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
             DFD_HIP_TRY(h, hipStreamSynchronize(s));
-            const size_t nc = std::min<size_t>(*(const unsigned*)S->pin, (size_t)cells);
-            if (nc * sizeof(MtCand) > S->pin_cap) {
-                (void)hipHostFree(S->pin);
-                S->pin = nullptr;
-                S->pin_cap = (nc * sizeof(MtCand) + (1 << 20)) & ~(size_t)((1 << 20) - 1);
-                DFD_HIP_TRY(h, hipHostMalloc(&S->pin, S->pin_cap, hipHostMallocDefault));
-            }
+            const size_t nc = std::min<size_t>(*pc, (size_t)cells);
             if (nc) {
-                DFD_HIP_TRY(h, hipMemcpyAsync(S->pin, d_cand, nc * sizeof(MtCand), hipMemcpyDeviceToHost, s));
+                const MtCand* pr = (const MtCand*)mailbox_d2h(h, d_cand, nc * sizeof(MtCand));
+                if (!pr) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
                 DFD_HIP_TRY(h, hipStreamSynchronize(s));
+                cands.assign(pr, pr + nc);
             }
-            cands.assign((const MtCand*)S->pin, (const MtCand*)S->pin + nc);
             std::sort(cands.begin(), cands.end(), [](const MtCand& a, const MtCand& b) { return a.cell < b.cell; });
             if (tap_name) {                                   // parity taps read whole maps
                 prob.resize(cells);
@@ -546,12 +538,13 @@ struct Cascade {
                 // dense6_3 (landmarks) does not influence the selected crop: not evaluated
             }
             DFD_HIP_TRY(h, hipGetLastError());
-            std::vector<float> p, r;
-            p.resize(m);
-            DFD_HIP_TRY(h, hipMemcpyAsync(p.data(), S->prob.p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-            if ((rc = download(S->reg.p, (size_t)m * 4, &r))) return rc;
-            prob->insert(prob->end(), p.begin(), p.end());
-            reg->insert(reg->end(), r.begin(), r.end());
+            const float* pp = (const float*)mailbox_d2h(h, S->prob.p, (size_t)m * 4);
+            const float* rr = (const float*)mailbox_d2h(h, S->reg.p, (size_t)m * 16);
+            if (!pp || !rr) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
+            DFD_HIP_TRY(h, hipGetLastError());
+            DFD_HIP_TRY(h, hipStreamSynchronize(s));
+            prob->insert(prob->end(), pp, pp + m);
+            reg->insert(reg->end(), rr, rr + (size_t)m * 4);
         }
         return DFD_OK;
     }
