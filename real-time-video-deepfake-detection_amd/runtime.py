@@ -21,6 +21,7 @@ Device: ``$DFD_DEVICE`` or ``$LOCAL_RANK`` or 0.
 """
 from __future__ import annotations
 
+import gc
 import logging
 import os
 import threading
@@ -121,6 +122,11 @@ def default_handle() -> Handle:
                 log.info("loaded Haar cascade %s (fallback detector)", cascade)
             _default = Handle(W.pack_all(default_state_dict(), ssd, mt, ssd_arch=ssd_arch, haar=hc), device=device_index(),
                               max_batch=int(os.environ.get("DFD_MAX_BATCH", "16")))
+            # the start-up objects (state dicts, the blob, module globals) move to the permanent generation: a full
+            # collection in the middle of a request stream otherwise walks them all - measured as a one-off 40 ms stall
+            # of a 6.5 ms `analyze_batch` call (profiles/mtcnn_profile_driver.py, gone with the collector off)
+            gc.collect()
+            gc.freeze()
         return _default
 
 
