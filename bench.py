@@ -313,7 +313,7 @@ def stream_frame(base, t):
     return f
 
 
-def config5_streams(h, rank, world, dist, local_rank, waves=12, n_streams=8, verify_frames=12):
+def config5_streams(h, rank, world, dist, local_rank, waves=32, n_streams=8, verify_frames=12, lookahead=8):
     """BASELINE.json configs[4] / SURVEY 8(d) Config 5: 8 seeded 1080p streams (seeds 100-107), frame t of every
     stream on rank t % G (weak scaling: 8 frames per GPU per wave), per wave ONE all-gather of 80-byte records
     (dfd_vote_allgather = ncclAllGather over RCCL through the C ABI; torch.distributed as a fallback) inside the
@@ -340,14 +340,23 @@ def config5_streams(h, rank, world, dist, local_rank, waves=12, n_streams=8, ver
         prev = [stream_frame(bases[s], t - 1) for s in range(n_streams)] if t > 0 else []
         return np.stack(cur + prev), [(s, t, t > 0) for s in range(n_streams)]
 
-    # resident in HBM before the timed region: this rank's frames (and their predecessors) for every wave
+    # resident in HBM before the timed region: this rank's frames (and their predecessors), `lookahead` waves per device
+    # batch (current frames of the group wave by wave, then their predecessors)
     staged = []
-    for w in range(waves):
-        arr, items = batch(sh.frame_of(w))
+    for g0 in range(0, waves, lookahead):
+        cur, prev, items = [], [], []
+        for w in range(g0, min(g0 + lookahead, waves)):
+            t = sh.frame_of(w)
+            cur += [stream_frame(bases[s], t) for s in range(n_streams)]
+            if t > 0:
+                prev += [stream_frame(bases[s], t - 1) for s in range(n_streams)]
+            items.append([(s, t, t > 0) for s in range(n_streams)])
+        arr = np.stack(cur + prev)
         staged.append((h.alloc(arr.nbytes).upload(arr), items))
     # untimed warm-up on a throw-away driver (workspace growth, first-use costs), incl. one collective
     warm = S.ShardedStreams(h, n_streams, rank, world, transport=transport)
-    warm.finish_wave(warm.local_records(staged[0][0].ptr, Hh, Ww, staged[0][1]))
+    for block in warm.local_records_waves(staged[0][0].ptr, Hh, Ww, staged[0][1]):
+        warm.finish_wave(block)
     h.sync()
     if dist is not None:
         dist.barrier()
@@ -355,9 +364,10 @@ def config5_streams(h, rank, world, dist, local_rank, waves=12, n_streams=8, ver
     seq = {s: [] for s in range(n_streams)}
     t0 = time.perf_counter()
     for fd, items in staged:
-        out = sh.finish_wave(sh.local_records(fd.ptr, Hh, Ww, items))       # collective inside the timed loop
-        for s, rows in out.items():
-            seq[s] += [(r['frame'], r['confidence_level'], r['fake_probability']) for r in rows]
+        for block in sh.local_records_waves(fd.ptr, Hh, Ww, items):            # one device pass for `lookahead` waves
+            out = sh.finish_wave(block)                                          # one collective per wave, in wave order
+            for s, rows in out.items():
+                seq[s] += [(r['frame'], r['confidence_level'], r['fake_probability']) for r in rows]
     h.sync()
     if dist is not None:
         dist.barrier()
@@ -372,9 +382,10 @@ def config5_streams(h, rank, world, dist, local_rank, waves=12, n_streams=8, ver
     frames = waves * world * n_streams
     res = {"workload": f"{n_streams} seeded 1080p streams (seeds 100-107), frame t on rank t % {world}; per wave: SSD detect + "
                        "faces[0] -> CLAHE -> 224 -> B0, six forensic signals (temporal from recomputed gray(t-1)), one "
-                       "all-gather of 80-byte records, replay of temporal score + votes on every rank",
+                       "all-gather of 80-byte records, replay of temporal score + votes on every rank; the frames of "
+                       f"{lookahead} consecutive waves share one device batch (look-ahead), the exchange stays per wave",
            "frames_per_s": round(frames / dt, 1), "ms_per_wave": round(dt / waves * 1e3, 3), "waves": waves,
-           "frames_per_wave_per_gpu": n_streams, "transport": transport,
+           "frames_per_wave_per_gpu": n_streams, "lookahead_waves": lookahead, "transport": transport,
            "collective": "dfd_vote_allgather (ncclAllGather, RCCL)" if transport == "rccl" else transport,
            "record_bytes": S.RECORD_FLOATS * 8, "bytes_gathered_per_wave": S.RECORD_FLOATS * 8 * n_streams * world}
     if note:

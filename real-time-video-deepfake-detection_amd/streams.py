@@ -156,27 +156,40 @@ class ShardedStreams:
         """items: [(stream, frame index, has_prev)] for the batch resident at frames_dev, laid out as all current
         frames first, then the predecessors of those that have one, in the same order.  One detector + classifier
         pass over the current frames (faces[0] per frame, as the server does) and one forensic pass."""
-        m = len(items)
-        prevs = [i for i, it in enumerate(items) if it[2]]
+        return self.local_records_waves(frames_dev, height, width, [items], conf_thr)[0]
+
+    def local_records_waves(self, frames_dev: int, height: int, width: int, waves_items, conf_thr: float = 0.5) -> List[np.ndarray]:
+        """Several waves of this rank in ONE device pass (look-ahead batching: what a frame contributes to its record is a
+        pure function of the frame and its predecessor, only the replay is sequential, so the frames of the next L waves can
+        share a detector / classifier / forensic batch; the exchange stays one all-gather per wave, in wave order).
+        waves_items: L lists of (stream, frame index, has_prev); device layout: the current frames of all waves, wave by
+        wave, then the predecessors of those that have one in the same order.  Returns the L record blocks."""
+        flat = [it for items in waves_items for it in items]
+        m = len(flat)
+        if any(len(items) > self.n_streams for items in waves_items):
+            raise ValueError("more frames in a wave than record slots")
+        prevs = [i for i, it in enumerate(flat) if it[2]]
         prev_index = np.full(m + len(prevs), -1, np.int32)
         for k, i in enumerate(prevs):
             prev_index[i] = m + k
         boxes, logits, _ = self.h.analyze_batch_device(frames_dev, m, height, width, forced_boxes=None,
                                                        confidence_threshold=conf_thr, max_faces=1, with_forensics=False)
         scores, mdiff = self.h.forensic_signals_device(frames_dev, m + len(prevs), height, width, prev_index)
-        block = np.full((self.n_streams, RECORD_FLOATS), -1.0, np.float64)
-        if m > self.n_streams:
-            raise ValueError("more frames in a wave than record slots")
         small = height < 30 or width < 30
-        for i, (stream, frame, _) in enumerate(items):
-            p = np.nan
-            if boxes[i] and not small:
-                x, y, w, h = boxes[i][0]
-                lg = logits[i][0]
-                if not np.isnan(lg):
-                    p = float(np.clip(_sigmoid32(lg) + (0.10 if (h < 80 or w < 80) else 0.0), 0, 1))   # :445-455,489-502
-            block[i] = (stream, frame, p, mdiff[i], *scores[i], len(boxes[i]))
-        return block
+        blocks, i = [], 0
+        for items in waves_items:
+            block = np.full((self.n_streams, RECORD_FLOATS), -1.0, np.float64)
+            for j, (stream, frame, _) in enumerate(items):
+                p = np.nan
+                if boxes[i] and not small:
+                    x, y, w, h = boxes[i][0]
+                    lg = logits[i][0]
+                    if not np.isnan(lg):
+                        p = float(np.clip(_sigmoid32(lg) + (0.10 if (h < 80 or w < 80) else 0.0), 0, 1))   # :445-455,489-502
+                block[j] = (stream, frame, p, mdiff[i], *scores[i], len(boxes[i]))
+                i += 1
+            blocks.append(block)
+        return blocks
 
     def finish_wave(self, block: np.ndarray) -> Dict[int, List[dict]]:
         """collective: exchange + replay; identical return value on every rank"""

@@ -104,3 +104,36 @@ def test_rccl_transport_world1(pkg, b0_handle):
     assert h.comm_info()[1] == 0
     with pytest.raises(pkg._lib.DfdError):
         h.vote_allgather(np.zeros((1, 10)))
+
+
+def test_lookahead_batches_give_the_per_wave_records(pkg, b0_handle):
+    """local_records_waves (L waves of a rank in one device pass) returns, wave by wave, exactly the blocks that L
+    calls of local_records return - the look-ahead only changes how frames are batched on the device."""
+    S = pkg.streams
+    h = b0_handle
+    streams = [_stream(3, 7), _stream(4, 7)]
+    n_streams = len(streams)
+    for world, rank in ((1, 0), (2, 1)):
+        sh = S.ShardedStreams(h, n_streams, rank, world, transport="local")
+        waves = [w for w in range(7) if sh.frame_of(w) < 7]
+        single = []
+        for w in waves:
+            t = sh.frame_of(w)
+            arr = np.stack([streams[s][t] for s in range(n_streams)] + ([streams[s][t - 1] for s in range(n_streams)] if t > 0 else []))
+            fd = h.alloc(arr.nbytes).upload(arr)
+            single.append(sh.local_records(fd.ptr, H, W, [(s, t, t > 0) for s in range(n_streams)]))
+            fd.free()
+        cur, prev, items = [], [], []
+        for w in waves:
+            t = sh.frame_of(w)
+            cur += [streams[s][t] for s in range(n_streams)]
+            if t > 0:
+                prev += [streams[s][t - 1] for s in range(n_streams)]
+            items.append([(s, t, t > 0) for s in range(n_streams)])
+        arr = np.stack(cur + prev)
+        fd = h.alloc(arr.nbytes).upload(arr)
+        multi = sh.local_records_waves(fd.ptr, H, W, items)
+        fd.free()
+        assert len(multi) == len(single)
+        for a, b in zip(single, multi):
+            assert np.array_equal(a, b, equal_nan=True), (world, rank)
