@@ -7,6 +7,7 @@
 #    passes, SQ counters in two passes of 8 - of the classifier-only driver (fp32 and bf16).
 set -u
 TAG=${1:-r02}
+MODE=${2:-all}          # all | e2e (kernel stats of bench / e2e / MTCNN only: what changes when the classifier kernels do not)
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -18,11 +19,18 @@ python3 bench.py --steps 20 --warmup 5 --no-e2e --no-streams --no-cpu-baseline >
 cd /tmp
 run() { name=$1; shift; rocprofv3 "$@" > "$OUT/$name.log" 2>&1 || { echo "rocprofv3 $name failed"; tail -5 "$OUT/$name.log"; exit 1; }; }
 run stats_bench --kernel-trace --stats -d "$OUT/stats_bench" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-e2e --no-streams --no-cpu-baseline
+export MT_FRAMES=64
+run stats_mtcnn_selective --kernel-trace --stats -d "$OUT/stats_mtcnn_selective" -o s --output-format csv -- python3 "$ROOT/profiles/mtcnn_profile_driver.py"
+unset MT_FRAMES
+export MT_DENSE=1
+run stats_mtcnn_stress --kernel-trace --stats -d "$OUT/stats_mtcnn_stress" -o s --output-format csv -- python3 "$ROOT/profiles/mtcnn_profile_driver.py"
+unset MT_DENSE
+run stats_e2e --kernel-trace --stats -d "$OUT/stats_e2e" -o s --output-format csv -- python3 "$ROOT/profiles/e2e_profile_driver.py"
+if [ "$MODE" = "e2e" ]; then cd "$ROOT"; find "$OUT" -name "*.csv" | sort; exit 0; fi
 run stats_b0 --kernel-trace --stats -d "$OUT/stats_b0" -o s --output-format csv -- python3 "$ROOT/profiles/b0_profile_driver.py"
 export B0_BF16=1
 run stats_b0_bf16 --kernel-trace --stats -d "$OUT/stats_b0_bf16" -o s --output-format csv -- python3 "$ROOT/profiles/b0_profile_driver.py"
 unset B0_BF16
-run stats_e2e --kernel-trace --stats -d "$OUT/stats_e2e" -o s --output-format csv -- python3 "$ROOT/profiles/e2e_profile_driver.py"
 run pmc_fetch --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o p --output-format csv -- python3 "$ROOT/profiles/b0_profile_driver.py"
 run pmc_write --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o p --output-format csv -- python3 "$ROOT/profiles/b0_profile_driver.py"
 run pmc_sqa --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --kernel-trace -d "$OUT/pmc_sqa" -o p --output-format csv -- python3 "$ROOT/profiles/b0_profile_driver.py"
