@@ -30,6 +30,7 @@ struct MtcnnState {
     MtConv o1, o2, o3, o4;
     MtDense o5, o61, o62, o63;
     MtConv r1p;                           // R-Net conv1 with 32 output channels (4 zero filters)
+    const float* p1w_pad = nullptr;       // P-Net conv1 weights in a 288-float buffer (scalar loads read 16 at a time)
     MtGemmConv r2g, r3g, o2g, o3g, o4g;
     DevBuf in, a0, a1, z, prob, reg, win, coef, bnd, tmp, face, d_lv, d_items, d_pre, bs, cand;
 };
@@ -331,7 +332,7 @@ struct Cascade {
         std::vector<Level> levels;
         std::vector<MtLevel> lv;
         // per layer: items + running totals of output elements (arena offsets are the same running totals)
-        std::vector<MtItem> it_c1, it_p, it_c2, it_c3, it_z, it_r;
+        std::vector<MtItem> it_c1, it_p, it_c2, it_c3, it_z, it_r, it_f;
         std::vector<long long> pre_in{0}, pre_c1{0}, pre_p{0}, pre_c2{0}, pre_c3{0}, pre_z{0}, pre_r{0};
         long long cells = 0;
         for (int c = 0; c < n; ++c) {
@@ -346,6 +347,7 @@ struct Cascade {
                 lv.push_back(MtLevel{imgs[c].src, (long long)imgs[c].stride, hh, ww, sh, sw, pre_in.back()});
                 it_c1.push_back(MtItem{pre_in.back(), pre_c1.back(), sh, sw});
                 it_p.push_back(MtItem{pre_c1.back(), pre_p.back(), c1h, c1w});
+                it_f.push_back(MtItem{pre_in.back(), pre_p.back(), sh, sw});           // conv1 + pool fused: pyramid -> pooled map
                 it_c2.push_back(MtItem{pre_p.back(), pre_c2.back(), ph, pw});
                 it_c3.push_back(MtItem{pre_c2.back(), pre_c3.back(), c2h, c2w});
                 it_z.push_back(MtItem{pre_c3.back(), pre_z.back(), c3h, c3w});
@@ -372,7 +374,7 @@ struct Cascade {
             if ((rc = upload(&S->d_lv, lv))) return rc;
             std::vector<MtItem> items;
             std::vector<long long> pres;
-            const std::vector<MtItem>* its[6] = {&it_c1, &it_p, &it_c2, &it_c3, &it_z, &it_r};
+            const std::vector<MtItem>* its[7] = {&it_c1, &it_p, &it_c2, &it_c3, &it_z, &it_r, &it_f};
             const std::vector<long long>* prs[7] = {&pre_in, &pre_c1, &pre_p, &pre_c2, &pre_c3, &pre_z, &pre_r};
             for (auto* v : its) items.insert(items.end(), v->begin(), v->end());
             for (auto* v : prs) pres.insert(pres.end(), v->begin(), v->end());
@@ -399,8 +401,9 @@ struct Cascade {
             DFD_HIP_TRY(h, hipMemsetAsync(d_count, 0, 16, s));
             const MtPnetHeads heads{S->p41.w, S->p41.b, S->p42.w, S->p42.b, (float*)S->prob.p, (float*)S->reg.p,
                                     d_cand, d_count, (unsigned)cells, 0.6f};                  // thresholds[0], >=, float32
-            bool ok = launch_mt_convpx_ragged(in, S->p1.w, S->p1.b, S->p1.a, a0, item_at(0), pre_at(1), nl, pre_c1.back(), 3, 10, 3, nullptr, s);
-            launch_mt_maxpool_ragged(a0, a1, item_at(1), pre_at(2), nl, pre_p.back(), 10, 2, 2, s);
+            // conv1 + PReLU + pool in one launch (the 10-channel conv map is never stored), then conv2, then conv3 + heads
+            launch_mt_pnet_conv1_pool(in, S->p1w_pad, S->p1.b, S->p1.a, a1, item_at(6), pre_at(2), nl, pre_p.back(), s);
+            bool ok = true;
             ok = ok && launch_mt_convpx_ragged(a1, S->p2.w, S->p2.b, S->p2.a, a0, item_at(2), pre_at(3), nl, pre_c2.back(), 10, 16, 3, nullptr, s);
             ok = ok && launch_mt_convpx_ragged(a0, S->p3.w, S->p3.b, S->p3.a, nullptr, item_at(3), pre_at(4), nl, pre_c3.back(), 16, 32, 3, &heads, s);
             if (!ok) return fail(h, DFD_ERR_STATE, "mtcnn: no P-Net kernel instance for this layer shape");
@@ -667,11 +670,15 @@ int mtcnn_init(dfd_handle* h) {
                           {S->o2g.b, S->o2g.a, S->o2g.co, &S->o2g.ba}, {S->o3g.b, S->o3g.a, S->o3g.co, &S->o3g.ba},
                           {S->o4g.b, S->o4g.a, S->o4g.co, &S->o4g.ba}, {S->r4.b, S->r4.a, S->r4.out, &S->r4.ba},
                           {S->o5.b, S->o5.a, S->o5.out, &S->o5.ba}};
-    size_t floats = 0;
+    size_t floats = 288;
     for (const Pair& p : pairs) floats += 2 * (size_t)p.n;
     int rc = ensure(h, &S->bs, floats * 4);
     if (rc) return rc;
     float* dst = (float*)S->bs.p;
+    DFD_HIP_TRY(h, hipMemsetAsync(dst, 0, 288 * 4, h->stream));
+    DFD_HIP_TRY(h, hipMemcpyAsync(dst, S->p1.w, 270 * 4, hipMemcpyDeviceToDevice, h->stream));
+    S->p1w_pad = dst;
+    dst += 288;
     for (const Pair& p : pairs) {
         DFD_HIP_TRY(h, hipMemcpyAsync(dst, p.b, (size_t)p.n * 4, hipMemcpyDeviceToDevice, h->stream));
         DFD_HIP_TRY(h, hipMemcpyAsync(dst + p.n, p.a, (size_t)p.n * 4, hipMemcpyDeviceToDevice, h->stream));

@@ -53,6 +53,10 @@ bool launch_mt_convpx_ragged(const float* x, const float* w, const float* b, con
                              const MtPnetHeads* heads, hipStream_t s);
 bool launch_mt_convpx(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int ih, int iw,
                       int ci, int co, int k, hipStream_t s);
+// P-Net conv1 (3 -> 10) + PReLU + MaxPool2d(2, 2, ceil_mode=True), ragged; items = {input offset, pooled offset, level h, w},
+// pre / total = running totals of pooled elements; w_padded: the [3][3][3][10] weights in a buffer of >= 272 floats
+void launch_mt_pnet_conv1_pool(const float* x, const float* w_padded, const float* b, const float* slope, float* y,
+                               const MtItem* items_dev, const long long* pre_dev, int n, long long total, hipStream_t s);
 // conv 3x3 (3 -> 32) + bias + PReLU + MaxPool2d(3, 2, ceil_mode=True) of `n` maps [ih][iw][3] -> [ph][pw][32]
 bool launch_mt_conv1_pool(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int ih, int iw,
                           int co, hipStream_t s);

@@ -479,6 +479,98 @@ __device__ __forceinline__ sf16 sload16s(const float* p, int byte_off) {      //
 __device__ __forceinline__ void swait1(sf16& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
 __device__ __forceinline__ void swait2(sf16& a, sf16& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
 
+// P-Net conv1 (3 -> 10, 3x3) + PReLU + MaxPool2d(2, 2, ceil_mode) over every pyramid level of every crop in one ragged
+// launch: a thread owns one pooled pixel = the 2x2 convolution pixels under it (no overlap at stride 2: nothing is
+// recomputed), 4 x 10 accumulators, the 4x4x3 input patch in registers, the 270 weights as SGPR operands (sload16s, one
+// group of 16 ahead; `w` must be readable up to 272 floats).  Products accumulate as fmaf in (ci, ky, kx) order, then
+// + bias, PReLU, max over the pixels that exist (ceil mode clips the last row / column): the bits of mt_convpx + the
+// separate pool.  items[i] = {pyramid offset, pooled-map offset (elements), level height, width}; pre = running totals
+// of pooled ELEMENTS (pixels x 10).  The 10-channel conv map (1.4 GB per 256 crops, written and read back) is gone.
+__global__ __launch_bounds__(256) void mt_pnet_conv1_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, const float* __restrict__ slope,
+                                                                 float* __restrict__ y, const MtItem* __restrict__ items,
+                                                                 const long long* __restrict__ pre, int n) {
+    constexpr int CO = 10;
+    const long long npix = pre[n] / CO;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long q = t < npix ? t : npix - 1;             // surplus threads redo the last pixel (uniform control flow)
+    const int i = mt_find(pre, n, q * CO);
+    const MtItem it = items[i];
+    const long long r = q - pre[i] / CO;
+    const int c1h = it.ih - 2, c1w = it.iw - 2;
+    int pw = (c1w - 2 + 1) / 2 + 1;                          // MaxPool2d(2, 2, ceil_mode): as mt_pool_out
+    if ((pw - 1) * 2 >= c1w) --pw;
+    const int py = (int)(r / pw), px = (int)(r % pw);
+    const bool vy = 2 * py + 1 < c1h, vx = 2 * px + 1 < c1w;
+    const float* xi = x + it.in_off;
+    float patch[4][4][3];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int row = min(2 * py + a, it.ih - 1);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int col = min(2 * px + c4, it.iw - 1);
+            const float* p = xi + ((size_t)row * it.iw + col) * 3;
+            patch[a][c4][0] = p[0]; patch[a][c4][1] = p[1]; patch[a][c4][2] = p[2];
+        }
+    }
+    float acc[4][CO];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[p][o] = 0.f;
+    sf16 wn = sload16<0>(w);
+#pragma unroll
+    for (int g = 0; g < 17; ++g) {                           // 17 groups of 16 weights: flat index = tap * 10 + channel
+        swait1(wn);
+        const sf16 wc = wn;
+        if (g + 1 < 17) wn = sload16s(w, (g + 1) * 64);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int idx = g * 16 + j;
+            if (idx < 270) {
+                const int tap = idx / CO, o = idx % CO, c = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[p][o] = fmaf(patch[(p >> 1) + ky][(p & 1) + kx][c], wc[j], acc[p][o]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // the group's FMAs stay before the next wait / load: two groups live
+    }
+    float out[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+        const float bo = b[o], so = slope[o];
+        float v[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            v[p] = acc[p][o] + bo;
+            v[p] = v[p] >= 0.f ? v[p] : v[p] * so;
+        }
+        float m = v[0];
+        if (vx) m = fmaxf(m, v[1]);
+        if (vy) m = fmaxf(m, v[2]);
+        if (vx && vy) m = fmaxf(m, v[3]);
+        out[o] = m;
+    }
+    // the results are pinned here: with the guarded store as their only use the optimiser sinks the whole FMA sequence into
+    // the branch, below every scalar load, and then spills all 17 weight groups lane by lane
+    asm volatile("" ::"v"(out[0]), "v"(out[1]), "v"(out[2]), "v"(out[3]), "v"(out[4]), "v"(out[5]), "v"(out[6]), "v"(out[7]),
+                 "v"(out[8]), "v"(out[9]));
+    if (t < npix) {
+        float* yp = y + it.out_off + r * CO;
+#pragma unroll
+        for (int o = 0; o < CO; o += 2) *reinterpret_cast<float2*>(yp + o) = make_float2(out[o], out[o + 1]);
+    }
+}
+
+void launch_mt_pnet_conv1_pool(const float* x, const float* w_padded, const float* b, const float* slope, float* y,
+                               const MtItem* items_dev, const long long* pre_dev, int n, long long total, hipStream_t s) {
+    const long long npix = total / 10;
+    if (npix <= 0) return;
+    hipLaunchKernelGGL(mt_pnet_conv1_pool_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, x, w_padded, b, slope, y,
+                       items_dev, pre_dev, n);
+}
+
 // First layer of R-Net / O-Net with its pooling: conv 3x3 (3 -> 32) + bias + PReLU + MaxPool2d(3, 2, ceil_mode) in one
 // launch.  A thread owns one pooled column of one window and walks down the convolution rows: per row it evaluates the
 // three convolution pixels of its pooling window (all 32 channels in registers, products accumulated as fmaf in
@@ -558,6 +650,7 @@ __global__ __launch_bounds__(256, 3) void mt_conv1_pool_kernel(const float* __re
                     a = __builtin_elementwise_fma(x2, (v2f){wc[o], wc[o + 1]}, a);
                     acc[p][o] = a.x; acc[p][o + 1] = a.y;
                 }
+            __builtin_amdgcn_sched_barrier(0);               // the tap's FMAs stay before the next wait / load: two groups live
         }
         const bool even = (yy & 1) == 0;
         sf16 bv = sload16<0>(b), sv = sload16<0>(slope);

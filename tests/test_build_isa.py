@@ -18,20 +18,31 @@ CSRC = os.path.join(ROOT, "real-time-video-deepfake-detection_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+def _kernel_body(lines, mangled_prefix):
+    start = next(i for i, l in enumerate(lines) if l.startswith(mangled_prefix) and ":" in l)
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    return lines[start:end], "\n".join(lines[end:end + 80])
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
-def test_conv1_pool_kernel_has_no_sgpr_spills():
+def test_scalar_operand_kernels_have_no_sgpr_spills_after_their_loads():
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "mtcnn_kernels.s")
         subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "--cuda-device-only", "-S",
                         os.path.join(CSRC, "mtcnn_kernels.hip"), "-o", out], check=True, cwd=CSRC)
         lines = open(out).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3dfd20mt_conv1_pool_kernel") and ":" in l)
-    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
-    body = lines[start:end]
-    ops = [m.group(1) for l in body for m in [re.match(r"\s+([a-z_0-9]+)", l)] if m]
-    assert ops.count("s_load_dwordx16") >= 29 and ops.count("v_pk_fma_f32") == 27 * 24        # SGPR operands, packed FMAs
-    # spills of loop-invariant pointers before the row loop are harmless; none may follow the first asm load
-    first_load = next(i for i, l in enumerate(body) if "s_load_dwordx16" in l)
-    assert not any("v_writelane_b32" in l for l in body[first_load:]), "SGPR spill inside mt_conv1_pool_kernel's row loop"
-    meta = "\n".join(lines[end:end + 80])
-    assert int(re.search(r"; Occupancy: (\d+)", meta).group(1)) >= 3
+    for prefix, n_loads, fma_op, n_fma in (("_ZN3dfd20mt_conv1_pool_kernel", 29, "v_pk_fma_f32", 27 * 24),
+                                           ("_ZN3dfd25mt_pnet_conv1_pool_kernel", 17, None, 0)):
+        body, meta = _kernel_body(lines, prefix)
+        ops = [m.group(1) for l in body for m in [re.match(r"\s+([a-z_0-9]+)", l)] if m]
+        assert ops.count("s_load_dwordx16") >= n_loads, prefix                       # weights as SGPR operands
+        if fma_op:
+            assert ops.count(fma_op) == n_fma, prefix                                # packed FMAs
+        # spills of loop-invariant pointers before the first asm load are harmless; none may follow it
+        first_load = next(i for i, l in enumerate(body) if "s_load_dwordx16" in l)
+        assert not any("v_writelane_b32" in l for l in body[first_load:]), f"SGPR spill after the scalar loads of {prefix}"
+        # the FMAs sit between the loads (a sunk FMA block would put them all after the last one)
+        loads = [i for i, l in enumerate(body) if "s_load_dwordx16" in l]
+        fmas = [i for i, l in enumerate(body) if re.search(r"v_(pk_)?fma(c)?_f32", l)]
+        assert sum(1 for i in fmas if i < loads[-1]) > len(fmas) // 2, prefix
+        assert int(re.search(r"; Occupancy: (\d+)", meta).group(1)) >= 3, prefix
