@@ -192,18 +192,35 @@ __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__
     __shared__ int n_kept;
     const int tid = threadIdx.x, img = blockIdx.x;
     const float* pr = prob + (size_t)img * n_priors;
-    for (int i = tid; i < NMS_SORT; i += 1024) {
+    // priors above the confidence threshold are appended to the front of key[] (any order: the keys are unique and the
+    // sort below orders them), then only the next power of two above their number is sorted - a few hundred for a
+    // trained detector instead of all 16384 slots (105 barrier-separated bitonic stages down to ~40)
+    __shared__ int n_valid;
+    if (tid == 0) n_valid = 0;
+    unsigned long long mine[NMS_SORT / 1024];
+#pragma unroll
+    for (int r = 0; r < NMS_SORT / 1024; ++r) {
+        const int i = tid + r * 1024;
         unsigned long long k = 0ull;
         if (i < n_priors) {
             const float p = pr[i];
             if (p > conf_thr) k = ((unsigned long long)__float_as_uint(p) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
         }
-        key[i] = k;
+        mine[r] = k;
     }
     __syncthreads();
-    for (int size = 2; size <= NMS_SORT; size <<= 1)
+#pragma unroll
+    for (int r = 0; r < NMS_SORT / 1024; ++r)
+        if (mine[r] != 0ull) key[atomicAdd(&n_valid, 1)] = mine[r];
+    __syncthreads();
+    int sort_n = 2;
+    while (sort_n < n_valid) sort_n <<= 1;
+    if (sort_n < NMS_TOPK) sort_n = 512;                   // the candidate scan below reads the first NMS_TOPK slots
+    for (int i = n_valid + tid; i < sort_n; i += 1024) key[i] = 0ull;
+    __syncthreads();
+    for (int size = 2; size <= sort_n; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < NMS_SORT / 2; t += 1024) {
+            for (int t = tid; t < sort_n / 2; t += 1024) {
                 const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
                 const bool desc = (lo & size) == 0;
                 const unsigned long long a = key[lo], b = key[hi];
@@ -223,7 +240,7 @@ __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__
     }
     if (tid == 0) n_kept = 0;
     __syncthreads();
-    for (int i = 0; i < NMS_TOPK; ++i) ncand += key[i] != 0ull;     // every thread computes the same count
+    ncand = n_valid < NMS_TOPK ? n_valid : NMS_TOPK;                // the valid keys sort to the front
     for (int i = 0; i < ncand; ++i) {
         if (!dead[i]) {                                             // uniform: all threads read the same flag
             if (tid == 0) kept[n_kept++] = i;
