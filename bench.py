@@ -244,6 +244,8 @@ def e2e_mtcnn(frames, boxes, K):
         if tag not in handles:
             hh = pkg._lib.Handle(W.pack_all(W.seeded_state_dict(0), W.seeded_ssd_state_dict(0),
                                             W.seeded_mtcnn_state_dict(0, bias)), device=0, max_batch=len(frames) * K)
+            hh.warmup(len(frames) * K, len(frames))             # classifier / detector GEMM tiles, as for the main handle
+            hh.warmup(8 * K, 8)
             handles[tag] = (hh, hh.alloc(frames.nbytes).upload(frames))
         h, fd = handles[tag]
         h.set_option("mtcnn", flag)
@@ -334,6 +336,7 @@ def config5_streams(h, rank, world, dist, local_rank, waves=32, n_streams=8, ver
     except Exception as e:                                       # noqa: BLE001 - any failure -> documented fallback
         transport, note = ("torch" if world > 1 else "local"), f"dfd_comm_init failed: {e}"
     sh = S.ShardedStreams(h, n_streams, rank, world, transport=transport)
+    h.warmup(min(n_streams * lookahead, h.max_batch), n_streams * lookahead)     # GEMM tiles of this batch shape (untimed)
 
     def batch(t):
         cur = [stream_frame(bases[s], t) for s in range(n_streams)]
