@@ -184,6 +184,26 @@ __global__ __launch_bounds__(256) void clahe_hist_kernel(const uint8_t* __restri
     luts[((size_t)blockIdx.y * 64 + blockIdx.x) * 256 + tid] = (uint8_t)clampi((int)v, 0, 255);
 }
 
+// Lab -> BGR with the two linear offset tables and abToXZ_b evaluated instead of gathered (the same integers: the
+// tables are defined by these formulas, luts.py / oracle lab_tables; C division truncates toward zero like the
+// Python restatement): a_div / b_div are L1 hits but abToXZ_b is 147 KB - two L2 gathers per pixel.
+__device__ __forceinline__ int ab_to_xz(int v) {
+    const int lin = (v * 108) / 841 - 290;                                   // BASE*16/116*108/841 = 290
+    const int cube = (int)((((unsigned)(v * v) >> 14) * (unsigned)v) >> 14);  // v > 3390 here: all factors positive
+    return v <= 3390 ? lin : cube;
+}
+
+__device__ __forceinline__ void lab2bgr_fast(const ColorTables& T, int L, int A, int B, int& b, int& g, int& r) {
+    const int TAB = 1 << 12;
+    const int fy = T.L_fy[L], y = T.L_y[L];
+    const int adiv = ((5 * A * 53687 + 128) >> 13) - 4194, bdiv = ((B * 41943 + 16) >> 9) - 10485 + 1;
+    const long long x = ab_to_xz(fy + adiv), z = ab_to_xz(fy - bdiv);
+    r = T.inv_gamma[clampi(descale(T.inv[0] * x + T.inv[1] * y + T.inv[2] * z, 14), 0, TAB - 1)];
+    g = T.inv_gamma[clampi(descale(T.inv[3] * x + T.inv[4] * y + T.inv[5] * z, 14), 0, TAB - 1)];
+    b = T.inv_gamma[clampi(descale(T.inv[6] * x + T.inv[7] * y + T.inv[8] * z, 14), 0, TAB - 1)];
+}
+
+// four pixels (12 bytes of the packed crop: three aligned dwords in, three out) per thread and iteration
 __global__ __launch_bounds__(256) void clahe_apply_kernel(const CropDesc* __restrict__ crops,
                                                           const uint8_t* __restrict__ lab_in,
                                                           const uint8_t* __restrict__ luts,
@@ -195,25 +215,37 @@ __global__ __launch_bounds__(256) void clahe_apply_kernel(const CropDesc* __rest
     const uint8_t* lut = luts + (size_t)blockIdx.y * 64 * 256;
     const uint8_t* lab = lab_in + cd.offset;
     uint8_t* out = bgr_out + cd.offset;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < cd.w * cd.h; i += gridDim.x * 256) {
-        const int x = i % cd.w, y = i / cd.w;
-        const float txf = (float)x * inv_tw - 0.5f, tyf = (float)y * inv_th - 0.5f;
-        int tx1 = (int)floorf(txf), ty1 = (int)floorf(tyf);
-        const float xa = txf - (float)tx1, ya = tyf - (float)ty1;
-        const float xa1 = 1.0f - xa, ya1 = 1.0f - ya;
-        int tx2 = tx1 + 1 < 7 ? tx1 + 1 : 7, ty2 = ty1 + 1 < 7 ? ty1 + 1 : 7;
-        tx1 = tx1 > 0 ? tx1 : 0;
-        ty1 = ty1 > 0 ? ty1 : 0;
-        const uint8_t* p = lab + (size_t)i * 3;
-        const int L = p[0];
-        const float l11 = lut[(ty1 * 8 + tx1) * 256 + L], l12 = lut[(ty1 * 8 + tx2) * 256 + L];
-        const float l21 = lut[(ty2 * 8 + tx1) * 256 + L], l22 = lut[(ty2 * 8 + tx2) * 256 + L];
-        const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
-        const int Ln = clampi((int)rintf(res), 0, 255);
-        int b, g, r;
-        lab2bgr(T, Ln, p[1], p[2], b, g, r);
-        uint8_t* o = out + (size_t)i * 3;
-        o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r;
+    const int npix = cd.w * cd.h, ngroups = (npix + 3) / 4;
+    for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ngroups; gi += gridDim.x * 256) {
+        const int i0 = gi * 4;
+        const int cnt = npix - i0 < 4 ? npix - i0 : 4;                     // the crop's last group may be short
+        unsigned char px[12], res8[12];
+        if (cnt == 4) *reinterpret_cast<uint3*>(px) = *reinterpret_cast<const uint3*>(lab + (size_t)i0 * 3);
+        else
+            for (int k = 0; k < 12; ++k) px[k] = k < cnt * 3 ? lab[(size_t)i0 * 3 + k] : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k < npix ? i0 + k : npix - 1;
+            const int x = i % cd.w, y = i / cd.w;
+            const float txf = (float)x * inv_tw - 0.5f, tyf = (float)y * inv_th - 0.5f;
+            int tx1 = (int)floorf(txf), ty1 = (int)floorf(tyf);
+            const float xa = txf - (float)tx1, ya = tyf - (float)ty1;
+            const float xa1 = 1.0f - xa, ya1 = 1.0f - ya;
+            int tx2 = tx1 + 1 < 7 ? tx1 + 1 : 7, ty2 = ty1 + 1 < 7 ? ty1 + 1 : 7;
+            tx1 = tx1 > 0 ? tx1 : 0;
+            ty1 = ty1 > 0 ? ty1 : 0;
+            const int L = px[3 * k];
+            const float l11 = lut[(ty1 * 8 + tx1) * 256 + L], l12 = lut[(ty1 * 8 + tx2) * 256 + L];
+            const float l21 = lut[(ty2 * 8 + tx1) * 256 + L], l22 = lut[(ty2 * 8 + tx2) * 256 + L];
+            const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+            const int Ln = clampi((int)rintf(res), 0, 255);
+            int b, g, r;
+            lab2bgr_fast(T, Ln, px[3 * k + 1], px[3 * k + 2], b, g, r);
+            res8[3 * k] = (unsigned char)b; res8[3 * k + 1] = (unsigned char)g; res8[3 * k + 2] = (unsigned char)r;
+        }
+        if (cnt == 4) *reinterpret_cast<uint3*>(out + (size_t)i0 * 3) = *reinterpret_cast<const uint3*>(res8);
+        else
+            for (int k = 0; k < cnt * 3; ++k) out[(size_t)i0 * 3 + k] = res8[k];
     }
 }
 
@@ -259,7 +291,7 @@ __global__ __launch_bounds__(256) void crop_norm_kernel(const uint8_t* __restric
 void launch_clahe(const uint8_t* frame, size_t fstride, const CropDesc* crops_dev, int n, uint8_t* lab,
                   uint8_t* luts, uint8_t* bgr_out, const ColorTables& T, int max_pixels, hipStream_t s) {
     hipLaunchKernelGGL(clahe_hist_kernel, dim3(64, n), dim3(256), 0, s, frame, fstride, crops_dev, lab, luts, T, 2.0f);
-    int gx = (max_pixels + 255) / 256;
+    int gx = (max_pixels / 4 + 255) / 256;
     if (gx > 1024) gx = 1024;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(clahe_apply_kernel, dim3(gx, n), dim3(256), 0, s, crops_dev, lab, luts, bgr_out, T);
