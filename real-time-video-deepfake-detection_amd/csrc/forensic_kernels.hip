@@ -308,45 +308,72 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(const short2* __restrict
     map[(size_t)blockIdx.y * FPIX + i] = lab;
 }
 
-// One 1024-thread block per frame: the whole label map lives in LDS (64 KiB); candidates
-// adjacent (8-neighbourhood) to an edge become edges until nothing changes.  The fixpoint is
-// the set OpenCV's stack-based flood fill reaches, whatever the visiting order.
+// One 1024-thread block per frame, one 64-pixel word of a row per thread: strong pixels S and weak candidates W as
+// bitboards (8 KiB of LDS for S).  A sweep ORs the three rows around a word, dilates by one column (with the edge bits
+// of the neighbouring words), ANDs with W and then floods along the row inside the word (Kogge-Stone occluded fill,
+// both directions); sweeps repeat until no word changes.  The fixpoint - weak pixels 8-connected to a strong one - is
+// the set OpenCV's stack-based flood fill reaches, whatever the visiting order.  (The byte-map version of this kernel
+// scanned 64 pixels x 9 LDS reads per thread and sweep: 480 us per 64 frames, more than the other nine forensic
+// kernels together.)
+__device__ __forceinline__ unsigned long long fill_row(unsigned long long gen, unsigned long long pro) {
+    unsigned long long g = gen, p = pro;                    // towards higher columns
+    g |= p & (g << 1);  p &= p << 1;
+    g |= p & (g << 2);  p &= p << 2;
+    g |= p & (g << 4);  p &= p << 4;
+    g |= p & (g << 8);  p &= p << 8;
+    g |= p & (g << 16); p &= p << 16;
+    g |= p & (g << 32);
+    unsigned long long h = gen;                             // towards lower columns
+    p = pro;
+    h |= p & (h >> 1);  p &= p >> 1;
+    h |= p & (h >> 2);  p &= p >> 2;
+    h |= p & (h >> 4);  p &= p >> 4;
+    h |= p & (h >> 8);  p &= p >> 8;
+    h |= p & (h >> 16); p &= p >> 16;
+    h |= p & (h >> 32);
+    return g | h;
+}
+
 __global__ __launch_bounds__(1024) void canny_hyst_kernel(const uint8_t* __restrict__ map, double* __restrict__ count) {
-    __shared__ uint8_t m[FPIX];
-    __shared__ int changed;
+    __shared__ unsigned long long S[FS * 4 + 8];            // [row][word], one guard word each side
     __shared__ double red[16];
-    const int tid = threadIdx.x;
-    const uint8_t* src = map + (size_t)blockIdx.x * FPIX;
-    for (int i = tid; i < FPIX / 16; i += 1024)
-        reinterpret_cast<uint4*>(m)[i] = reinterpret_cast<const uint4*>(src)[i];
-    __syncthreads();
-    for (int iter = 0; iter < FPIX; ++iter) {           // bounded: each productive sweep adds >= 1 edge
-        if (tid == 0) changed = 0;
-        __syncthreads();
-        bool any = false;
-        // thread owns a 64-pixel run of one row quarter: row = tid >> 2, cols (tid & 3)*64 ..
-        const int y = tid >> 2, x0 = (tid & 3) * 64;
-        for (int x = x0; x < x0 + 64; ++x) {
-            if (m[y * FS + x] != 0) continue;
-            bool hit = false;
+    const int tid = threadIdx.x, row = tid >> 2, wd = tid & 3;
+    const uint8_t* src = map + (size_t)blockIdx.x * FPIX + row * FS + wd * 64;
+    unsigned long long s = 0ull, w = 0ull;
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
+    for (int k = 0; k < 4; ++k) {
+        const uint4 v = reinterpret_cast<const uint4*>(src)[k];
+        const unsigned wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int yy = y + dy, xx = x + dx;
-                    if ((dy | dx) != 0 && (unsigned)yy < (unsigned)FS && (unsigned)xx < (unsigned)FS && m[yy * FS + xx] == 2) hit = true;
-                }
-            if (hit) { m[y * FS + x] = 2; any = true; }
-        }
-        if (any) changed = 1;
-        __syncthreads();
-        const int c = changed;
-        __syncthreads();
-        if (!c) break;
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const unsigned lab = (wv[q] >> (8 * b)) & 0xFFu;
+                const int bit = k * 16 + q * 4 + b;
+                s |= (unsigned long long)(lab == 2u) << bit;
+                w |= (unsigned long long)(lab == 0u) << bit;
+            }
     }
-    int n = 0;
-    for (int i = tid; i < FPIX; i += 1024) n += m[i] == 2;
-    const double tot = block_sum<1024>((double)n, red);
+    const unsigned long long pass = s | w;
+    unsigned long long* Sw = S + 4;                         // word index row * 4 + wd, guards at -4..-1 and FS*4..FS*4+3
+    if (tid < 4) { S[tid] = 0ull; S[FS * 4 + 4 + tid] = 0ull; }
+    Sw[tid] = s;
+    __syncthreads();
+    for (int iter = 0; iter < FPIX; ++iter) {               // bounded: each productive sweep adds >= 1 edge
+        const unsigned long long up = Sw[tid - 4], dn = Sw[tid + 4];
+        const unsigned long long v = up | s | dn;
+        // edge bits of the horizontal neighbours (rows above / below included); none beyond the image border
+        const unsigned long long vl = wd > 0 ? (Sw[tid - 5] | Sw[tid - 1] | Sw[tid + 3]) : 0ull;
+        const unsigned long long vr = wd < 3 ? (Sw[tid - 3] | Sw[tid + 1] | Sw[tid + 5]) : 0ull;
+        const unsigned long long dil = v | (v << 1) | (v >> 1) | (vl >> 63) | (vr << 63);
+        const unsigned long long nw = fill_row(s | (w & dil), pass);
+        const int any = __syncthreads_or(nw != s);          // also: every read of this sweep is done
+        s = nw;
+        Sw[tid] = s;
+        __syncthreads();
+        if (!any) break;
+    }
+    const double tot = block_sum<1024>((double)__popcll(s), red);
     if (tid == 0) count[blockIdx.x] = tot;
 }
 
