@@ -417,30 +417,47 @@ __global__ __launch_bounds__(256) void absdiff_kernel(const uint8_t* __restrict_
 
 // ------------------------------------------------------------------------------- finalize
 // stats layout per frame (doubles), see forensic_kernels.h
+// One wave per frame: lane l folds partial rows l, l + 64, l + 128, l + 192 (in that order), then a butterfly over the
+// lanes - a fixed order, so the sums are run-to-run and batch-size invariant.  (One thread per frame walking all 256
+// rows was 3,300 dependent L2 round trips: 69 us, the longest forensic kernel once the hysteresis was fixed.)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
 __global__ __launch_bounds__(64) void stats_finalize_kernel(ForensicBuffers B, int full, int nframes) {
-    const int f = blockIdx.x * 64 + threadIdx.x;
+    const int f = blockIdx.x, lane = threadIdx.x;
     if (f >= nframes) return;
     double* st = B.stats + (size_t)f * FORENSIC_STATS;
-    double a[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int r = 0; r < 256; ++r)
-        for (int j = 0; j < 7; ++j) a[j] += B.fft_part[((size_t)f * 256 + r) * 7 + j];
+    double a[7] = {0, 0, 0, 0, 0, 0, 0}, l1 = 0, l2 = 0, s1 = 0, s2 = 0, v1 = 0, v2 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t r = (size_t)f * 256 + lane + 64 * k;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) a[j] += B.fft_part[r * 7 + j];
+        l1 += B.lap_part[r * 2];
+        l2 += B.lap_part[r * 2 + 1];
+        if (full) {
+            const double* p = B.hsv_part + r * 4;
+            s1 += p[0]; s2 += p[1]; v1 += p[2]; v2 += p[3];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) a[j] = wave_sum(a[j]);
+    l1 = wave_sum(l1); l2 = wave_sum(l2);
+    s1 = wave_sum(s1); s2 = wave_sum(s2); v1 = wave_sum(v1); v2 = wave_sum(v2);
+    if (lane != 0) return;
     const double mid_mean = a[2] / a[4];
     st[ST_FREQ_LOW] = a[0] / a[1];
     st[ST_FREQ_MID] = mid_mean;
     st[ST_FREQ_HIGH] = a[5] / a[6];
     const double var = a[3] / a[4] - mid_mean * mid_mean;
     st[ST_FREQ_MID_STD] = sqrt(var > 0 ? var : 0);
-    double l1 = 0, l2 = 0;
-    for (int r = 0; r < 256; ++r) { l1 += B.lap_part[((size_t)f * 256 + r) * 2]; l2 += B.lap_part[((size_t)f * 256 + r) * 2 + 1]; }
     const double lm = l1 / FPIX;
     st[ST_LAP_VAR] = l2 / FPIX - lm * lm;
     st[ST_EDGE_COUNT] = B.edge_count[f];
     if (full) {
-        double s1 = 0, s2 = 0, v1 = 0, v2 = 0;
-        for (int r = 0; r < 256; ++r) {
-            const double* p = B.hsv_part + ((size_t)f * 256 + r) * 4;
-            s1 += p[0]; s2 += p[1]; v1 += p[2]; v2 += p[3];
-        }
         const double sm = s1 / FPIX, vm = v1 / FPIX;
         const double sv = s2 / FPIX - sm * sm, vv = v2 / FPIX - vm * vm;
         st[ST_SAT_STD] = sqrt(sv > 0 ? sv : 0);
@@ -466,7 +483,7 @@ void launch_forensics(const ForensicBuffers& B, int n, bool full, const ColorTab
         hipMemsetAsync(B.hue_bits, 0, (size_t)n * 6 * sizeof(unsigned), s);
         hipLaunchKernelGGL(hsv_stats_kernel, dim3(256, n), dim3(256), 0, s, B.rs, B.hsv_part, B.hue_bits, T);
     }
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((n + 63) / 64), dim3(64), 0, s, B, full ? 1 : 0, n);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(n), dim3(64), 0, s, B, full ? 1 : 0, n);
 }
 
 // frame-sharded streams: frame f against frame prev_index[f] of the same batch (gray planes [n][65536]);
