@@ -62,4 +62,26 @@ __device__ __forceinline__ void split8(const v4f lo, const v4f hi, bf8& s0, bf8&
     }
 }
 
+
+// ---- scalar operands ----
+// Scalar (wave-uniform) operand loads under program control: 16 consecutive floats of a kernel-argument array into
+// SGPRs.  Plain C++ reads of uniform addresses also become s_load, but hipcc hoists all of a loop's invariant ones to
+// the top and then spills hundreds of SGPR values lane by lane (v_readlane): here the load is issued one group ahead of
+// its use and the wait names the registers it releases.
+typedef float sf16 __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int BYTE_OFF>
+__device__ __forceinline__ sf16 sload16(const float* p) {
+    sf16 v;
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(p), "n"(BYTE_OFF));
+    return v;
+}
+__device__ __forceinline__ sf16 sload16s(const float* p, int byte_off) {      // offset in an SGPR: usable from an unrolled loop
+    sf16 v;
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(v) : "s"(p), "s"(byte_off));
+    return v;
+}
+__device__ __forceinline__ void swait1(sf16& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a)); }
+__device__ __forceinline__ void swait2(sf16& a, sf16& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+
 }  // namespace dfd

@@ -9,52 +9,91 @@
 //                      stable), top_k, greedy NMS, keep_top_k
 // The 3x3 / 1x1 trunk and head convolutions run on pw_kernel<NT, true> (b0_kernels.hip).
 #include "ssd_kernels.h"
+#include "kernel_util.h"
 
 namespace dfd {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------- conv1
-// thread = (output pixel, 4 of the 32 output channels); weights [7][7][3][32] staged in LDS
+// thread = one output pixel x 16 of the 32 output channels (blockIdx.y = channel half).  The 7x7x3 x 16 weights of the
+// half are SGPR operands of v_pk_fma_f32 (scalar loads, one tap ahead, kernel_util.h): no LDS, no weight VGPRs; the
+// products accumulate in (ky, kx, ci) order on top of the bias.  A tap outside the image contributes 0 (Caffe pads the
+// mean-subtracted blob with zeros): the byte is read from a clamped address and the VALUE is masked, so every load of
+// a kernel row is unconditional.  Replaces a thread-per-channel-quad kernel with LDS weights (365 us per 64 frames).
 __global__ __launch_bounds__(256) void ssd_conv1_kernel(const uint8_t* __restrict__ img, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y, int n_img,
                                                         float sb, float sg, float sr, float hb, float hg, float hr, int relu) {
-    __shared__ float ws[147 * 32];
-    for (int i = threadIdx.x; i < 147 * 32; i += 256) ws[i] = w[i];
-    __syncthreads();
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int cg = (int)(gid & 7);
-    const long long pix = gid >> 3;
-    if (pix >= (long long)n_img * 150 * 150) return;
+    const int half = blockIdx.y;
+    const float* wh = w + half * 16;                         // weights [7][7][3][32]: a tap's 16 floats of this half
+    const long long npix = (long long)n_img * 150 * 150;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long pix = t < npix ? t : npix - 1;           // surplus threads redo the last pixel (uniform control flow)
     const int ox = (int)(pix % 150), oy = (int)((pix / 150) % 150), n = (int)(pix / 22500);
     const uint8_t* src = img + (size_t)n * 300 * 300 * 3;
     const float sc[3] = {sb, sg, sr}, sh[3] = {hb, hg, hr};
-    v4f acc = *reinterpret_cast<const v4f*>(b + 4 * cg);
-    // (taps outside the image contribute 0: Caffe pads the mean-subtracted blob with zeros.  The branchy form is
-    // kept on purpose: with all 147 byte loads made unconditional and unrolled the kernel ran 20x slower.)
+    float acc[16];
+    {
+        sf16 bv = sload16s(b, half * 64);
+        swait1(bv);
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = bv[o];
+    }
+    int col[7];
+    float mx[7];                                             // 1 inside the image, 0 outside (a multiplier, not a branch)
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+        const int ix = 2 * ox - 3 + kx;
+        mx[kx] = (unsigned)ix < 300u ? 1.f : 0.f;
+        col[kx] = (ix < 0 ? 0 : (ix > 299 ? 299 : ix)) * 3;
+    }
+#pragma unroll 1
     for (int ky = 0; ky < 7; ++ky) {
         const int iy = 2 * oy - 3 + ky;
-        if ((unsigned)iy >= 300u) continue;
+        const float my = (unsigned)iy < 300u ? 1.f : 0.f;
+        const uint8_t* row = src + (size_t)(iy < 0 ? 0 : (iy > 299 ? 299 : iy)) * 900;
+        float v[21];
 #pragma unroll
-        for (int kx = 0; kx < 7; ++kx) {
-            const int ix = 2 * ox - 3 + kx;
-            if ((unsigned)ix >= 300u) continue;
-            const uint8_t* p = src + ((size_t)iy * 300 + ix) * 3;
+        for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) {
-                const float v = (float)p[ci] * sc[ci] + sh[ci];
-                acc += v * *reinterpret_cast<const v4f*>(&ws[((ky * 7 + kx) * 3 + ci) * 32 + 4 * cg]);
+                const float f = (float)row[col[kx] + ci] * sc[ci] + sh[ci];
+                v[kx * 3 + ci] = f * (my * mx[kx]);          // x 1 is exact; a select here makes hipcc branch around the load
             }
+        sf16 wn = sload16s(wh, ky * 21 * 128);
+#pragma unroll
+        for (int tp = 0; tp < 21; ++tp) {
+            swait1(wn);
+            const sf16 wc = wn;
+            if (tp + 1 < 21) wn = sload16s(wh, (ky * 21 + tp + 1) * 128);
+#pragma unroll
+            for (int o = 0; o < 16; o += 2) {
+                const v2f x2 = {v[tp], v[tp]};
+                v2f a = {acc[o], acc[o + 1]};
+                a = __builtin_elementwise_fma(x2, (v2f){wc[o], wc[o + 1]}, a);
+                acc[o] = a.x; acc[o + 1] = a.y;
+            }
+            __builtin_amdgcn_sched_barrier(0);               // the tap's FMAs stay before the next wait / load
         }
     }
-    if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-    *reinterpret_cast<v4f*>(y + (size_t)pix * 32 + 4 * cg) = acc;
+    if (relu) {
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = fmaxf(acc[o], 0.f);
+    }
+    // the results are pinned before the guarded store (see mt_pnet_conv1_pool_kernel: otherwise the FMAs sink into the branch)
+    asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]),
+                 "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]), "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15]));
+    if (t < npix) {
+        float* yp = y + (size_t)pix * 32 + half * 16;
+#pragma unroll
+        for (int o = 0; o < 16; o += 4) *reinterpret_cast<v4f*>(yp + o) = (v4f){acc[o], acc[o + 1], acc[o + 2], acc[o + 3]};
+    }
 }
 
 void launch_ssd_conv1(const uint8_t* img, const float* w, const float* b, float* y, int n, const float in_scale[3],
                       const float in_shift[3], bool relu, hipStream_t s) {
-    const long long threads = (long long)n * 150 * 150 * 8;
-    hipLaunchKernelGGL(ssd_conv1_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, s, img, w, b, y, n,
+    const long long threads = (long long)n * 150 * 150;
+    hipLaunchKernelGGL(ssd_conv1_kernel, dim3((int)((threads + 255) / 256), 2), dim3(256), 0, s, img, w, b, y, n,
                        in_scale[0], in_scale[1], in_scale[2], in_shift[0], in_shift[1], in_shift[2], relu ? 1 : 0);
 }
 
