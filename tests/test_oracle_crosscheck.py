@@ -73,3 +73,18 @@ def test_gray_is_the_601_luma():
     g = R.bgr2gray_u8(px)[0].astype(np.float64)
     want = px[0].astype(np.float64) @ np.array([0.114, 0.587, 0.299])
     assert np.abs(g - want).max() <= 0.51
+
+
+def test_resize_linear_within_one_level_of_float_bilinear():
+    """cv2.resize(INTER_LINEAR) is plain bilinear sampling at half-pixel centres (no antialiasing) in 11-bit fixed point:
+    torch's F.interpolate(mode="bilinear", align_corners=False) is the same sampling in float."""
+    import torch
+    import torch.nn.functional as F
+
+    rs = np.random.RandomState(6)
+    for (h, w, dh, dw) in ((120, 160, 64, 64), (97, 131, 256, 256), (300, 300, 112, 75)):
+        img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        got = R.resize_linear_u8(img, dw, dh).astype(np.float64)
+        t = torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None]
+        want = F.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert np.abs(got - want).max() <= 1.0, (h, w, dh, dw, np.abs(got - want).max())
