@@ -74,20 +74,38 @@ void launch_mt_conv(const float* x, const float* w, const float* b, const float*
                        ci, co, k);
 }
 
+// thread = output pixel x 4 channels (c % 4 == 0: every pooled map of R-/O-Net has 32 or 64 channels; other widths take
+// the scalar path).  Ceil mode: a tap outside the map re-reads the window's first element (a max is idempotent), so
+// all k x k vector loads are unconditional and in flight together.
+template <int V>
 __global__ __launch_bounds__(256) void mt_maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int ih,
                                                          int iw, int c, int k, int st, int oh, int ow) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)n * oh * ow * c;
+    const int cv = c / V;
+    const long long total = (long long)n * oh * ow * cv;
     if (t >= total) return;
-    const int ch = (int)(t % c);
-    const int ox = (int)((t / c) % ow), oy = (int)((t / c / ow) % oh), i = (int)(t / c / ow / oh);
-    float m = -INFINITY;
+    const int ch = (int)(t % cv) * V;
+    const int ox = (int)((t / cv) % ow), oy = (int)((t / cv / ow) % oh), i = (int)(t / cv / ow / oh);
+    const float* xi = x + (size_t)i * ih * iw * c + ch;
+    float m[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) m[e] = -INFINITY;
     for (int ky = 0; ky < k; ++ky)
         for (int kx = 0; kx < k; ++kx) {
-            const int yy = oy * st + ky, xx = ox * st + kx;
-            if (yy < ih && xx < iw) m = fmaxf(m, x[(((size_t)i * ih + yy) * iw + xx) * c + ch]);      // ceil mode: clipped window
+            int yy = oy * st + ky, xx = ox * st + kx;
+            if (yy >= ih) yy = oy * st;                                  // clipped window: repeat an element of it
+            if (xx >= iw) xx = ox * st;
+            const float* p = xi + ((size_t)yy * iw + xx) * c;
+            if (V == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(p);
+                m[0] = fmaxf(m[0], v.x); m[1 % V] = fmaxf(m[1 % V], v.y); m[2 % V] = fmaxf(m[2 % V], v.z); m[3 % V] = fmaxf(m[3 % V], v.w);
+            } else {
+                m[0] = fmaxf(m[0], p[0]);
+            }
         }
-    y[t] = m;
+    float* yp = y + (((size_t)i * oh + oy) * ow + ox) * c + ch;
+    if (V == 4) *reinterpret_cast<float4*>(yp) = make_float4(m[0], m[1 % V], m[2 % V], m[3 % V]);
+    else yp[0] = m[0];
 }
 
 int mt_pool_out(int in, int k, int st) {
@@ -98,10 +116,15 @@ int mt_pool_out(int in, int k, int st) {
 
 void launch_mt_maxpool(const float* x, float* y, int n, int ih, int iw, int c, int k, int st, hipStream_t s) {
     const int oh = mt_pool_out(ih, k, st), ow = mt_pool_out(iw, k, st);
-    const long long total = (long long)n * oh * ow * c;
-    if (total <= 0) return;
-    hipLaunchKernelGGL(mt_maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, n, ih, iw, c, k, st,
-                       oh, ow);
+    if (c % 4 == 0) {
+        const long long total = (long long)n * oh * ow * (c / 4);
+        if (total <= 0) return;
+        hipLaunchKernelGGL(mt_maxpool_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, n, ih, iw, c, k, st, oh, ow);
+    } else {
+        const long long total = (long long)n * oh * ow * c;
+        if (total <= 0) return;
+        hipLaunchKernelGGL(mt_maxpool_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, n, ih, iw, c, k, st, oh, ow);
+    }
 }
 
 __global__ __launch_bounds__(256) void mt_dense_kernel(const float* __restrict__ x, const float* __restrict__ w,
