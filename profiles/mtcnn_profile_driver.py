@@ -10,6 +10,7 @@ h = pkg._lib.Handle(W.pack_all(W.seeded_state_dict(0), W.seeded_ssd_state_dict(0
 NF = int(os.environ.get("MT_FRAMES", "8"))
 frames = np.random.default_rng(7).integers(50, 200, (NF, 1080, 1920, 3), dtype=np.uint8)
 boxes = [[(200, 150, 320, 400), (900, 300, 256, 256), (1400, 500, 400, 480), (600, 700, 224, 224)]] * NF
+h.warmup(4 * NF, NF)                                        # measured GEMM tiles, as in bench.py
 fd = h.alloc(frames.nbytes).upload(frames)
 if os.environ.get('MT_OFF') == '1':
     h.set_option('mtcnn', 0)

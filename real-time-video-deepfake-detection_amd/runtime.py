@@ -9,8 +9,8 @@ Weights (the reference tree ships none):
               deploy.prototxt (``$DFD_SSD_PROTOTXT``, default: ``deploy.prototxt`` next to it), read by `caffe_io`
               into a detector plan - or an .npz / .pth state dict in `ssd_arch` naming.  Without it there is NO detector:
               the handle is built without one, `detect_bounding_box` returns [] and every frame is analysed in
-              'frame_only' mode (where the reference, whose model files are missing too, face_detection.py:22-34,
-              falls back to a Haar cascade - not built here, DESIGN.md section 8);
+              'frame_only' mode unless a Haar cascade is configured (the reference, whose model files are missing too,
+              face_detection.py:22-34, falls back to Haar: next entry);
   Haar        ``$DFD_HAAR_CASCADE``: OpenCV's haarcascade_frontalface_default.xml (reference face_detection.py:12) - the
               detector the reference falls back to; used here when there are no SSD weights or the SSD call fails;
   MTCNN       ``$DFD_MTCNN_WEIGHTS``: directory with pnet.pt / rnet.pt / onet.pt (facenet-pytorch's files); without it
