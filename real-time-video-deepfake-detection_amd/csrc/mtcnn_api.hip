@@ -105,7 +105,8 @@ int gemm_dense_prelu(dfd_handle* h, const MtDense& d, const float* x, float* y, 
 template <typename F>
 void parallel_for(int count, size_t work, F fn) {
     const int hw = (int)std::thread::hardware_concurrency();
-    const int nt = std::min(std::min(count, 8), std::max(hw / 2, 1));
+    const char* cap = getenv("DFD_HOST_THREADS");            // 1 = everything on the calling thread
+    const int nt = std::min(std::min(count, cap ? std::max(atoi(cap), 1) : 8), std::max(hw / 2, 1));
     if (nt <= 1 || work < 200000) {
         for (int i = 0; i < count; ++i) fn(i);
         return;

@@ -126,3 +126,16 @@ def test_selective_cascade_batch(pkg, seeded_sd):
         assert any(found_want) and not all(found_want)          # the funnel both passes and rejects crops
     finally:
         h.close()
+
+
+def test_threaded_box_logic_equals_serial(pkg, mt_handle, monkeypatch):
+    """A dense funnel (the random-init cascade on large crops: thousands of candidates per crop) sends the per-level and
+    per-crop box logic to host threads; DFD_HOST_THREADS=1 keeps it on the calling thread.  Same logits, same crops
+    without a face."""
+    frame = np.random.default_rng(7).integers(50, 200, (2, 1080, 1920, 3), dtype=np.uint8)[0]
+    boxes = np.array([[200, 150, 320, 400], [900, 300, 256, 256], [1400, 500, 400, 480], [600, 700, 224, 224]], np.int32)
+    threaded = mt_handle.classify_crops(frame, boxes, apply_clahe=True).reshape(-1)
+    monkeypatch.setenv("DFD_HOST_THREADS", "1")
+    serial = mt_handle.classify_crops(frame, boxes, apply_clahe=True).reshape(-1)
+    assert np.array_equal(threaded, serial, equal_nan=True), (threaded, serial)
+    assert not np.isnan(threaded).all()
