@@ -1,10 +1,10 @@
 // MTCNN align/crop stage: the cascade the reference runs on every cropped face before the
 // classifier (reference deepfake_detection.py:24-28, 376-380 -> facenet-pytorch MTCNN.forward: detect_face,
-// select by probability, extract_face to 160x160).  Networks and the two resamplers run as HIP kernels
-// (mtcnn_kernels.hip); the box bookkeeping between the stages (threshold scan, NMS, regression, squaring,
-// clipping: a few hundred rows of float32 arithmetic in the package's operation order) runs here on the host
-// of the library, as the package does it in numpy/torch glue.  Operation order and float32/double choices
-// follow the restatement in oracle/mtcnn_ref.py line by line.
+// select by probability, extract_face to 160x160).  All crops of a call go through the three stages together: the
+// networks, the resamplers and the P-Net candidate compaction run as HIP kernels (mtcnn_kernels.hip, gemm_split.hip);
+// the box bookkeeping between the stages (NMS, regression, squaring, clipping - float32 arithmetic in the package's
+// operation order, restated line by line from oracle/mtcnn_ref.py) runs here on the host side of the library, as the
+// package does it in numpy / torch glue: grid-local per-level NMS, SoA sweeps, host threads when the funnel is dense.
 #include <algorithm>
 #include <chrono>
 #include <cmath>

@@ -13,12 +13,6 @@ struct MtLevel { const uint8_t* src; long long stride; int h, w, oh, ow; long lo
 // one image of a ragged layer launch: offsets (floats) into the input / output arenas, input size
 struct MtItem { long long in_off, out_off; int ih, iw; };
 
-// interpolate(mode="area") of `n` windows of a u8 BGR image to oh x ow, RGB order, (x - 127.5) / 128
-void launch_mt_area_resize(const uint8_t* src, size_t stride, const MtWindow* win_dev, int n, int oh, int ow, float* dst,
-                           hipStream_t s);
-// valid k x k conv, weights [ci][ky][kx][co], + bias, + PReLU when slope != null
-void launch_mt_conv(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int ih, int iw,
-                    int ci, int co, int k, hipStream_t s);
 int mt_pool_out(int in, int k, int st);   // MaxPool2d(k, st, ceil_mode=True) output size
 void launch_mt_maxpool(const float* x, float* y, int n, int ih, int iw, int c, int k, int st, hipStream_t s);
 // y[n][out] = x[n][in] . w[in][out] + b (+ PReLU)
@@ -26,17 +20,9 @@ void launch_mt_dense(const float* x, const float* w, const float* b, const float
                      hipStream_t s);
 // z [n][2] -> softmax(z)[1]
 void launch_mt_softmax_face(const float* z, float* p, long long n, hipStream_t s);
-// one pass of Pillow's 8-bit resize; coeff [out][ksize] int32 (22 fractional bits), bounds [out][2] = (first, count)
-void launch_mt_pil_pass(const uint8_t* src, size_t stride, int x0, int y0, int sw, int sh, const int* coeff_dev,
-                        const int* bounds_dev, int ksize, int out, int vertical, uint8_t* dst, hipStream_t s);
 // ragged variants: `n` images of different sizes per launch; pre[n + 1] = running total of output elements
 void launch_mt_area_resize_ragged(const MtLevel* lv_dev, const long long* pre_dev, int n, long long total, float* dst,
                                   hipStream_t s);
-void launch_mt_conv_ragged(const float* x, const float* w, const float* b, const float* slope, float* y,
-                           const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co, int k,
-                           hipStream_t s);
-// register-blocked variants (thread per output pixel, weights in LDS); false = no instance for that shape.
-// With `heads` (P-Net conv3) the 1x1 heads + softmax run in the same launch: prob [cell], reg [cell][4]; y is not written.
 // a P-Net cell whose face probability reaches the stage-1 threshold: appended (unordered, atomic counter) by the conv3
 // launch so that the host downloads candidates instead of whole probability / regression maps
 struct MtCand { unsigned cell; float p; float r[4]; };
@@ -48,11 +34,12 @@ struct MtPnetHeads {
     unsigned cand_cap;
     float thr;
 };
+// P-Net conv2 / conv3, register-blocked (a thread owns 4 output pixels, weights in LDS); false = no instance for that
+// shape.  With `heads` (conv3) the 1x1 heads + softmax run in the same launch: prob [cell], reg [cell][4], candidates;
+// y is not written.
 bool launch_mt_convpx_ragged(const float* x, const float* w, const float* b, const float* slope, float* y,
                              const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co, int k,
                              const MtPnetHeads* heads, hipStream_t s);
-bool launch_mt_convpx(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int ih, int iw,
-                      int ci, int co, int k, hipStream_t s);
 // P-Net conv1 (3 -> 10) + PReLU + MaxPool2d(2, 2, ceil_mode=True), ragged; items = {input offset, pooled offset, level h, w},
 // pre / total = running totals of pooled elements; w_padded: the [3][3][3][10] weights in a buffer of >= 272 floats
 void launch_mt_pnet_conv1_pool(const float* x, const float* w_padded, const float* b, const float* slope, float* y,
@@ -60,11 +47,7 @@ void launch_mt_pnet_conv1_pool(const float* x, const float* w_padded, const floa
 // conv 3x3 (3 -> 32) + bias + PReLU + MaxPool2d(3, 2, ceil_mode=True) of `n` maps [ih][iw][3] -> [ph][pw][32]
 bool launch_mt_conv1_pool(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int ih, int iw,
                           int co, hipStream_t s);
-void launch_mt_maxpool_ragged(const float* x, float* y, const MtItem* items_dev, const long long* pre_dev, int n, long long total,
-                              int c, int k, int st, hipStream_t s);
 void launch_mt_area_resize_multi(const MtSrcWindow* win_dev, int n, int oh, int ow, float* dst, hipStream_t s);
-// in-place PReLU over NHWC data with `c` channels
-void launch_mt_prelu(float* x, const float* slope, long long n, int c, hipStream_t s);
 // extract_face of every crop of a step: window (x1, y1, cw x ch) of the image at src -> 160 x 160 x 3 (Pillow bilinear,
 // horizontal then vertical pass; coefficient / bounds tables at the given int offsets of one table array); found = 0:
 // the slot is zero-filled.  tmp_off: byte offset of the crop's [ch][160][3] intermediate.

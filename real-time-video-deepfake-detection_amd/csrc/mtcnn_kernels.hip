@@ -1,78 +1,23 @@
 // Kernels of the MTCNN align/crop stage (reference deepfake_detection.py:376-380 calls
-// facenet-pytorch's MTCNN.forward on the cropped face).  The cascade's tensors are tiny (12x12 receptive
-// fields, <= 128 channels, a few hundred candidate windows), so these are plain NHWC fp32 kernels - one thread
-// per output element, weights laid out [ci][ky][kx][co] so that consecutive threads read consecutive
-// addresses - not MFMA tiles: the stage is launch/latency bound, not arithmetic bound.
-//   mt_area_resize    interpolate(mode="area") (= adaptive average pool) of a u8 BGR window -> RGB fp32 NHWC,
-//                     (x - 127.5) * 0.0078125; exact: window sums are integers < 2^24
-//   mt_conv           valid k x k convolution + bias (+ PReLU)
-//   mt_maxpool        MaxPool2d(k, s, ceil_mode=True)
-//   mt_dense          fully connected + bias (+ PReLU)
-//   mt_softmax_face   softmax over the two classes, face probability only
-//   mt_pil_pass       one pass of Pillow's 8-bit fixed-point Image.resize (coefficients from the host)
+// facenet-pytorch's MTCNN.forward on the cropped face).  NHWC fp32, weights laid out [ci][ky][kx][co].  The layers with
+// 3-16 input channels do not fill an MFMA K and run on the VALU, register-blocked; every later convolution and the wide
+// FC layers run on the split-precision MFMA GEMM (gemm_split.hip) from mtcnn_api.hip.
+//   mt_area_resize_ragged / _multi   interpolate(mode="area") (= adaptive average pool) of u8 BGR windows -> RGB fp32,
+//                                    (x - 127.5) * 0.0078125; exact: window sums are integers < 2^24
+//   mt_pnet_conv1_pool               P-Net conv1 + PReLU + MaxPool(2, 2, ceil) over all pyramid levels of all crops
+//   mt_convpx (ragged)               P-Net conv2, conv3 (+ both heads, softmax, candidate compaction)
+//   mt_conv1_pool                    R-/O-Net conv1 + PReLU + MaxPool(3, 2, ceil)
+//   mt_maxpool                       MaxPool2d(k, s, ceil_mode=True) behind the GEMM convolutions
+//   mt_dense, mt_softmax_face        the 2- / 4-wide heads of R-/O-Net
+//   mt_extract_h / _v                extract_face of all crops: Pillow's 8-bit fixed-point Image.resize passes
+// Every convolution accumulates its products as fmaf in (ci, ky, kx) order, then + bias, then PReLU - the order a
+// direct convolution over the weight tensor [co][ci][ky][kx] walks.
 #include "mtcnn_kernels.h"
 #include "kernel_util.h"
 
 #include <cstdlib>
 
 namespace dfd {
-
-__global__ __launch_bounds__(256) void mt_area_resize_kernel(const uint8_t* __restrict__ src, size_t stride,
-                                                             const MtWindow* __restrict__ win, int n, int oh, int ow,
-                                                             float* __restrict__ dst) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)n * oh * ow * 3;
-    if (t >= total) return;
-    const int c = (int)(t % 3);                        // RGB channel of the output
-    const int ox = (int)((t / 3) % ow), oy = (int)((t / 3 / ow) % oh), i = (int)(t / 3 / ow / oh);
-    const MtWindow w = win[i];
-    // adaptive pooling window: [floor(o * in / out), ceil((o + 1) * in / out))
-    const int y0 = (int)(((long long)oy * w.h) / oh), y1 = (int)((((long long)oy + 1) * w.h + oh - 1) / oh);
-    const int x0 = (int)(((long long)ox * w.w) / ow), x1 = (int)((((long long)ox + 1) * w.w + ow - 1) / ow);
-    const uint8_t* p = src + (size_t)w.y * stride + (size_t)w.x * 3 + (2 - c);      // BGR bytes
-    float sum = 0.f;
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) sum += (float)p[(size_t)y * stride + (size_t)x * 3];
-    const float mean = sum / (float)((y1 - y0) * (x1 - x0));
-    dst[t] = (mean - 127.5f) * 0.0078125f;
-}
-
-void launch_mt_area_resize(const uint8_t* src, size_t stride, const MtWindow* win_dev, int n, int oh, int ow, float* dst,
-                           hipStream_t s) {
-    const long long total = (long long)n * oh * ow * 3;
-    if (total <= 0) return;
-    hipLaunchKernelGGL(mt_area_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, stride, win_dev,
-                       n, oh, ow, dst);
-}
-
-__global__ __launch_bounds__(256) void mt_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                      const float* __restrict__ b, const float* __restrict__ slope,
-                                                      float* __restrict__ y, int n, int ih, int iw, int ci, int co, int k) {
-    const int oh = ih - k + 1, ow = iw - k + 1;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)n * oh * ow * co;
-    if (t >= total) return;
-    const int o = (int)(t % co);
-    const int ox = (int)((t / co) % ow), oy = (int)((t / co / ow) % oh), i = (int)(t / co / ow / oh);
-    const float* xp = x + (((size_t)i * ih + oy) * iw + ox) * ci;
-    float acc = 0.f;
-    // accumulation order (ci, ky, kx): the order of the weight tensor [co][ci][ky][kx] a direct convolution walks
-    for (int c = 0; c < ci; ++c)
-        for (int ky = 0; ky < k; ++ky)
-            for (int kx = 0; kx < k; ++kx)
-                acc = fmaf(xp[((size_t)ky * iw + kx) * ci + c], w[(((size_t)c * k + ky) * k + kx) * co + o], acc);
-    acc += b[o];
-    if (slope) acc = acc >= 0.f ? acc : acc * slope[o];
-    y[t] = acc;
-}
-
-void launch_mt_conv(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int ih, int iw,
-                    int ci, int co, int k, hipStream_t s) {
-    const long long total = (long long)n * (ih - k + 1) * (iw - k + 1) * co;
-    if (total <= 0) return;
-    hipLaunchKernelGGL(mt_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, b, slope, y, n, ih, iw,
-                       ci, co, k);
-}
 
 // thread = output pixel x 4 channels (c % 4 == 0: every pooled map of R-/O-Net has 32 or 64 channels; other widths take
 // the scalar path).  Ceil mode: a tap outside the map re-reads the window's first element (a max is idempotent), so
@@ -160,37 +105,6 @@ __global__ __launch_bounds__(256) void mt_softmax_face_kernel(const float* __res
 void launch_mt_softmax_face(const float* z, float* p, long long n, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(mt_softmax_face_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, p, n);
-}
-
-// One pass of ImagingResample (8 bits per channel): out = clip8((2^21 + sum_k coeff[k] * in[xmin + k]) >> 22).
-// horizontal: src window (x0, y0, sw x sh) of a BGR image -> dst [sh][out][3]; vertical: src [sh][sw][3] -> dst [out][sw][3].
-__global__ __launch_bounds__(256) void mt_pil_pass_kernel(const uint8_t* __restrict__ src, size_t stride, int x0, int y0,
-                                                          int sw, int sh, const int* __restrict__ coeff,
-                                                          const int* __restrict__ bounds, int ksize, int out, int vertical,
-                                                          uint8_t* __restrict__ dst) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int rows = vertical ? out : sh, cols = vertical ? sw : out;
-    if (t >= rows * cols * 3) return;
-    const int c = t % 3, col = (t / 3) % cols, row = t / 3 / cols;
-    const int o = vertical ? row : col;
-    const int xmin = bounds[2 * o], cnt = bounds[2 * o + 1];
-    const int* kk = coeff + (size_t)o * ksize;
-    int ss = 1 << 21;
-    for (int k = 0; k < cnt; ++k) {
-        const int yy = vertical ? xmin + k : row, xx = vertical ? col : xmin + k;
-        ss += kk[k] * (int)src[(size_t)(y0 + yy) * stride + (size_t)(x0 + xx) * 3 + c];
-    }
-    int v = ss >> 22;
-    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    dst[t] = (uint8_t)v;
-}
-
-void launch_mt_pil_pass(const uint8_t* src, size_t stride, int x0, int y0, int sw, int sh, const int* coeff_dev,
-                        const int* bounds_dev, int ksize, int out, int vertical, uint8_t* dst, hipStream_t s) {
-    const int total = (vertical ? out * sw : sh * out) * 3;
-    if (total <= 0) return;
-    hipLaunchKernelGGL(mt_pil_pass_kernel, dim3((total + 255) / 256), dim3(256), 0, s, src, stride, x0, y0, sw, sh, coeff_dev,
-                       bounds_dev, ksize, out, vertical, dst);
 }
 
 // extract_face for all crops of a step in two launches (blockIdx.y = crop): the horizontal pass of every crop whose
@@ -307,42 +221,12 @@ void launch_mt_area_resize_ragged(const MtLevel* lv_dev, const long long* pre_de
     hipLaunchKernelGGL(mt_area_resize_ragged_kernel, dim3((unsigned)((total / 3 + 255) / 256)), dim3(256), 0, s, lv_dev, pre_dev, n, dst);
 }
 
-__global__ __launch_bounds__(256) void mt_conv_ragged_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             const float* __restrict__ b, const float* __restrict__ slope,
-                                                             float* __restrict__ y, const MtItem* __restrict__ items,
-                                                             const long long* __restrict__ pre, int n, int ci, int co, int k) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= pre[n]) return;
-    const int i = mt_find(pre, n, t);
-    const MtItem it = items[i];
-    const long long r = t - pre[i];
-    const int ow = it.iw - k + 1;
-    const int o = (int)(r % co), ox = (int)((r / co) % ow), oy = (int)(r / co / ow);
-    const float* xp = x + it.in_off + ((size_t)oy * it.iw + ox) * ci;
-    float acc = 0.f;
-    for (int c = 0; c < ci; ++c)
-        for (int ky = 0; ky < k; ++ky)
-            for (int kx = 0; kx < k; ++kx)
-                acc = fmaf(xp[((size_t)ky * it.iw + kx) * ci + c], w[(((size_t)c * k + ky) * k + kx) * co + o], acc);
-    acc += b[o];
-    if (slope) acc = acc >= 0.f ? acc : acc * slope[o];
-    y[it.out_off + r] = acc;
-}
-
-void launch_mt_conv_ragged(const float* x, const float* w, const float* b, const float* slope, float* y,
-                           const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co, int k,
-                           hipStream_t s) {
-    if (total <= 0) return;
-    hipLaunchKernelGGL(mt_conv_ragged_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, b, slope, y, items_dev,
-                       pre_dev, n, ci, co, k);
-}
-
 // Register-blocked valid convolution, one thread per output pixel (P pixels per thread, all CO channels of each in
 // registers), weights [ci][ky][kx][co] staged once per block in LDS and read as wave-uniform broadcasts.  Replaces the
 // thread-per-output-element kernels above for the layers that carry the cascade's arithmetic (P-Net on every pyramid
 // level of every crop; the 3 -> 32 first convolution of R-/O-Net on every candidate window): those issue two loads
 // per FMA, this one CI*K*K activation loads per CI*K*K*CO FMAs.  Every output still accumulates its products as
-// fmaf in (ci, ky, kx) order, then + bias, then PReLU: bit-identical to mt_conv_kernel / mt_conv_ragged_kernel.
+// fmaf in (ci, ky, kx) order, then + bias, then PReLU (the order of the one-thread-per-output kernel it replaced: same bits).
 //   items != null: ragged launch (pre = running totals of output ELEMENTS, as for the kernels above);
 //   items == null: `n` maps of ih x iw.
 //   HEADS (P-Net conv3, CO = 32): the two 1x1 heads and the softmax are evaluated from the registers - the launch
@@ -487,7 +371,7 @@ __global__ __launch_bounds__(256) void mt_convpx_kernel(const float* __restrict_
 // launch: a thread owns one pooled pixel = the 2x2 convolution pixels under it (no overlap at stride 2: nothing is
 // recomputed), 4 x 10 accumulators, the 4x4x3 input patch in registers, the 270 weights as SGPR operands (sload16s, one
 // group of 16 ahead; `w` must be readable up to 272 floats).  Products accumulate as fmaf in (ci, ky, kx) order, then
-// + bias, PReLU, max over the pixels that exist (ceil mode clips the last row / column): the bits of mt_convpx + the
+// + bias, PReLU, max over the pixels that exist (ceil mode clips the last row / column): the bits of an unfused convolution + the
 // separate pool.  items[i] = {pyramid offset, pooled-map offset (elements), level height, width}; pre = running totals
 // of pooled ELEMENTS (pixels x 10).  The 10-channel conv map (1.4 GB per 256 crops, written and read back) is gone.
 __global__ __launch_bounds__(256) void mt_pnet_conv1_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -578,7 +462,7 @@ void launch_mt_pnet_conv1_pool(const float* x, const float* w_padded, const floa
 // First layer of R-Net / O-Net with its pooling: conv 3x3 (3 -> 32) + bias + PReLU + MaxPool2d(3, 2, ceil_mode) in one
 // launch.  A thread owns one pooled column of one window and walks down the convolution rows: per row it evaluates the
 // three convolution pixels of its pooling window (all 32 channels in registers, products accumulated as fmaf in
-// (ci, ky, kx) order like mt_conv_kernel: the same bits), keeps their maximum, and folds rows 2p, 2p+1, 2p+2 into pooled
+// (ci, ky, kx) order: the bits of an unfused convolution), keeps their maximum, and folds rows 2p, 2p+1, 2p+2 into pooled
 // row p.  The 46x46x32 (22x22x32) map is never stored: 8.5 GB of writes and as many reads per 25k windows gone, for
 // 1.5x the convolution arithmetic (columns 2p+2 / 2p are evaluated by both neighbours).  Weights, bias and slopes are
 // SGPR operands (sload16, one tap ahead): no LDS or VGPR traffic for them.
@@ -716,47 +600,12 @@ bool launch_mt_convpx_ragged(const float* x, const float* w, const float* b, con
                              const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co, int k,
                              const MtPnetHeads* heads, hipStream_t s) {
     const long long npix = total / co;
-    if (ci == 3 && co == 10 && k == 3 && !heads) convpx_launch<3, 10, 3, 4, false>(x, w, b, slope, y, items_dev, pre_dev, n, npix, 0, 0, nullptr, s);
-    else if (ci == 10 && co == 16 && k == 3 && !heads) convpx_launch<10, 16, 3, 4, false>(x, w, b, slope, y, items_dev, pre_dev, n, npix, 0, 0, nullptr, s);
+    if (ci == 10 && co == 16 && k == 3 && !heads) convpx_launch<10, 16, 3, 4, false>(x, w, b, slope, y, items_dev, pre_dev, n, npix, 0, 0, nullptr, s);
     else if (ci == 16 && co == 32 && k == 3 && heads) convpx_launch<16, 32, 3, 4, true>(x, w, b, slope, y, items_dev, pre_dev, n, npix, 0, 0, heads, s);
     else return false;
     return true;
 }
 
-bool launch_mt_convpx(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int ih, int iw,
-                      int ci, int co, int k, hipStream_t s) {
-    const long long npix = (long long)n * (ih - k + 1) * (iw - k + 1);
-    if (ci == 3 && co == 32 && k == 3) convpx_launch<3, 32, 3, 4, false>(x, w, b, slope, y, nullptr, nullptr, n, npix, ih, iw, nullptr, s);
-    else return false;
-    return true;
-}
-
-__global__ __launch_bounds__(256) void mt_maxpool_ragged_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                const MtItem* __restrict__ items, const long long* __restrict__ pre,
-                                                                int n, int c, int k, int st) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= pre[n]) return;
-    const int i = mt_find(pre, n, t);
-    const MtItem it = items[i];
-    const long long r = t - pre[i];
-    int ow = (it.iw - k + st - 1) / st + 1;
-    if ((ow - 1) * st >= it.iw) --ow;
-    const int ch = (int)(r % c), ox = (int)((r / c) % ow), oy = (int)(r / c / ow);
-    float m = -INFINITY;
-    for (int ky = 0; ky < k; ++ky)
-        for (int kx = 0; kx < k; ++kx) {
-            const int yy = oy * st + ky, xx = ox * st + kx;
-            if (yy < it.ih && xx < it.iw) m = fmaxf(m, x[it.in_off + ((size_t)yy * it.iw + xx) * c + ch]);
-        }
-    y[it.out_off + r] = m;
-}
-
-void launch_mt_maxpool_ragged(const float* x, float* y, const MtItem* items_dev, const long long* pre_dev, int n, long long total,
-                              int c, int k, int st, hipStream_t s) {
-    if (total <= 0) return;
-    hipLaunchKernelGGL(mt_maxpool_ragged_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, items_dev, pre_dev, n, c,
-                       k, st);
-}
 
 // windows that live in different images (the crops of a step): per-window source pointer and stride
 __global__ __launch_bounds__(256) void mt_area_resize_multi_kernel(const MtSrcWindow* __restrict__ win, int n, int oh, int ow,
@@ -785,16 +634,5 @@ void launch_mt_area_resize_multi(const MtSrcWindow* win_dev, int n, int oh, int 
     hipLaunchKernelGGL(mt_area_resize_multi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, win_dev, n, oh, ow, dst);
 }
 
-__global__ __launch_bounds__(256) void mt_prelu_kernel(float* __restrict__ x, const float* __restrict__ slope, long long n, int c) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    const float v = x[t];
-    x[t] = v >= 0.f ? v : v * slope[t % c];
-}
-
-void launch_mt_prelu(float* x, const float* slope, long long n, int c, hipStream_t s) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(mt_prelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, slope, n, c);
-}
 
 }  // namespace dfd
