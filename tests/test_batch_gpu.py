@@ -42,3 +42,23 @@ def test_batch_larger_than_classifier_capacity(b0_handle):
     for f in range(6):
         assert np.array_equal(fl[f], b0_handle.classify_crops(frames[f], forced[f], apply_clahe=True).ravel())
     dev.free()
+
+
+@pytest.mark.parametrize("h,w", [(353, 517), (31, 45), (721, 1283)])
+def test_batch_ragged_frame_sizes(b0_handle, h, w):
+    """odd frame geometry (no dimension a multiple of anything, one just above the detector's 30-pixel guard) and crops
+    whose byte size is not a multiple of 4 (the CLAHE kernel's vector path ends in a short group): batch == per-frame"""
+    frames = np.ascontiguousarray(np.stack([F.natural_like(h, w, 70 + i) for i in range(3)]))
+    dev = b0_handle.alloc(frames.nbytes).upload(frames)
+    forced = [[(1, 2, min(w - 2, 37), min(h - 3, 29)), (w // 3, h // 4, min(w - w // 3, 101), min(h - h // 4, 83))]] * 3
+    boxes, logits, fprob = b0_handle.analyze_batch_device(dev.ptr, 3, h, w, forced_boxes=forced, max_faces=2, with_forensics=True)
+    for f in range(3):
+        assert boxes[f] == forced[f]
+        assert np.array_equal(logits[f], b0_handle.classify_crops(frames[f], forced[f], apply_clahe=True).ravel())
+        b0_handle.forensics_reset(961)
+        _, p, _ = b0_handle.forensics(frames[f], True, 961)
+        assert fprob[f] == p
+    free = b0_handle.analyze_batch_device(dev.ptr, 3, h, w, max_faces=3)[0]
+    for f in range(3):
+        assert free[f] == b0_handle.detect_faces(frames[f], 0.5)[:3]
+    dev.free()
