@@ -308,8 +308,10 @@ int dfd_analyze_frames_host(dfd_handle* h, const uint8_t* frames_host, int n_tot
  * and every rank replays temporal score, weighted sum and vote in frame order (host: streams.py).
  *
  * dfd_forensic_signals_device: n packed BGR frames resident in HBM; prev_index[f] = index (inside this batch) of
- * frame f's predecessor or -1.  scores5_out [n][5] = frequency, noise, ela, edge, color (all five computed;
- * the caller drops noise/ela/color on "fast" frames); mean_diff_out [n] = mean |gray - gray_prev| or -1. */
+ * frame f's predecessor, -1 (none), or -2: frame f is itself only a predecessor - it gets a gray plane and no
+ * signals (its outputs are set to -1); such frames must form the tail of the batch.  scores5_out [n][5] =
+ * frequency, noise, ela, edge, color (all five computed; the caller drops noise/ela/color on "fast" frames);
+ * mean_diff_out [n] = mean |gray - gray_prev| or -1. */
 int dfd_forensic_signals_device(dfd_handle* h, const uint8_t* frames_dev, int n, int height, int width,
                                 const int32_t* prev_index, double* scores5_out, double* mean_diff_out);
 

@@ -532,7 +532,8 @@ class Handle:
         return boxes, logits, (fp if with_forensics else None)
 
     def forensic_signals_device(self, frames_dev: int, n: int, height: int, width: int, prev_index):
-        """-> (scores [n][5] = frequency, noise, ela, edge, color; mean_diff [n], -1 where prev_index < 0)"""
+        """-> (scores [n][5] = frequency, noise, ela, edge, color; mean_diff [n], -1 where prev_index < 0).
+        prev_index[f] = -2 marks a frame that is only a predecessor (tail of the batch): no signals, outputs -1."""
         pi = np.ascontiguousarray(np.asarray(prev_index, np.int32).reshape(-1))
         if pi.size != n:
             raise ValueError("prev_index must have one entry per frame")

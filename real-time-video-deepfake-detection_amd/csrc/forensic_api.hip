@@ -252,8 +252,15 @@ int dfd_forensic_signals_device(dfd_handle* h, const uint8_t* frames_dev, int n,
     if (!h) return DFD_ERR_ARG;
     if (!frames_dev || n <= 0 || hh <= 0 || ww <= 0 || !prev_index || !scores5_out || !mean_diff_out)
         return fail(h, DFD_ERR_ARG, "forensic_signals: bad pointer or geometry");
-    for (int f = 0; f < n; ++f)
+    // prev_index[f] = -2: frame f is only somebody's predecessor - it needs a gray plane, no signals.  Such frames
+    // form the tail of the batch (the kernels of the signals run on the leading ns frames).
+    int ns = n;
+    while (ns > 0 && prev_index[ns - 1] == -2) --ns;
+    for (int f = 0; f < n; ++f) {
         if (prev_index[f] >= n) return fail(h, DFD_ERR_ARG, "forensic_signals: prev_index[%d] = %d outside the batch", f, prev_index[f]);
+        if (prev_index[f] < -2 || (prev_index[f] == -2 && f < ns))
+            return fail(h, DFD_ERR_ARG, "forensic_signals: predecessor-only frames (-2) must be the tail of the batch");
+    }
     if (!h->has_color) return fail(h, DFD_ERR_STATE, "forensics needs the colour tables (blob packed without luts)");
     DFD_HIP_TRY(h, hipSetDevice(h->device));
     int rc = state_init(h, n);
@@ -264,16 +271,21 @@ int dfd_forensic_signals_device(dfd_handle* h, const uint8_t* frames_dev, int n,
     const int stride = ww * 3;
     if ((rc = mailbox_h2d(h, F.pair_idx.p, prev_index, (size_t)n * 4))) return rc;
     launch_resize_bgr(frames_dev, n, hh, ww, stride, (size_t)hh * stride, F.buf.rs, 256, 256, h->stream);
-    launch_forensics(F.buf, n, true, h->color, F.twiddle, h->stream);
-    launch_absdiff_pairs(F.buf.gray, (const int*)F.pair_idx.p, (double*)F.pair_part.p, n, h->stream);
-    const double* st = (const double*)mailbox_d2h(h, F.buf.stats, (size_t)n * FORENSIC_STATS * 8);
-    const double* noise = (const double*)mailbox_d2h(h, F.buf.stats_noise, (size_t)n * 64 * 8);
-    const double* ela = (const double*)mailbox_d2h(h, F.buf.stats_ela, (size_t)n * 64 * 8);
-    const double* part = (const double*)mailbox_d2h(h, F.pair_part.p, (size_t)n * 256 * 8);
+    launch_forensics(F.buf, ns, true, h->color, F.twiddle, h->stream, n - ns);
+    if (ns > 0) launch_absdiff_pairs(F.buf.gray, (const int*)F.pair_idx.p, (double*)F.pair_part.p, ns, h->stream);
+    const size_t nz = ns > 0 ? ns : 1;
+    const double* st = (const double*)mailbox_d2h(h, F.buf.stats, nz * FORENSIC_STATS * 8);
+    const double* noise = (const double*)mailbox_d2h(h, F.buf.stats_noise, nz * 64 * 8);
+    const double* ela = (const double*)mailbox_d2h(h, F.buf.stats_ela, nz * 64 * 8);
+    const double* part = (const double*)mailbox_d2h(h, F.pair_part.p, nz * 256 * 8);
     if (!st || !noise || !ela || !part) return fail(h, DFD_ERR_HIP, "forensics: mailbox allocation failed");
     DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
     DFD_HIP_TRY(h, hipGetLastError());
-    for (int f = 0; f < n; ++f) {
+    for (int f = ns; f < n; ++f) {                           // predecessor-only frames: no signals
+        for (int i = 0; i < 5; ++i) scores5_out[(size_t)f * 5 + i] = -1.0;
+        mean_diff_out[f] = -1.0;
+    }
+    for (int f = 0; f < ns; ++f) {
         double sc[6], ex[10];
         static_scores(&st[(size_t)f * FORENSIC_STATS], &noise[(size_t)f * 64], &ela[(size_t)f * 64], true, sc, ex);
         for (int i = 0; i < 5; ++i) scores5_out[(size_t)f * 5 + i] = sc[i];

@@ -32,7 +32,8 @@ struct ForensicBuffers {
 
 size_t forensic_bytes_per_frame();
 void forensic_carve(void* base, int n, ForensicBuffers* out);
-void launch_forensics(const ForensicBuffers& B, int n, bool full, const ColorTables& T, const float2* tw, hipStream_t s);
+void launch_forensics(const ForensicBuffers& B, int n, bool full, const ColorTables& T, const float2* tw, hipStream_t s,
+                      int gray_only = 0);
 void launch_absdiff(const uint8_t* gray, const uint8_t* prev, double* part256, hipStream_t s);
 void launch_absdiff_pairs(const uint8_t* gray, const int* prev_index, double* part /*[n][256]*/, int n, hipStream_t s);
 

@@ -469,8 +469,11 @@ __global__ __launch_bounds__(64) void stats_finalize_kernel(ForensicBuffers B, i
 }
 
 // ------------------------------------------------------------------------------- launchers
-void launch_forensics(const ForensicBuffers& B, int n, bool full, const ColorTables& T, const float2* tw, hipStream_t s) {
-    hipLaunchKernelGGL(gray_kernel, dim3(256, n), dim3(256), 0, s, B.rs, B.gray);
+// n frames get every signal; `gray_only` further frames (behind them in the buffers) only their gray plane
+void launch_forensics(const ForensicBuffers& B, int n, bool full, const ColorTables& T, const float2* tw, hipStream_t s,
+                      int gray_only) {
+    hipLaunchKernelGGL(gray_kernel, dim3(256, n + gray_only), dim3(256), 0, s, B.rs, B.gray);
+    if (n <= 0) return;
     hipLaunchKernelGGL(fft256_kernel, dim3(256, n), dim3(128), 0, s, B.gray, B.fft_tmp, tw);
     hipLaunchKernelGGL(fft_band_kernel, dim3(256, n), dim3(128), 0, s, B.fft_tmp, B.fft_part, tw);
     hipLaunchKernelGGL(sobel_lap_kernel, dim3(256, n), dim3(256), 0, s, B.gray, B.grad, B.lap_part);

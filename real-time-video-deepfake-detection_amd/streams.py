@@ -170,6 +170,7 @@ class ShardedStreams:
             raise ValueError("more frames in a wave than record slots")
         prevs = [i for i, it in enumerate(flat) if it[2]]
         prev_index = np.full(m + len(prevs), -1, np.int32)
+        prev_index[m:] = -2                                   # predecessor-only frames: a gray plane, no signals
         for k, i in enumerate(prevs):
             prev_index[i] = m + k
         boxes, logits, _ = self.h.analyze_batch_device(frames_dev, m, height, width, forced_boxes=None,

@@ -137,3 +137,22 @@ def test_lookahead_batches_give_the_per_wave_records(pkg, b0_handle):
         assert len(multi) == len(single)
         for a, b in zip(single, multi):
             assert np.array_equal(a, b, equal_nan=True), (world, rank)
+
+
+def test_predecessor_only_frames_skip_the_signals_not_the_differences(pkg, b0_handle):
+    """prev_index = -2 marks frames that are only somebody's predecessor: the scored frames get exactly the values of
+    a call that analyses every frame; -2 outside the tail of the batch is an argument error."""
+    h = b0_handle
+    cur = _stream(5, 3)
+    prev = _stream(6, 2)
+    arr = np.stack(cur + prev)
+    fd = h.alloc(arr.nbytes).upload(arr)
+    full_idx = np.array([3, 4, -1, -1, -1], np.int32)
+    lean_idx = np.array([3, 4, -1, -2, -2], np.int32)
+    s_full, d_full = h.forensic_signals_device(fd.ptr, 5, H, W, full_idx)
+    s_lean, d_lean = h.forensic_signals_device(fd.ptr, 5, H, W, lean_idx)
+    assert np.array_equal(s_full[:3], s_lean[:3]) and np.array_equal(d_full[:3], d_lean[:3])
+    assert np.all(s_lean[3:] == -1.0) and np.all(d_lean[3:] == -1.0) and d_lean[0] >= 0 and d_lean[2] == -1.0
+    with pytest.raises(pkg._lib.DfdError):
+        h.forensic_signals_device(fd.ptr, 5, H, W, np.array([3, -2, -1, -1, -1], np.int32))
+    fd.free()
