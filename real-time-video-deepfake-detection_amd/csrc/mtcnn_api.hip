@@ -32,7 +32,7 @@ struct MtcnnState {
     MtConv r1p;                           // R-Net conv1 with 32 output channels (4 zero filters)
     const float* p1w_pad = nullptr;       // P-Net conv1 weights in a 288-float buffer (scalar loads read 16 at a time)
     MtGemmConv r2g, r3g, o2g, o3g, o4g;
-    DevBuf in, a0, a1, z, prob, reg, win, coef, bnd, tmp, face, d_lv, d_items, d_pre, bs, cand;
+    DevBuf in, a0, a1, prob, reg, win, coef, bnd, tmp, face, d_lv, d_items, d_pre, bs, cand;
 };
 
 void mtcnn_destroy(dfd_handle* h) {
@@ -332,9 +332,10 @@ struct Cascade {
         int rc;
         std::vector<Level> levels;
         std::vector<MtLevel> lv;
-        // per layer: items + running totals of output elements (arena offsets are the same running totals)
-        std::vector<MtItem> it_c1, it_p, it_c2, it_c3, it_z, it_r, it_f;
-        std::vector<long long> pre_in{0}, pre_c1{0}, pre_p{0}, pre_c2{0}, pre_c3{0}, pre_z{0}, pre_r{0};
+        // per launch: items + running totals of output elements (arena offsets are the same running totals):
+        //   pyramid (resize) -> pooled conv1 map (conv1 + PReLU + pool) -> conv2 map -> conv3 cells (heads only)
+        std::vector<MtItem> it_f, it_c2, it_c3;
+        std::vector<long long> pre_in{0}, pre_p{0}, pre_c2{0}, pre_c3{0};
         long long cells = 0;
         for (int c = 0; c < n; ++c) {
             const int hh = imgs[c].h, ww = imgs[c].w;
@@ -346,20 +347,13 @@ struct Cascade {
                 const int c2h = ph - 2, c2w = pw - 2, c3h = c2h - 2, c3w = c2w - 2;
                 levels.push_back(Level{c, scale_i, sh, sw, c3h, c3w, cells});
                 lv.push_back(MtLevel{imgs[c].src, (long long)imgs[c].stride, hh, ww, sh, sw, pre_in.back()});
-                it_c1.push_back(MtItem{pre_in.back(), pre_c1.back(), sh, sw});
-                it_p.push_back(MtItem{pre_c1.back(), pre_p.back(), c1h, c1w});
-                it_f.push_back(MtItem{pre_in.back(), pre_p.back(), sh, sw});           // conv1 + pool fused: pyramid -> pooled map
+                it_f.push_back(MtItem{pre_in.back(), pre_p.back(), sh, sw});            // conv1 + pool: pyramid -> pooled map
                 it_c2.push_back(MtItem{pre_p.back(), pre_c2.back(), ph, pw});
                 it_c3.push_back(MtItem{pre_c2.back(), pre_c3.back(), c2h, c2w});
-                it_z.push_back(MtItem{pre_c3.back(), pre_z.back(), c3h, c3w});
-                it_r.push_back(MtItem{pre_c3.back(), pre_r.back(), c3h, c3w});
                 pre_in.push_back(pre_in.back() + (long long)sh * sw * 3);
-                pre_c1.push_back(pre_c1.back() + (long long)c1h * c1w * 10);
                 pre_p.push_back(pre_p.back() + (long long)ph * pw * 10);
                 pre_c2.push_back(pre_c2.back() + (long long)c2h * c2w * 16);
                 pre_c3.push_back(pre_c3.back() + (long long)c3h * c3w * 32);
-                pre_z.push_back(pre_z.back() + (long long)c3h * c3w * 2);
-                pre_r.push_back(pre_r.back() + (long long)c3h * c3w * 4);
                 cells += (long long)c3h * c3w;
                 scale_i *= 0.709;
                 minl *= 0.709;
@@ -371,12 +365,12 @@ struct Cascade {
         std::vector<float> prob, reg;
         std::vector<MtCand> cands;
         if (nl) {
-            // descriptors: one upload each (pageable source: staged before the call returns)
+            // descriptors through the mailbox (copied before the call returns)
             if ((rc = upload(&S->d_lv, lv))) return rc;
             std::vector<MtItem> items;
             std::vector<long long> pres;
-            const std::vector<MtItem>* its[7] = {&it_c1, &it_p, &it_c2, &it_c3, &it_z, &it_r, &it_f};
-            const std::vector<long long>* prs[7] = {&pre_in, &pre_c1, &pre_p, &pre_c2, &pre_c3, &pre_z, &pre_r};
+            const std::vector<MtItem>* its[3] = {&it_f, &it_c2, &it_c3};
+            const std::vector<long long>* prs[4] = {&pre_in, &pre_p, &pre_c2, &pre_c3};
             for (auto* v : its) items.insert(items.end(), v->begin(), v->end());
             for (auto* v : prs) pres.insert(pres.end(), v->begin(), v->end());
             if ((rc = upload(&S->d_items, items))) return rc;
@@ -386,27 +380,26 @@ struct Cascade {
             auto item_at = [&](int k) { return di + (size_t)k * nl; };
             auto pre_at = [&](int k) { return dp + (size_t)k * (nl + 1); };
             if ((rc = ensure(h, &S->in, pre_in.back() * 4))) return rc;
-            if ((rc = ensure(h, &S->a0, std::max(pre_c1.back(), pre_c2.back()) * 4))) return rc;
-            if ((rc = ensure(h, &S->a1, std::max(std::max(pre_p.back(), pre_c3.back()), (long long)4) * 4))) return rc;
-            if ((rc = ensure(h, &S->z, pre_z.back() * 4))) return rc;
+            if ((rc = ensure(h, &S->a0, std::max(pre_c2.back(), (long long)4) * 4))) return rc;
+            if ((rc = ensure(h, &S->a1, std::max(pre_p.back(), (long long)4) * 4))) return rc;
             if ((rc = ensure(h, &S->prob, cells * 4))) return rc;
-            if ((rc = ensure(h, &S->reg, pre_r.back() * 4))) return rc;
+            if ((rc = ensure(h, &S->reg, cells * 16))) return rc;
             float *in = (float*)S->in.p, *a0 = (float*)S->a0.p, *a1 = (float*)S->a1.p;
             launch_mt_area_resize_ragged((const MtLevel*)S->d_lv.p, pre_at(0), nl, pre_in.back(), in, s);
-            // P-Net: register-blocked convolutions; conv3 evaluates both 1x1 heads and the softmax from its registers
-            // (prob [cell], reg [cell][4]; the 32-channel map is never stored)
-            // 16 bytes of counter, then the records
+            // candidate list: 16 bytes of counter, then the records
             if ((rc = ensure(h, &S->cand, 16 + (size_t)cells * sizeof(MtCand)))) return rc;
             unsigned* d_count = (unsigned*)S->cand.p;
             MtCand* d_cand = (MtCand*)((char*)S->cand.p + 16);
             DFD_HIP_TRY(h, hipMemsetAsync(d_count, 0, 16, s));
             const MtPnetHeads heads{S->p41.w, S->p41.b, S->p42.w, S->p42.b, (float*)S->prob.p, (float*)S->reg.p,
                                     d_cand, d_count, (unsigned)cells, 0.6f};                  // thresholds[0], >=, float32
-            // conv1 + PReLU + pool in one launch (the 10-channel conv map is never stored), then conv2, then conv3 + heads
-            launch_mt_pnet_conv1_pool(in, S->p1w_pad, S->p1.b, S->p1.a, a1, item_at(6), pre_at(2), nl, pre_p.back(), s);
+            // conv1 + PReLU + pool in one launch (the 10-channel conv map is never stored), conv2, then conv3 with both
+            // 1x1 heads and the softmax evaluated from its registers (prob [cell], reg [cell][4], candidates; the
+            // 32-channel map is never stored either)
+            launch_mt_pnet_conv1_pool(in, S->p1w_pad, S->p1.b, S->p1.a, a1, item_at(0), pre_at(1), nl, pre_p.back(), s);
             bool ok = true;
-            ok = ok && launch_mt_convpx_ragged(a1, S->p2.w, S->p2.b, S->p2.a, a0, item_at(2), pre_at(3), nl, pre_c2.back(), 10, 16, 3, nullptr, s);
-            ok = ok && launch_mt_convpx_ragged(a0, S->p3.w, S->p3.b, S->p3.a, nullptr, item_at(3), pre_at(4), nl, pre_c3.back(), 16, 32, 3, &heads, s);
+            ok = ok && launch_mt_convpx_ragged(a1, S->p2.w, S->p2.b, S->p2.a, a0, item_at(1), pre_at(2), nl, pre_c2.back(), 10, 16, 3, nullptr, s);
+            ok = ok && launch_mt_convpx_ragged(a0, S->p3.w, S->p3.b, S->p3.a, nullptr, item_at(2), pre_at(3), nl, pre_c3.back(), 16, 32, 3, &heads, s);
             if (!ok) return fail(h, DFD_ERR_STATE, "mtcnn: no P-Net kernel instance for this layer shape");
             DFD_HIP_TRY(h, hipGetLastError());
             // the candidates (cells at or above the threshold), not the maps: count first, then that many records, both
