@@ -328,8 +328,8 @@ __global__ __launch_bounds__(256) void mt_convpx_kernel(const float* __restrict_
             if (slope) v = v >= 0.f ? v : v * slope[o];
             acc[p][o] = v;
         }
-        if (!ok[p]) continue;
-        if (HEADS) {
+        if (!HEADS && !ok[p]) continue;
+        if (HEADS) {                                        // (every lane runs this block: the append below uses a ballot)
             const float* h41 = sw + NW;
             const float* h42 = sw + NW + CO * 2;
             float z[2] = {0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -344,14 +344,24 @@ __global__ __launch_bounds__(256) void mt_convpx_kernel(const float* __restrict_
             const float m = fmaxf(z0, z1);
             const float e0 = expf(z0 - m), e1 = expf(z1 - m);
             const float pf = e1 / (e0 + e1);
-            prob[opix[p]] = pf;
             float4 rv;
             rv.x = r4[0] + sw[NW + CO * 6 + 2]; rv.y = r4[1] + sw[NW + CO * 6 + 3];
             rv.z = r4[2] + sw[NW + CO * 6 + 4]; rv.w = r4[3] + sw[NW + CO * 6 + 5];
-            *reinterpret_cast<float4*>(reg + opix[p] * 4) = rv;
-            if (cand && pf >= thr) {
-                const unsigned slot = atomicAdd(cand_count, 1u);
-                if (slot < cand_cap) cand[slot] = MtCand{(unsigned)opix[p], pf, {rv.x, rv.y, rv.z, rv.w}};
+            if (ok[p]) {
+                prob[opix[p]] = pf;
+                *reinterpret_cast<float4*>(reg + opix[p] * 4) = rv;
+            }
+            // one atomic per wave: the lanes that pass take consecutive slots behind the wave's base (with a dense
+            // funnel tens of thousands of per-lane atomics on one counter held this kernel at 0.7 of its cycles waiting)
+            const bool pass = cand && ok[p] && pf >= thr;
+            const unsigned long long mask = __ballot(pass);
+            if (mask) {
+                const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(cand_count, (unsigned)__popcll(mask));
+                base = __shfl(base, leader);
+                const unsigned slot = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                if (pass && slot < cand_cap) cand[slot] = MtCand{(unsigned)opix[p], pf, {rv.x, rv.y, rv.z, rv.w}};
             }
         } else {
             float* yp = y + opix[p] * CO;
