@@ -237,8 +237,10 @@ def e2e_mtcnn(frames, boxes, K):
     handles = {}
     # (key, option "mtcnn", head-bias recipe, frames per call): the 8-frame rows are per-call latency figures (every stage
     # of a call runs at a small batch), the 64-frame rows the batched throughput of the same path
+    # "..._forensics": every stage of the reference's per-frame flow on (detect, CLAHE, MTCNN, classify, six signals)
     for key, flag, bias, n in (("mtcnn_on", 1, None, 8), ("mtcnn_off", 0, None, 8), ("mtcnn_on_selective", 1, W.MTCNN_SELECTIVE, 8),
                                ("mtcnn_on_selective_64", 1, W.MTCNN_SELECTIVE, len(frames)),
+                               ("mtcnn_on_selective_64_forensics", 1, W.MTCNN_SELECTIVE, len(frames)),
                                ("mtcnn_off_64", 0, W.MTCNN_SELECTIVE, len(frames))):
         tag = "sel" if bias else "dense"
         if tag not in handles:
@@ -250,11 +252,12 @@ def e2e_mtcnn(frames, boxes, K):
         h, fd = handles[tag]
         h.set_option("mtcnn", flag)
         bx = boxes[:n]
-        h.analyze_batch_device(fd.ptr, n, H, Wd, forced_boxes=bx, max_faces=K, with_forensics=False)
+        wf = key.endswith("_forensics")
+        h.analyze_batch_device(fd.ptr, n, H, Wd, forced_boxes=bx, max_faces=K, with_forensics=wf)
         h.sync()
         t0 = time.perf_counter()
         for _ in range(2):
-            res = h.analyze_batch_device(fd.ptr, n, H, Wd, forced_boxes=bx, max_faces=K, with_forensics=False)
+            res = h.analyze_batch_device(fd.ptr, n, H, Wd, forced_boxes=bx, max_faces=K, with_forensics=wf)
         h.sync()
         dt = (time.perf_counter() - t0) / 2
         flat = np.concatenate([np.asarray(l, np.float32).reshape(-1) for l in res[1]]) if len(res[1]) else np.zeros(0)
