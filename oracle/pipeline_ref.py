@@ -18,19 +18,32 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import b0_ref, imgproc_ref, mtcnn_ref, ssd_ref
+from . import b0_ref, haar_ref, imgproc_ref, mtcnn_ref, ssd_ref
 from .forensics_ref import ForensicsRef
 from .tracker_ref import TrackerRef
 
 
 class PredictRef:
-    def __init__(self, b0_sd, ssd_sd, ssd_arch, detection_threshold=0.5, mtcnn_sd=None):
+    def __init__(self, b0_sd, ssd_sd, ssd_arch, detection_threshold=0.5, mtcnn_sd=None, haar_cascade=None):
         self.b0_sd, self.ssd_sd, self.arch, self.mtcnn_sd = b0_sd, ssd_sd, ssd_arch, mtcnn_sd
+        self.haar_cascade = haar_cascade
         self.tracker = TrackerRef(window_size=60, high_confidence_threshold=0.6, voting_window=10,
                                   detection_threshold=detection_threshold)
         self.analyzer = ForensicsRef()
         self.frame_count = 0
         self.full_forensic_interval = 3
+
+    def detect(self, frame):
+        """reference face_detection.py:37-68: the DNN when its model files were loaded, the Haar cascade otherwise
+        (:58-61; the shipped configuration); [] for empty / tiny frames."""
+        if self.ssd_sd is not None:
+            return ssd_ref.detect_bounding_box(self.ssd_sd, self.arch, frame)
+        if frame is None or frame.size == 0 or frame.ndim < 2 or frame.shape[0] < 30 or frame.shape[1] < 30:
+            return []
+        if self.haar_cascade is None:
+            return []
+        boxes, _ = haar_ref.detect(frame, self.haar_cascade)         # :108-123 (1.1, 5, 30x30)
+        return [tuple(int(v) for v in b) for b in boxes]
 
     def forensics(self, frame):                                     # :504-515
         if self.frame_count % self.full_forensic_interval == 0:
@@ -53,7 +66,7 @@ class PredictRef:
     def predict(self, frame):
         self.frame_count += 1
         forensic = self.forensics(frame)
-        faces = ssd_ref.detect_bounding_box(self.ssd_sd, self.arch, frame)
+        faces = self.detect(frame)
         face_results, level = [], None          # None = the reference's local is unassigned (it raises at :679 when
         # faces were detected and every analyze_face returned None)
         if len(faces) > 0:
@@ -78,7 +91,7 @@ class PredictRef:
     def request(self, frame):
         forensic = self.forensics(frame)
         fprob = forensic['fake_probability']
-        faces = ssd_ref.detect_bounding_box(self.ssd_sd, self.arch, frame)
+        faces = self.detect(frame)
         self.frame_count += 1
         if len(faces) > 0:
             x, y, w, h = faces[0]

@@ -32,6 +32,9 @@ logging.basicConfig(level=logging.INFO, format='%(asctime)s [%(levelname)s] %(me
 logger = logging.getLogger(__name__)
 
 app = Flask(__name__)
+# cv2.imdecode has no request-size notion; Flask would buffer any body.  32 MiB holds a 4K PNG or a 32-frame JPEG batch.
+app.config['MAX_CONTENT_LENGTH'] = 32 << 20
+MAX_BATCH_FRAMES = 32                     # /analyze_batch: frames per request (one lock hold, one device batch)
 
 
 @app.after_request
@@ -95,7 +98,9 @@ def health_check():
     """reference :82-99"""
     name = _gpu_name()
     h = runtime.peek_default_handle()
-    has_det = bool(h.has_detector) if h is not None else bool(runtime.detector_loaded or runtime.detector_synthetic)
+    # reference :93: face detection is the DNN or its Haar fallback (face_detection.py:58-61)
+    has_det = bool(h.has_detector or h.has_haar) if h is not None else bool(
+        runtime.detector_loaded or runtime.detector_synthetic or runtime.haar_loaded)
     # the reference's keys (:84-99) plus what was actually loaded: without trained weights the verdicts mean nothing
     return jsonify({'status': 'healthy', 'model_loaded': bool(runtime.model_loaded), 'detector_loaded': bool(runtime.detector_loaded),
                     'mtcnn_loaded': bool(runtime.mtcnn_loaded), 'synthetic_weights': bool(runtime.detector_synthetic),
@@ -154,6 +159,7 @@ def analyze_frame():
 
 
 @app.route('/analyze_batch', methods=['POST'])
+@rate_limit
 def analyze_batch():
     """Several consecutive frames of ONE stream in a single request (multipart parts all named ``frame``, in stream
     order): the same per-frame flow and vote order as /analyze, one JSON object per frame under ``results``.  Not in the
@@ -164,6 +170,8 @@ def analyze_batch():
         files = request.files.getlist('frame')
         if not files:
             return jsonify({'error': 'No frame provided'}), 400
+        if len(files) > MAX_BATCH_FRAMES:
+            return jsonify({'error': f'Too many frames in one request ({len(files)} > {MAX_BATCH_FRAMES})'}), 400
         results = []
         with _detector_lock:
             for f in files:

@@ -160,6 +160,9 @@ int forensics_run(dfd_handle* h, int stream_id, const uint8_t* frame_dev, int hh
                   double* scores_out, double* prob_out, double* stats_out);
 int detect_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, float conf_thr, int32_t* xywh_out,
                float* conf_out, int max_out, int* n_out);
+// haar_api.hip: detectMultiScale + groupRectangles on a resident frame; *n_total = groups before the max_out cut
+int haar_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, float scale_factor, int min_neighbors,
+             int min_size, int32_t* xywh_out, int max_out, int* n_out, int* n_candidates, int* n_total = nullptr);
 // frame_offs: per-crop byte offset of its frame inside frame_dev (null = single frame)
 int preprocess_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, const int32_t* xywh, int n,
                    int apply_clahe, const size_t* frame_offs = nullptr);

@@ -237,13 +237,32 @@ int dfd_detect_faces_haar(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int
         return fail(h, DFD_ERR_ARG, "detect_faces_haar: bad pointer, geometry or scale factor");
     *n_out = 0;
     if (n_candidates) *n_candidates = 0;
+    if (!h->haar) return fail(h, DFD_ERR_STATE, "no Haar cascade in the weights blob (weights.pack_all(..., haar=...))");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, &h->frame_buf, (size_t)hh * stride))) return rc;
+    DFD_HIP_TRY(h, hipMemcpyAsync(h->frame_buf.p, bgr, (size_t)hh * stride, hipMemcpyHostToDevice, h->stream));
+    return haar_run(h, (const uint8_t*)h->frame_buf.p, hh, ww, stride, scale_factor, min_neighbors, min_size, xywh_out, max_out,
+                    n_out, n_candidates);
+}
+
+}  // extern "C"
+
+namespace dfd {
+
+// detectMultiScale + groupRectangles on a frame already resident in HBM (the fallback inside dfd_analyze_frame /
+// dfd_analyze_jpeg when the handle has no SSD or the SSD pass failed: reference face_detection.py:58-66).
+// *n_total (optional) = number of grouped rectangles before max_out cut the list.
+int haar_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, float scale_factor, int min_neighbors,
+             int min_size, int32_t* xywh_out, int max_out, int* n_out, int* n_candidates, int* n_total) {
+    *n_out = 0;
+    if (n_candidates) *n_candidates = 0;
+    if (n_total) *n_total = 0;
     HaarState* S = h->haar;
     if (!S) return fail(h, DFD_ERR_STATE, "no Haar cascade in the weights blob (weights.pack_all(..., haar=...))");
-    DFD_HIP_TRY(h, hipSetDevice(h->device));
     int rc;
     const size_t npix = (size_t)hh * ww;
     constexpr int CAP = 1 << 16;
-    if ((rc = ensure(h, &h->frame_buf, (size_t)hh * stride))) return rc;
     if ((rc = ensure(h, &S->gray, npix))) return rc;
     if ((rc = ensure(h, &S->scaled, npix))) return rc;
     if ((rc = ensure(h, &S->sum, (size_t)(hh + 1) * (ww + 1) * 4))) return rc;
@@ -252,8 +271,7 @@ int dfd_detect_faces_haar(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int
     if ((rc = ensure(h, &S->cand, (size_t)CAP * 12))) return rc;
     if ((rc = ensure(h, &S->count, 4))) return rc;
     hipStream_t s = h->stream;
-    DFD_HIP_TRY(h, hipMemcpyAsync(h->frame_buf.p, bgr, (size_t)hh * stride, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(haar_gray_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, (const uint8_t*)h->frame_buf.p, ww,
+    hipLaunchKernelGGL(haar_gray_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, frame_dev, ww,
                        stride, (uint8_t*)S->gray.p, (long long)npix);
     DFD_HIP_TRY(h, hipMemsetAsync(S->count.p, 0, 4, s));
     std::vector<double> factors;
@@ -304,7 +322,8 @@ int dfd_detect_faces_haar(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int
         ++k;
     }
     *n_out = k;
+    if (n_total) *n_total = (int)out.size();
     return DFD_OK;
 }
 
-}  // extern "C"
+}  // namespace dfd

@@ -257,9 +257,16 @@ int analyze_frame_resident(dfd_handle* h, int stream_id, int hh, int ww, int str
     const uint8_t* fd = (const uint8_t*)h->frame_buf.p;
     if ((rc = forensics_run(h, stream_id, fd, hh, ww, stride, full_forensics, scores_out, forensic_prob_out, nullptr))) return rc;
     *n_faces_out = 0;
-    if (!h->ssd || hh < 30 || ww < 30) return DFD_OK;              // no detector weights / tiny frame: no faces
+    h->last_detections = 0;
+    if ((!h->ssd && !h->haar) || hh < 30 || ww < 30) return DFD_OK;  // no detector at all / tiny frame: no faces
     int n = 0;
-    if ((rc = detect_run(h, fd, hh, ww, stride, conf_thr, xywh_out, nullptr, max_faces, &n))) return rc;
+    // reference face_detection.py:58-66: the DNN when its files were loaded, the Haar cascade otherwise - and after
+    // a DNN failure (detectMultiScale(gray, 1.1, 5, minSize 30x30), :115-121)
+    rc = h->ssd ? detect_run(h, fd, hh, ww, stride, conf_thr, xywh_out, nullptr, max_faces, &n) : DFD_ERR_STATE;
+    if (rc) {
+        if (!h->haar) return rc;
+        if ((rc = haar_run(h, fd, hh, ww, stride, 1.1f, 5, 30, xywh_out, max_faces, &n, nullptr, &h->last_detections))) return rc;
+    }
     *n_faces_out = n;
     // every returned face is classified, in chunks of the handle's batch capacity (predict votes on all detections,
     // reference deepfake_detection.py:611-626; dfd_last_detection_count gives len(faces) when max_faces cut the list)

@@ -13,6 +13,7 @@
 // Anything else (progressive, arithmetic, CMYK, 12-bit, multi-scan) returns DFD_ERR_UNSUPPORTED and the host
 // keeps its own decoder for it (backend_server.decode_image).
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "dfd_common.h"
@@ -26,16 +27,24 @@ const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18,
                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+constexpr size_t kMaxJpegPixels = (size_t)1 << 26;       // 8192 x 8192: 0.4 GB of coefficients at 4:4:4
+
 struct HuffTable {
     bool present = false;
     uint8_t vals[256];
     int maxcode[18], valptr[17], mincode[17];
     uint16_t look[512];                       // 9-bit lookahead: (length << 8) | symbol, 0 = longer code
-    void build(const uint8_t* bits, const uint8_t* v, int nvals) {
+    // false: the code lengths over-subscribe the code space (jdhuff.c's "code >= 1 << si" check, the Kraft
+    // inequality) - such a table would index past look[] here and below vals[0] in huff_decode
+    bool build(const uint8_t* bits, const uint8_t* v, int nvals) {
+        present = false;
+        if (nvals < 0 || nvals > 256) return false;
+        memset(vals, 0, sizeof vals);
         memcpy(vals, v, (size_t)nvals);
         int code = 0, k = 0;
         memset(look, 0, sizeof look);
         for (int l = 1; l <= 16; ++l) {
+            if (code + (int)bits[l] > (1 << l)) return false;
             valptr[l] = k;
             mincode[l] = code;
             for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
@@ -49,6 +58,7 @@ struct HuffTable {
         }
         maxcode[17] = 0x7fffffff;
         present = true;
+        return true;
     }
 };
 
@@ -87,7 +97,11 @@ inline int huff_decode(BitReader& br, const HuffTable& t) {
     int code = br.peek(16), l = 10;
     for (; l <= 16; ++l) {
         const int c = code >> (16 - l);
-        if (c <= t.maxcode[l]) { br.skip(l); return t.vals[t.valptr[l] + c - t.mincode[l]]; }
+        if (c <= t.maxcode[l]) {
+            const int idx = t.valptr[l] + c - t.mincode[l];
+            br.skip(l);
+            return (idx >= 0 && idx < 256) ? t.vals[idx] : -1;
+        }
     }
     br.skip(16);
     return -1;                                                     // corrupt stream
@@ -146,7 +160,8 @@ int parse_headers(dfd_handle* h, const uint8_t* d, size_t len, Parsed* P) {
                 int total = 0;
                 for (int l = 1; l <= 16; ++l) { bits[l] = s[i + l]; total += bits[l]; }
                 if (tc > 1 || th > 3 || total > 256 || i + 17 + total > n) return fail(h, DFD_ERR_ARG, "decode_jpeg: bad DHT");
-                (tc ? P->ac[th] : P->dc[th]).build(bits, s + i + 17, total);
+                if (!(tc ? P->ac[th] : P->dc[th]).build(bits, s + i + 17, total))
+                    return fail(h, DFD_ERR_ARG, "decode_jpeg: bad DHT (code lengths over-subscribed)");
                 i += 17 + total;
             }
         } else if (m == 0xC0 || m == 0xC1) {                       // SOF0 / SOF1: sequential Huffman
@@ -156,6 +171,11 @@ int parse_headers(dfd_handle* h, const uint8_t* d, size_t len, Parsed* P) {
             P->ncomp = s[5];
             if (P->ncomp != 1 && P->ncomp != 3) return fail(h, DFD_ERR_UNSUPPORTED, "decode_jpeg: %d components", P->ncomp);
             if (n < 6 + 3 * P->ncomp || P->width <= 0 || P->height <= 0) return fail(h, DFD_ERR_ARG, "decode_jpeg: bad SOF");
+            // cv2.imdecode is capped by CV_IO_MAX_IMAGE_PIXELS (2^30) and Pillow by MAX_IMAGE_PIXELS; here a header
+            // alone would make decode_scan allocate width x height coefficients, so the cap comes first
+            if ((size_t)P->width * (size_t)P->height > kMaxJpegPixels)
+                return fail(h, DFD_ERR_UNSUPPORTED, "decode_jpeg: %d x %d exceeds the %zu-pixel limit of the GPU path", P->width,
+                            P->height, kMaxJpegPixels);
             for (int c = 0; c < P->ncomp; ++c) {
                 Component& C = P->comp[c];
                 C.id = s[6 + 3 * c];
@@ -214,7 +234,11 @@ int decode_scan(dfd_handle* h, Parsed* P, std::vector<int16_t>* coef, size_t* co
         comp_off[c] = total;
         total += (size_t)C.bw * C.bh * 64;
     }
-    coef->assign(total, 0);
+    try {
+        coef->assign(total, 0);
+    } catch (const std::bad_alloc&) {                              // never unwinds through the C ABI
+        return fail(h, DFD_ERR_CAPACITY, "decode_jpeg: %zu coefficients do not fit in host memory", total);
+    }
     BitReader br{P->scan, P->end};
     int pred[3] = {0, 0, 0};
     int until_restart = P->restart;

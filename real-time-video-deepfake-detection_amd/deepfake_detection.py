@@ -8,8 +8,11 @@ does forensics, face detection, crop -> CLAHE -> 224x224 -> EfficientNet-B0 in O
 the reference.  The MTCNN align/crop of reference :376-380 runs inside the same library call when the handle's
 weights carry the cascade (`mtcnn` below is its module-level mirror); a crop in which it finds no face yields no
 prediction, exactly as the reference's `None` (:378-380, :616-617, backend_server.py:166).  Deliberate differences
-(DESIGN.md section 8): TTA and GradCAM are not implemented (both are disabled in the reference's shipped configurations,
-:730-736 and backend_server.py:57), frames are returned un-annotated, nothing is printed per frame.
+(DESIGN.md section 8): GradCAM is not implemented (disabled in the reference's shipped configurations, :730-736 and
+backend_server.py:57), frames are returned un-annotated, nothing is printed per frame.  TTA (:408-443) is
+`analyze_face_with_tta` over `dfd_tta_augment`.  Face detection inside the fused call follows the reference's
+`detect_bounding_box` (face_detection.py:58-66): the SSD when the handle carries one, else - and after an SSD failure -
+the Haar cascade, else no faces ('frame_only').
 """
 from __future__ import annotations
 
@@ -216,10 +219,11 @@ class DeepfakeDetector:
                             'analysis_type': 'frame_forensic' if full else 'frame_forensic_fast', 'frame_number': number}
                 self.last_frame_forensic_result = forensic
                 return forensic, boxes, logits, shape
-            if self.handle.has_detector:
+            if self.handle.has_detector or self.handle.has_haar:
+                # SSD, or the reference's Haar fallback (face_detection.py:58-61), inside the same library call
                 scores, prob, boxes, logits = self.handle.analyze_frame(
                     frame, full, stream_id=self.frame_analyzer.stream_id, confidence_threshold=0.5, max_faces=max_faces)
-            else:                                   # no detector weights: 'frame_only' mode (runtime.py)
+            else:                                   # no detector of either kind: 'frame_only' mode (runtime.py)
                 scores, prob, _ = self.handle.forensics(frame, full=full, stream_id=self.frame_analyzer.stream_id)
                 boxes, logits = [], []
             number = self.frame_analyzer.frame_count
@@ -279,7 +283,7 @@ class DeepfakeDetector:
         dict without timing.  `jpeg`: the request's bytes, decoded on the device; raises
         DfdError (code -7 / -1) when the library does not decode that file - the caller then passes a frame."""
         if jpeg is not None:
-            if not self.handle.has_detector:
+            if not (self.handle.has_detector or self.handle.has_haar):
                 frame = self.handle.decode_jpeg(jpeg)              # frame_only mode has no fused JPEG entry point
                 jpeg = None
             else:

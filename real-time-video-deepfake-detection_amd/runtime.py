@@ -40,6 +40,7 @@ model_loaded = False          # True when a trained classifier checkpoint was fo
 detector_loaded = False       # True when real detector weights were loaded ($DFD_SSD_WEIGHTS)
 mtcnn_loaded = False          # True when real MTCNN weights were loaded ($DFD_MTCNN_WEIGHTS)
 detector_synthetic = False    # seeded stand-ins in use (DFD_SYNTHETIC_WEIGHTS=1)
+haar_loaded = False           # True when a Haar cascade XML was loaded ($DFD_HAAR_CASCADE)
 
 
 def device_index() -> int:
@@ -84,7 +85,7 @@ def _load_state_dict(path: str) -> Dict[str, np.ndarray]:
 
 
 def default_handle() -> Handle:
-    global _default, detector_loaded, mtcnn_loaded, detector_synthetic
+    global _default, detector_loaded, mtcnn_loaded, detector_synthetic, haar_loaded
     with _lock:
         if _default is None:
             seed = int(os.environ.get("DFD_SEED", "0"))
@@ -100,8 +101,8 @@ def default_handle() -> Handle:
                 detector_synthetic = True
                 log.warning("DFD_SYNTHETIC_WEIGHTS=1: random-init detector weights - face boxes are meaningless")
             else:
-                log.warning("no detector weights ($DFD_SSD_WEIGHTS): no face detection, every frame is analysed in "
-                            "'frame_only' mode")
+                log.warning("no detector weights ($DFD_SSD_WEIGHTS): faces come from the Haar cascade if $DFD_HAAR_CASCADE "
+                            "is set, else every frame is analysed in 'frame_only' mode")
             mt = None
             if os.environ.get("DFD_MTCNN", "1") != "0":
                 d = os.environ.get("DFD_MTCNN_WEIGHTS")
@@ -119,6 +120,7 @@ def default_handle() -> Handle:
                 from . import haar
 
                 hc = haar.load_cascade_xml(cascade)
+                haar_loaded = True
                 log.info("loaded Haar cascade %s (fallback detector)", cascade)
             _default = Handle(W.pack_all(default_state_dict(), ssd, mt, ssd_arch=ssd_arch, haar=hc), device=device_index(),
                               max_batch=int(os.environ.get("DFD_MAX_BATCH", "16")))

@@ -119,3 +119,89 @@ def test_host_falls_back_to_haar_without_ssd(pkg, haar_handle):
     want, _ = haar_ref.detect(frame, cas)
     assert pkg.face_detection.detect_bounding_box(frame, handle=h) == [tuple(int(v) for v in b) for b in want]
     assert pkg.face_detection.detect_bounding_box(np.zeros((10, 10, 3), np.uint8), handle=h) == []
+
+
+def _haar_stream():
+    """planted blobs of several sizes, a noise-only frame (no detection -> 'frame_only'), a tiny frame"""
+    return [_frame(480, 640, [(150, 120, 20), (400, 300, 45)], 11), _frame(480, 640, [(320, 240, 60)], 12),
+            _frame(200, 260, [], 13), _frame(480, 640, [(500, 100, 25), (120, 350, 50), (330, 220, 18)], 14),
+            _frame(720, 1280, [(640, 360, 70)], 15), _frame(480, 640, [(150, 120, 20), (400, 300, 45)], 16),
+            _frame(20, 300, [(100, 10, 8)], 17), _frame(480, 640, [(320, 240, 60)], 18),
+            _frame(480, 640, [(200, 200, 30)], 19), _frame(480, 640, [(420, 260, 40)], 20),
+            _frame(480, 640, [(100, 380, 33)], 21), _frame(480, 640, [(320, 240, 60)], 22)]
+
+
+@pytest.mark.gpu
+def test_server_flow_on_a_haar_only_handle_matches_oracle(pkg, haar_handle, seeded_sd):
+    """The reference AS SHIPPED has no SSD files, so `/analyze` detects with the cascade and classifies faces[0]
+    (backend_server.py:153-171 -> face_detection.py:58-61,108-123).  A Haar-only handle must do exactly that inside
+    the fused call: box == haar_ref.detect's first, 'face+frame', votes == the oracle flow driven by that detector."""
+    from oracle.pipeline_ref import PredictRef
+
+    h, cas = haar_handle
+    det = pkg.deepfake_detection.DeepfakeDetector(use_tta=False, num_tta_augmentations=1, detection_threshold=0.55, handle=h)
+    ref = PredictRef(pkg.weights.to_torch(seeded_sd), None, None, detection_threshold=0.55, haar_cascade=cas)
+    modes = []
+    for frame in _haar_stream():
+        want = ref.request(frame)
+        got = det.analyze_request(frame)
+        for k in ('analysis_mode', 'faces_detected', 'confidence_level', 'frame_count'):
+            assert got[k] == want[k], k
+        assert got.get('face_bbox') == want.get('face_bbox')
+        assert abs(got['fake_probability'] - want['fake_probability']) <= 1e-3
+        assert got['frame_forensic_probability'] == want['frame_forensic_probability']
+        assert det.temporal_tracker.get_voting_stats() == want['votes']
+        modes.append(got['analysis_mode'])
+    assert modes.count('face+frame') >= 8 and modes.count('frame_only') >= 2, modes
+
+
+@pytest.mark.gpu
+def test_predict_on_a_haar_only_handle_matches_oracle(pkg, haar_handle, seeded_sd):
+    """`predict` (deepfake_detection.py:603-626) classifies and votes on EVERY box the cascade returns."""
+    from oracle.pipeline_ref import PredictRef
+
+    h, cas = haar_handle
+    det = pkg.deepfake_detection.DeepfakeDetector(use_tta=False, num_tta_augmentations=1, detection_threshold=0.5, handle=h)
+    ref = PredictRef(pkg.weights.to_torch(seeded_sd), None, None, detection_threshold=0.5, haar_cascade=cas)
+    total = 0
+    for frame in _haar_stream()[:6]:
+        want = ref.predict(frame)
+        got = det.predict(frame)[3]
+        assert got['faces_detected'] == want['faces_detected'] and got['analysis_mode'] == want['analysis_mode']
+        assert [r['bbox'] for r in got['face_results']] == [r['bbox'] for r in want['face_results']]
+        for g, w in zip(got['face_results'], want['face_results']):
+            assert abs(g['face_prob'] - w['face_prob']) <= 1e-3
+        assert det.temporal_tracker.get_voting_stats() == want['votes']
+        assert got['confidence_level'] == want['confidence_level']
+        total += got['faces_detected']
+    assert total >= 6
+
+
+@pytest.mark.gpu
+def test_jpeg_request_and_health_on_a_haar_only_handle(pkg, haar_handle):
+    """dfd_analyze_jpeg takes the same fallback (the decoded frame never visits the host), and /health reports face
+    detection as available (reference backend_server.py:93: the DNN or its Haar fallback)."""
+    import io
+
+    from PIL import Image
+
+    h, cas = haar_handle
+    frame = _frame(480, 640, [(320, 240, 60)], 12)
+    buf = io.BytesIO()
+    Image.fromarray(frame[..., ::-1]).save(buf, "JPEG", quality=92)
+    a = pkg.deepfake_detection.DeepfakeDetector(use_tta=False, num_tta_augmentations=1, detection_threshold=0.55, handle=h)
+    b = pkg.deepfake_detection.DeepfakeDetector(use_tta=False, num_tta_augmentations=1, detection_threshold=0.55, handle=h)
+    b.frame_analyzer.stream_id = a.frame_analyzer.stream_id + 1
+    got = a.analyze_request(jpeg=buf.getvalue())
+    decoded = np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))[..., ::-1])
+    want = b.analyze_request(decoded)
+    assert got == want and got['analysis_mode'] == 'face+frame' and got['faces_detected'] >= 1
+    prev = pkg.runtime.peek_default_handle()
+    pkg.runtime.set_default_handle(h)
+    try:
+        from rtdfd_amd import backend_server
+
+        caps = backend_server.app.test_client().get('/health').get_json()['capabilities']
+        assert caps['face_detection'] is True
+    finally:
+        pkg.runtime.set_default_handle(prev)
