@@ -275,6 +275,22 @@ int dfd_analyze_jpeg(dfd_handle* h, int stream_id, const uint8_t* jpeg, size_t l
                      int max_faces, int apply_clahe, double* scores_out, double* forensic_prob_out, int32_t* xywh_out,
                      int* n_faces_out, float* logits_out, int* height_out, int* width_out);
 
+/* ---- one request, several consecutive frames of ONE stream (POST /analyze_batch) --------------
+ * The per-frame flow of dfd_analyze_frame / dfd_analyze_jpeg (reference backend_server.py:139-164, executed once per
+ * request there) for n frames in stream order with every stage batched: data[i] is a JPEG of len[i] bytes (entropy
+ * decoding of the files in parallel on the library's host threads, IDCT / colour on the device) or, with len[i] = 0, a
+ * packed BGR frame of height x width; all frames of a call share one size.  full_forensics[i]: the caller's full / fast
+ * schedule (reference deepfake_detection.py:509-512).  The stream's temporal forensic state advances n frames.
+ * Outputs: scores [n][6], forensic_prob [n], xywh [n][max_faces][4], n_faces [n] (boxes returned and classified),
+ * n_detected [n] or NULL (len(faces) before the max_faces cut, backend_server.py:181), logits [n][max_faces] (NaN:
+ * the MTCNN stage found no face), *height / *width or NULL.  Results equal n single calls in the same order.
+ * DFD_ERR_UNSUPPORTED / DFD_ERR_ARG for a JPEG the device path does not decode: nothing of the stream's state has
+ * moved yet (headers of all parts are parsed before any stage runs). */
+int dfd_analyze_stream_batch(dfd_handle* h, int stream_id, int n, const uint8_t* const* data, const size_t* len, int height,
+                             int width, const int* full_forensics, float conf_thr, int max_faces, int apply_clahe,
+                             double* scores_out, double* forensic_prob_out, int32_t* xywh_out, int* n_faces_out,
+                             int* n_detected_out, float* logits_out, int* height_out, int* width_out);
+
 /* ---- many frames, resident in HBM (throughput path; BASELINE.json configs[2]/[3]) ----------
  * frames_dev: n packed 8-bit BGR frames of height x width on the handle's device (row stride
  * width*3).  Runs the detector on all frames in one launch set; then, per frame, classifies

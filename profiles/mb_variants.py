@@ -24,7 +24,9 @@ xd = h.alloc(xn.nbytes).upload(xn)
 yd = h.alloc(1024)
 h.warmup(256, 0)
 blocks = {(112, 2): "b1.dw", (56, 1): "b2.dw", (56, 2): "b3.dw", (28, 1): "b4.dw", (28, 2): "b5.dw"}
-nvar = {(112, 2): range(6), (56, 1): range(6), (56, 2): range(5), (28, 1): range(6), (28, 2): range(5)}
+# -1 = first generation (fp32, stride 2 only), 0-1 = DFD_MB2_TABLE, 6.. = DFD_MB3_TABLE (round 3: NT / INS)
+nvar = {(112, 2): [-1, 0, 1] if not bf16 else [0, 1], (56, 1): [0, 1, 6, 7, 8, 9, 10], (56, 2): [-1, 0, 1, 6, 7, 8], (28, 1): [0, 1, 6, 7, 8, 9, 10, 11, 12],
+        (28, 2): [-1, 0, 1, 6, 7, 8, 9]}
 if os.environ.get("MB_VARS"):
     nvar = {k: [int(v) for v in os.environ["MB_VARS"].split(",")] for k in nvar}
 
@@ -50,4 +52,4 @@ for key, layer in blocks.items():
         os.environ[f"DFD_MB_VARIANT_{key[0]}_{key[1]}"] = str(v)
         t, err = run()
         print(f"{layer} variant {v}: {t[layer] * 1e3:7.1f} us   (step dw total {sum(ms for n, ms in t.items() if n.endswith('.dw')) * 1e3:.0f} us)  err {err:.2e}", flush=True)
-    os.environ[f"DFD_MB_VARIANT_{key[0]}_{key[1]}"] = "0"
+    del os.environ[f"DFD_MB_VARIANT_{key[0]}_{key[1]}"]

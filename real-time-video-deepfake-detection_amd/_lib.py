@@ -84,6 +84,9 @@ SIGNATURES = {
     "dfd_analyze_jpeg": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int),
                                    C.POINTER(C.c_int)]),
+    "dfd_analyze_stream_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dfd_analyze_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                            C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),
@@ -468,6 +471,47 @@ class Handle:
         scores = {k: float(v) for k, v in zip(self.FORENSIC_KEYS, sc) if not np.isnan(v)}
         return (scores, float(prob.value), [tuple(int(v) for v in boxes[i]) for i in range(n.value)], logits[: n.value].copy(),
                 (hh.value, ww.value))
+
+    def analyze_stream_batch(self, items, full_flags, stream_id: int = 0, confidence_threshold: float = 0.5,
+                             max_faces: int = 1, apply_clahe: bool = True):
+        """n consecutive frames of one stream in ONE call (dfd_analyze_stream_batch).  items: JPEG `bytes` and / or BGR
+        uint8 arrays of one size.  -> list of (scores dict, forensic prob, boxes, logits, n_detected) per frame, (H, W)"""
+        n = len(items)
+        if n == 0 or len(full_flags) != n:
+            raise ValueError("analyze_stream_batch: one full / fast flag per frame")
+        keep, ptrs, lens = [], (C.c_void_p * n)(), (C.c_size_t * n)()
+        hh = ww = 0
+        for i, it in enumerate(items):
+            if isinstance(it, (bytes, bytearray, memoryview)):
+                b = (C.c_char * len(it)).from_buffer_copy(it)
+                keep.append(b)
+                ptrs[i], lens[i] = C.addressof(b), len(it)
+            else:
+                a = np.ascontiguousarray(it, dtype=np.uint8)
+                if a.ndim != 3 or a.shape[2] != 3 or (hh and a.shape[:2] != (hh, ww)):
+                    raise ValueError("analyze_stream_batch: raw frames are (H, W, 3) uint8 of one size")
+                hh, ww = a.shape[:2]
+                keep.append(a)
+                ptrs[i], lens[i] = a.ctypes.data, 0
+        max_faces = max(1, int(max_faces))
+        full = np.ascontiguousarray([int(bool(f)) for f in full_flags], dtype=np.int32)
+        sc = np.empty((n, 6), np.float64)
+        prob = np.empty(n, np.float64)
+        boxes = np.zeros((n, max_faces, 4), np.int32)
+        nf = np.zeros(n, np.int32)
+        nd = np.zeros(n, np.int32)
+        logits = np.zeros((n, max_faces), np.float32)
+        oh, ow = C.c_int(), C.c_int()
+        self._check(self._lib.dfd_analyze_stream_batch(self._p, int(stream_id), n, ptrs, lens, int(hh), int(ww), _ptr(full),
+                                                       float(confidence_threshold), max_faces, int(bool(apply_clahe)), _ptr(sc),
+                                                       _ptr(prob), _ptr(boxes), _ptr(nf), _ptr(nd), _ptr(logits),
+                                                       C.byref(oh), C.byref(ow)))
+        out = []
+        for i in range(n):
+            scores = {k: float(v) for k, v in zip(self.FORENSIC_KEYS, sc[i]) if not np.isnan(v)}
+            out.append((scores, float(prob[i]), [tuple(int(v) for v in boxes[i, j]) for j in range(nf[i])],
+                        logits[i, : nf[i]].copy(), int(nd[i])))
+        return out, (oh.value, ow.value)
 
     def host_alloc(self, shape, dtype=np.uint8) -> np.ndarray:
         """A numpy array over pinned host memory (hipHostMalloc); release with host_free(arr)."""

@@ -25,7 +25,7 @@ namespace dfd {
 __device__ long long g_mb_trace[256];
 #define MB_TP(id)                                                                                             \
     do {                                                                                                      \
-        if (H == MB_TRACE_H && S == MB_TRACE_S && blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0 && mtp < 250) { \
+        if (H == MB_TRACE_H && S == MB_TRACE_S && bid.x == 5 && bid.n == 3 && threadIdx.x == 0 && mtp < 250) { \
             g_mb_trace[mtp++] = (long long)(id);                                                              \
             g_mb_trace[mtp++] = (long long)__builtin_amdgcn_s_memtime();                                      \
         }                                                                                                     \
@@ -368,6 +368,22 @@ bool launch_conv_gemm(const float* X, const float* W, const float* bias, const f
 }
 
 // --------------------------------------------------------------------------- depthwise
+// XCD-aware, image-major block order for the depthwise family (1-D grids of bpi * n_img blocks).  The dispatcher
+// deals consecutive workgroup ids round-robin over the 8 XCDs (MI355X_MICROARCH.md, Workgroup dispatch): with the
+// natural order the 15 channel-chunk blocks of ONE image landed on all eight L2s and each fetched the image's input
+// again (PMC, round 2: block 4 read 8.4x its input, block 5 4.2x, the stem 3.0x).  Here ids that share an XCD
+// (id % 8) walk a contiguous run of the image-major sequence, so every block of an image - all its channel chunks
+// and spatial tiles with their overlapping halos - runs on one XCD close in time and the input crosses HBM once.
+// Bijective for any grid size (guide T1); placement only affects speed, never results.
+struct BlkId { int x, n; };
+__device__ __forceinline__ BlkId blk_image_major(int bpi) {
+    const int L = blockIdx.x, total = gridDim.x;
+    const int xcd = L & 7, slot = L >> 3, q = total >> 3, r = total & 7;
+    const int Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int n = Lp / bpi;
+    return BlkId{Lp - n * bpi, n};
+}
+
 // Block = one image x one CB-channel chunk x one TH x TW output tile.  The (TH-1)S+K by
 // (TW-1)S+K input halo tile is staged in LDS as float4 channel vectors (zero-filled outside
 // the image: TF-SAME padding), weights too.  Thread = (channel quad, strip of RP outputs
@@ -398,22 +414,22 @@ struct DwShape {
 // depthwise conv of the LDS tile + folded BN + swish + store + per-tile SE partial sums.
 // Ends with a barrier-protected write of P; callers that reuse tile/wl/red afterwards must
 // __syncthreads() first.
-template <int K, int S, int CB, int TH, int TW, int RP, bool SWZ = false, typename XT = float, int ABL = 0>
+template <int K, int S, int CB, int TH, int TW, int RP, bool SWZ = false, typename XT = float, int ABL = 0, int NT = 256>
 __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* red,
                                            const v4f bv, XT* __restrict__ Y,
                                            float* __restrict__ P, int n, int Ho, int C, int c0, int ty0,
                                            int tx0, int t, int tiles_sp) {
     constexpr int CG = CB / 4;
     constexpr int IW = (TW - 1) * S + K;
-    constexpr int SX = TW / RP, NSTRIP = TH * SX, NSLOT = 256 / CG;
+    constexpr int SX = TW / RP, NSTRIP = TH * SX, NSLOT = NT / CG, NW = NT / 64;
     constexpr int NIN = (RP - 1) * S + K;
     constexpr bool POW2 = (CG & (CG - 1)) == 0;
-    static_assert(TW % RP == 0 && CG <= 64, "tile shape");
+    static_assert(TW % RP == 0 && CG <= 64 && (NW == 4 || NW == 8), "tile shape");
     const int tid = threadIdx.x;
     const int cg = tid % CG, slot = tid / CG;
     v4f psum = (v4f){0.f, 0.f, 0.f, 0.f};
     XT* yb = Y + (size_t)n * Ho * Ho * C + c0 + 4 * cg;
-    if (POW2 || slot < NSLOT) {                          // CG not a power of two: the last 256 % CG threads idle
+    if (POW2 || slot < NSLOT) {                          // CG not a power of two: the last NT % CG threads idle
         for (int strip = slot; strip < NSTRIP; strip += NSLOT) {
             const int oy = strip / SX, ox0 = (strip % SX) * RP;
             v4f acc[RP];
@@ -459,7 +475,8 @@ __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* 
         if (lane < CG) red[wave * CG + lane] = psum;
         __syncthreads();
         if (tid < CG) {
-            const v4f v = (red[tid] + red[CG + tid]) + (red[2 * CG + tid] + red[3 * CG + tid]);
+            v4f v = (red[tid] + red[CG + tid]) + (red[2 * CG + tid] + red[3 * CG + tid]);
+            if constexpr (NW == 8) v += (red[4 * CG + tid] + red[5 * CG + tid]) + (red[6 * CG + tid] + red[7 * CG + tid]);
             stg4(P + ((size_t)n * tiles_sp + t) * C + c0 + 4 * tid, v);
         }
     } else {
@@ -487,8 +504,9 @@ __global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const XT* __
     __shared__ v4f wl[K * K * CG];
     __shared__ v4f red[4 * CG];
     const int tid = threadIdx.x;
-    const int n = blockIdx.y;
-    const int t = blockIdx.x % tiles_sp, chunk = blockIdx.x / tiles_sp;
+    const BlkId bid = blk_image_major(tiles_sp * (C / CB));
+    const int n = bid.n;
+    const int t = bid.x % tiles_sp, chunk = bid.x / tiles_sp;
     const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW, c0 = chunk * CB;
     const v4f bv = ldg4(bias + c0 + 4 * (tid % CG));      // issued with the tile loads, used after the barrier
     for (int i = tid; i < K * K * CG; i += 256)
@@ -529,7 +547,9 @@ __global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const XT* __
 // HBM.  A block walks NSUB channel chunks of CB channels over the same spatial tile: the input
 // fragments of all its pixels are loaded ONCE, up front (one batch of loads in flight), and reused
 // for every chunk.  Price: the halo's expand FLOPs are recomputed (1.1-1.65x).
-template <int K, int S, int CB, int TH, int TW, int RP, int KC, int NSUB, typename XT>
+// (round 3) fp32 only, exactly Cin / 4 MFMAs per pixel tile: lane k-group q supplies the NM = Cin / 4 consecutive
+// channels q * NM .. of its pixel (see mbconv2_kernel); KC = 16-byte registers per tile and lane = ceil(NM / 4).
+template <int K, int S, int CB, int TH, int TW, int RP, int KC, int NSUB, typename XT, int CI>
 __global__ __launch_bounds__(256, 3) void mbconv_kernel(const XT* __restrict__ X,
                                                      const float* __restrict__ We,
                                                      const float* __restrict__ be,
@@ -542,12 +562,15 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const XT* __restrict__ X
     constexpr int CG = Sh::CG, IH = Sh::IH, IW = Sh::IW;
     constexpr int NTB = CB / 16;                        // 16-channel MFMA row tiles per chunk
     constexpr int NP = IH * IW, NMT = (NP + 15) / 16, NIT = (NMT + 3) / 4;
+    constexpr int NM = CI / 4;
+    static_assert(sizeof(XT) == 4 && CI % 8 == 0 && KC == (NM + 3) / 4, "fp32 activations, compile-time Cin");
     __shared__ v4f tile[IH * IW * CG];
     __shared__ v4f wl[K * K * CG];
     __shared__ v4f red[4 * CG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
-    const int n = blockIdx.y;
-    const int t = blockIdx.x % tiles_sp, group = blockIdx.x / tiles_sp;
+    const BlkId bid = blk_image_major(tiles_sp * (C / (CB * NSUB)));
+    const int n = bid.n;
+    const int t = bid.x % tiles_sp, group = bid.x / tiles_sp;
     const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
     const int iy0 = ty0 * S - pad_lo, ix0 = tx0 * S - pad_lo;
 #ifdef MB_TRACE
@@ -563,12 +586,13 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const XT* __restrict__ X
         const int p = (wave + 4 * it) * 16 + j;
         const int iy = iy0 + p / IW, ix = ix0 + p % IW;
         const bool inside = p < NP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
-        const XT* px = xb + ((size_t)(inside ? iy : 0) * H + (inside ? ix : 0)) * Cin;
+        const float* px = reinterpret_cast<const float*>(xb) + ((size_t)(inside ? iy : 0) * H + (inside ? ix : 0)) * CI + q * NM;
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
-            const int k = kk * 16 + 4 * q;
-            const v4f v = ld4(px + (k < Cin ? k : 0));           // unconditional load, masked value
-            xf[it][kk] = (inside && k < Cin) ? v : (v4f){0.f, 0.f, 0.f, 0.f};
+            v4f v;                                               // unconditional load, masked value
+            if (NM % 4 == 0 || kk < KC - 1) v = ldg4u(px + 4 * kk);
+            else { const v2f t2 = ldg2(px + 4 * kk); v = (v4f){t2.x, t2.y, 0.f, 0.f}; }
+            xf[it][kk] = inside ? v : (v4f){0.f, 0.f, 0.f, 0.f};
         }
     }
 
@@ -587,9 +611,9 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const XT* __restrict__ X
             w.bex[nt] = ldg4(be + c0 + nt * 16 + 4 * q);
 #pragma unroll
             for (int kk = 0; kk < KC; ++kk) {
-                const int k = kk * 16 + 4 * q;
-                const v4f v = ldg4(We + (size_t)(c0 + nt * 16 + j) * Cin + (k < Cin ? k : 0));
-                w.wf[nt][kk] = k < Cin ? v : (v4f){0.f, 0.f, 0.f, 0.f};
+                const float* pw = We + (size_t)(c0 + nt * 16 + j) * CI + q * NM + 4 * kk;
+                if (NM % 4 == 0 || kk < KC - 1) w.wf[nt][kk] = ldg4u(pw);
+                else { const v2f t2 = ldg2(pw); w.wf[nt][kk] = (v4f){t2.x, t2.y, 0.f, 0.f}; }
             }
         }
     };
@@ -612,23 +636,21 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const XT* __restrict__ X
         for (int it = 0; it < NIT; ++it) {
             const int mt = wave + 4 * it;
             if (mt < NMT) {                                      // wave-uniform
-                v4f acc[NTB];
+                v4f acc[NTB];                                    // starts at the folded-BN bias: no add in the epilogue
 #pragma unroll
-                for (int nt = 0; nt < NTB; ++nt) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+                for (int nt = 0; nt < NTB; ++nt) acc[nt] = bex[nt];
 #pragma unroll
-                for (int kk = 0; kk < KC; ++kk)
+                for (int i = 0; i < NM; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int nt = 0; nt < NTB; ++nt)
-                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][kk][e], xf[it][kk][e], acc[nt], 0, 0, 0);
+                    for (int nt = 0; nt < NTB; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i / 4][i % 4], xf[it][i / 4][i % 4], acc[nt], 0, 0, 0);
                 const int p = mt * 16 + j;
                 const int iy = iy0 + p / IW, ix = ix0 + p % IW;
                 const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
                 if (p < NP) {
 #pragma unroll
                     for (int nt = 0; nt < NTB; ++nt)
-                        tile[tile_unit<CG, (CG >= 8)>(p, nt * 4 + q)] = inside ? swish4(acc[nt] + bex[nt]) : (v4f){0.f, 0.f, 0.f, 0.f};
+                        tile[tile_unit<CG, (CG >= 8)>(p, nt * 4 + q)] = inside ? swish4(acc[nt]) : (v4f){0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
@@ -639,7 +661,7 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const XT* __restrict__ X
         MB_TP(6);
     }
 #ifdef MB_TRACE
-    if (H == MB_TRACE_H && S == MB_TRACE_S && blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
+    if (H == MB_TRACE_H && S == MB_TRACE_S && bid.x == 5 && bid.n == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
 #endif
 }
 
@@ -659,8 +681,21 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const XT* __restrict__ X
 //     activations requested before the current tile's MFMAs: registers stay bounded for any tile size, so tiles
 //     grow until LDS says stop and the halo recompute shrinks;
 //   * dw_compute takes any CG (pool partials through LDS when CG is not a power of two).
-template <int K, int S, int CB, int TH, int TW, int RP, int NK, typename XT, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void mbconv2_kernel(const XT* __restrict__ X,
+//   * (round 3) NT = threads per block: 512 doubles the waves that share one LDS tile (block 4's whole-image tile is
+//     64 KB: two blocks per CU were two waves per SIMD);
+//   * (round 3) INS: the pixel tiles enumerate only the pixels of the halo tile that lie INSIDE the image (its clipped
+//     rectangle, row-major): the zero border of the TF-SAME padding is written directly, not computed - block 4's
+//     32 x 32 halo tile holds 28 x 28 = 49 tiles of real pixels, not 64.
+//   * (round 3) fp32 expand with EXACTLY Cin / 4 MFMAs per pixel tile: lane k-group q supplies the NM = Cin / 4
+//     consecutive channels q * NM .. q * NM + NM - 1 of its pixel (one contiguous 4 * NM-byte piece of the NHWC record;
+//     MFMA e contracts k = {e, NM + e, 2 NM + e, 3 NM + e} - the same permutation on both operands).  The 16-channel
+//     steps it replaces issued 16 MFMAs for Cin = 40 (10 needed) and 8 for Cin = 24 (6 needed);
+//   * (round 3) the activation ring is refilled AFTER the tile's MFMAs have issued: refilled before them the slot's
+//     old value had to be copied aside, the copy landed in the loop latch behind `s_waitcnt vmcnt(0)` (ISA), and every
+//     4-tile iteration drained the whole ring - an s_memtime trace put 64 % of block 4's time in that loop.
+template <int K, int S, int CB, int TH, int TW, int RP, int NK, typename XT, int ABL = 0, int NT = 256, bool INS = false,
+          int CI = 0>
+__global__ __launch_bounds__(NT, (NT == 256 ? 2 : 4)) void mbconv2_kernel(const XT* __restrict__ X,
                                                       const unsigned short* __restrict__ We3, int plane, int Kp,
                                                       const float* __restrict__ Wef,
                                                       const float* __restrict__ be,
@@ -672,23 +707,27 @@ __global__ __launch_bounds__(256, 2) void mbconv2_kernel(const XT* __restrict__ 
     using Sh = DwShape<K, S, CB, TH, TW>;
     constexpr int CG = Sh::CG, IH = Sh::IH, IW = Sh::IW;
     constexpr int NTB = CB / 16;                        // 16-channel MFMA row tiles of the chunk
-    constexpr int NPX = IH * IW, NMT = (NPX + 15) / 16, NIT = (NMT + 3) / 4;
+    constexpr int NW = NT / 64;
+    constexpr int NPX = IH * IW, NMT = (NPX + 15) / 16, NIT = (NMT + NW - 1) / NW;
     constexpr int ESZ = (int)sizeof(XT);
     // fp32 activations: the expand runs on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, KC = ceil(Cin / 16) steps of
     // four MFMAs, lane = k-quad q).  These kernels are VALU-bound (SQ_ACTIVE_INST_VALU 80-90 % of the launch) and
     // the matrix pipe is ~20 % busy: splitting every activation into three bf16 terms costs ~45 VALU instructions
     // per 8 values - on the bottleneck - to save time on a unit that is idle anyway.  bf16 activations are the
     // bf16 MFMA's operand as loaded (three products against the three weight planes).
-    constexpr int KC = ESZ == 4 ? (NK * 32 + 15) / 16 : NK;            // loads per pixel tile (16 B each per lane)
+    constexpr int NM = CI / 4;                                         // fp32: MFMAs per pixel tile = floats per lane and tile
+    static_assert(ESZ != 4 || (CI > 0 && CI % 8 == 0 && (CI + 31) / 32 == NK), "fp32 path: compile-time Cin, a multiple of 8");
+    constexpr int KC = ESZ == 4 ? (NM + 3) / 4 : NK;                   // 16-byte registers per pixel tile and lane
     constexpr bool SWZ = (CG & (CG - 1)) == 0 && CG >= 8;
-    constexpr int NSLOT = 256 / CG;
+    constexpr int NSLOT = NT / CG;
     static_assert(CB % 16 == 0, "channel chunk = whole MFMA row tiles");
     __shared__ v4f tile[IH * IW * CG];
     __shared__ v4f wl[K * K * CG];
-    __shared__ v4f red[(CG & (CG - 1)) == 0 ? 4 * CG : NSLOT * CG];
+    __shared__ v4f red[(CG & (CG - 1)) == 0 ? NW * CG : NSLOT * CG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
-    const int n = blockIdx.y;
-    const int t = blockIdx.x % tiles_sp, chunk = blockIdx.x / tiles_sp;
+    const BlkId bid = blk_image_major(tiles_sp * (C / CB));
+    const int n = bid.n;
+    const int t = bid.x % tiles_sp, chunk = bid.x / tiles_sp;
     const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW, c0 = chunk * CB;
     const int iy0 = ty0 * S - pad_lo, ix0 = tx0 * S - pad_lo;
 #ifdef MB_TRACE
@@ -699,19 +738,39 @@ __global__ __launch_bounds__(256, 2) void mbconv2_kernel(const XT* __restrict__ 
     // activations of pixel tile `mt` for this lane: pixel p = mt * 16 + j, K-step ks: the 8 channels ks*32 + 8q ..
     // (channels >= Cin: the address falls back to channel 0 - the weight planes are zero there)
     const XT* xb = X + (size_t)n * H * H * Cin;
+    // INS: the halo tile's rectangle inside the image, in tile coordinates: rows [ry0, ry0 + RH), cols [rx0, rx0 + RW)
+    const int ry0 = iy0 < 0 ? -iy0 : 0, rx0 = ix0 < 0 ? -ix0 : 0;
+    const int RH = (H - iy0 < IH ? H - iy0 : IH) - ry0, RW = (H - ix0 < IW ? H - ix0 : IW) - rx0;
+    const int npin = RH * RW;
+    const int nmt = INS ? (npin + 15) >> 4 : NMT;           // pixel tiles that hold work (block-uniform)
+    const float inv_rw = 1.0f / (float)RW;
+    // pixel index of the enumeration -> (row, col) in tile coordinates
+    auto tile_rc = [&](int pidx, int& r, int& c) {
+        if constexpr (INS) {
+            const int pc = pidx < npin ? pidx : npin - 1;
+            const int rr = (int)(((float)pc + 0.5f) * inv_rw);           // exact: pc < 2^12, RW <= 64
+            r = ry0 + rr;
+            c = rx0 + pc - rr * RW;
+        } else {
+            const int pc = pidx < NPX ? pidx : NPX - 1;
+            r = pc / IW;
+            c = pc - r * IW;
+        }
+    };
     struct XTile { v4f raw[KC]; };
     auto load_tile = [&](int mt, XTile& xt) {
-        int p = mt * 16 + j;
-        p = p < NPX ? p : NPX - 1;
-        const int iy = iy0 + p / IW, ix = ix0 + p % IW;
-        const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
+        int r, c;
+        tile_rc(mt * 16 + j, r, c);
+        const int iy = iy0 + r, ix = ix0 + c;
+        const bool inside = INS || ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H);
         const XT* px = xb + ((size_t)(inside ? iy : 0) * H + (inside ? ix : 0)) * Cin;
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
             if constexpr (ESZ == 4) {
-                const int k = kk * 16 + 4 * q;
-                const v4f v = ldg4(reinterpret_cast<const float*>(px) + (k < Cin ? k : 0));
-                xt.raw[kk] = k < Cin ? v : (v4f){0.f, 0.f, 0.f, 0.f};
+                const float* pf = reinterpret_cast<const float*>(px) + q * NM + 4 * kk;
+                if constexpr (NM % 4 == 0) xt.raw[kk] = ldg4u(pf);
+                else if (kk < KC - 1) xt.raw[kk] = ldg4u(pf);
+                else { const v2f t = ldg2(pf); xt.raw[kk] = (v4f){t.x, t.y, 0.f, 0.f}; }      // NM % 4 == 2
             } else {
                 const int k = kk * 32 + 8 * q;
                 xt.raw[kk] = *reinterpret_cast<const v4f*>(px + (k < Cin ? k : 0));          // 8 bf16
@@ -723,14 +782,20 @@ __global__ __launch_bounds__(256, 2) void mbconv2_kernel(const XT* __restrict__ 
     // at 155 us of a 232 us launch with MFMAs and swish together accounting for 44 of them.
     constexpr int RD = NIT < (64 / (4 * KC)) ? NIT : (64 / (4 * KC));
     XTile ring[RD];
-#pragma unroll
-    for (int d = 0; d < RD; ++d) load_tile(wave + 4 * d < NMT ? wave + 4 * d : NMT - 1, ring[d]);
-
-    // the chunk's expand rows as MFMA A operands (lane: channel row j, k-octet q), its folded-BN biases, the
-    // depthwise taps and bias: all requested together with the first activation tile
+    // Request order = wait order.  The block's constants (expand rows as MFMA A operands: lane = channel row j,
+    // k-group q; folded-BN biases; depthwise taps and bias) go FIRST, the activation ring after them: vmcnt retires in
+    // order, so "the constants and the ring's oldest tile have landed" is the same count (3 * (RD - 1) loads still in
+    // flight) on the loop's entry edge and on its back edge.  Requested after the ring (rounds 1-2) the entry edge
+    // needed vmcnt(1), hipcc put the stricter count at the loop header, and every iteration drained the whole ring;
+    // the depthwise taps went global -> LDS in the prologue, a vmcnt(0) before the first MFMA (6k of a block's 52k
+    // cycles in the s_memtime trace) - they now wait in a register until the expand loop is done.
     constexpr int WREG = ESZ == 4 ? KC : NK * 3;             // 16-byte weight registers per 16-channel tile
+    static_assert(K * K * CG <= NT, "one depthwise weight vector per thread");
     v4f wfr[NTB][WREG];
     v4f bex[NTB];
+    const int wli = tid < K * K * CG ? tid : 0;
+    const v4f wl_v = ldg4(Wt + (size_t)(wli / CG) * C + c0 + 4 * (wli % CG));
+    const v4f bv = ldg4(bias + c0 + 4 * (tid % CG));
     const unsigned short* wrow = We3 + (size_t)(c0 + j) * Kp + 8 * q;
 #pragma unroll
     for (int nt = 0; nt < NTB; ++nt) {
@@ -738,9 +803,10 @@ __global__ __launch_bounds__(256, 2) void mbconv2_kernel(const XT* __restrict__ 
         if constexpr (ESZ == 4) {
 #pragma unroll
             for (int kk = 0; kk < KC; ++kk) {
-                const int k = kk * 16 + 4 * q;
-                const v4f v = ldg4(Wef + (size_t)(c0 + nt * 16 + j) * Cin + (k < Cin ? k : 0));
-                wfr[nt][kk] = k < Cin ? v : (v4f){0.f, 0.f, 0.f, 0.f};
+                const float* pw = Wef + (size_t)(c0 + nt * 16 + j) * CI + q * NM + 4 * kk;
+                if constexpr (NM % 4 == 0) wfr[nt][kk] = ldg4u(pw);
+                else if (kk < KC - 1) wfr[nt][kk] = ldg4u(pw);
+                else { const v2f t = ldg2(pw); wfr[nt][kk] = (v4f){t.x, t.y, 0.f, 0.f}; }
             }
         } else {
 #pragma unroll
@@ -750,8 +816,16 @@ __global__ __launch_bounds__(256, 2) void mbconv2_kernel(const XT* __restrict__ 
                     wfr[nt][ks * 3 + pl] = *reinterpret_cast<const v4f*>(wrow + (size_t)pl * plane + (size_t)nt * 16 * Kp + ks * 32);
         }
     }
-    const v4f bv = ldg4(bias + c0 + 4 * (tid % CG));
-    for (int i = tid; i < K * K * CG; i += 256) wl[i] = ldg4(Wt + (size_t)(i / CG) * C + c0 + 4 * (i % CG));
+#pragma unroll
+    for (int d = 0; d < RD; ++d) load_tile(wave + NW * d < nmt ? wave + NW * d : nmt - 1, ring[d]);
+    if constexpr (INS) {
+        // the padding border of the tile: written, not computed (disjoint from the units the expand writes below)
+        for (int i = tid; i < NPX * CG; i += NT) {
+            const int pp = i / CG, r = pp / IW, c = pp - r * IW;
+            if ((unsigned)(r - ry0) >= (unsigned)RH || (unsigned)(c - rx0) >= (unsigned)RW)
+                tile[tile_unit<CG, SWZ>(pp, i - pp * CG)] = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    }
     MB_TP(1);
 
 #pragma unroll 1
@@ -759,27 +833,33 @@ __global__ __launch_bounds__(256, 2) void mbconv2_kernel(const XT* __restrict__ 
 #pragma unroll
       for (int d = 0; d < RD; ++d) {
         const int it = it0 + d;
-        const int mt = wave + 4 * it;
-        const XTile xa = ring[d];
-        {   // tile it + RD into the slot just read (past the end: re-requests the last tile, never used)
-            const int mn = mt + 4 * RD;
-            load_tile(mn < NMT ? mn : NMT - 1, ring[d]);
-        }
-        v4f acc[NTB];
+        const int mt = wave + NW * it;
+        XTile& xa = ring[d];
+        v4f acc[NTB];                                            // starts at the folded-BN bias: no add in the epilogue
 #pragma unroll
-        for (int nt = 0; nt < NTB; ++nt) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NTB; ++nt) acc[nt] = bex[nt];
         // the NTB accumulators interleaved (independent chains)
         if constexpr (ABL == 1) {
 #pragma unroll
             for (int nt = 0; nt < NTB; ++nt) acc[nt] = xa.raw[0] + wfr[nt][0];
         } else if constexpr (ESZ == 4) {
+            if constexpr (NTB == 1) {
+                // one 16-channel tile: the K steps alternate between two accumulators (two independent MFMA chains instead
+                // of one dependent chain of NM), folded once at the end
+                v4f acc1 = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < KC; ++kk)
+                for (int i = 0; i < NM; ++i) {
+                    if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[0][i / 4][i % 4], xa.raw[i / 4][i % 4], acc1, 0, 0, 0);
+                    else acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[0][i / 4][i % 4], xa.raw[i / 4][i % 4], acc[0], 0, 0, 0);
+                }
+                acc[0] += acc1;
+            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int i = 0; i < NM; ++i)
 #pragma unroll
                     for (int nt = 0; nt < NTB; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[nt][kk][e], xa.raw[kk][e], acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[nt][i / 4][i % 4], xa.raw[i / 4][i % 4], acc[nt], 0, 0, 0);
+            }
         } else {
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks)
@@ -790,28 +870,34 @@ __global__ __launch_bounds__(256, 2) void mbconv2_kernel(const XT* __restrict__ 
                         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, wfr[nt][ks * 3 + pl]),
                                                                           __builtin_bit_cast(bf8, xa.raw[ks]), acc[nt], 0, 0, 0);
         }
-        const int p = mt * 16 + j;
-        const int pc = p < NPX ? p : NPX - 1;
-        const int iy = iy0 + pc / IW, ix = ix0 + pc % IW;
-        const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
-        if (mt < NMT && p < NPX) {
+        {   // tile it + RD into the slot whose MFMAs have just issued (past the end: re-requests the last tile, never used)
+            const int mn = mt + NW * RD;
+            load_tile(mn < nmt ? mn : nmt - 1, ring[d]);
+        }
+        int pr, pcol;
+        tile_rc(mt * 16 + j, pr, pcol);
+        const int p = pr * IW + pcol;                               // unit of the LDS tile
+        const int iy = iy0 + pr, ix = ix0 + pcol;
+        const bool inside = INS || ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H);
+        if (mt < nmt && mt * 16 + j < (INS ? npin : NPX)) {
 #pragma unroll
             for (int nt = 0; nt < NTB; ++nt)
-                tile[tile_unit<CG, SWZ>(p, nt * 4 + q)] = inside ? (ABL == 2 ? acc[nt] + bex[nt] : swish4(acc[nt] + bex[nt])) : (v4f){0.f, 0.f, 0.f, 0.f};
+                tile[tile_unit<CG, SWZ>(p, nt * 4 + q)] = inside ? (ABL == 2 ? acc[nt] : swish4(acc[nt])) : (v4f){0.f, 0.f, 0.f, 0.f};
         }
       }
     }
+    if (tid < K * K * CG) wl[tid] = wl_v;
     MB_TP(4);
     __syncthreads();
     MB_TP(5);
     if constexpr (ABL == 3) {
         if (tid < CG) stg4(P + ((size_t)n * tiles_sp + t) * C + c0 + 4 * tid, tile[tid] + bv);
     } else {
-        dw_compute<K, S, CB, TH, TW, RP, SWZ, XT, ABL>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
+        dw_compute<K, S, CB, TH, TW, RP, SWZ, XT, ABL, NT>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
     }
     MB_TP(6);
 #ifdef MB_TRACE
-    if (H == MB_TRACE_H && S == MB_TRACE_S && blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
+    if (H == MB_TRACE_H && S == MB_TRACE_S && bid.x == 5 && bid.n == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
 #endif
 }
 
@@ -835,7 +921,8 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
     __shared__ v4f wl[K * K * CG];
     __shared__ v4f red[4 * CG];
     __shared__ float patch[3 * PH * PWP];
-    const int tid = threadIdx.x, n = blockIdx.y, t = blockIdx.x;
+    const BlkId bid = blk_image_major(tiles_sp);
+    const int tid = threadIdx.x, n = bid.n, t = bid.x;
     const int lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
     const int ty0 = (t / tiles_x) * TH, tx0 = (t % tiles_x) * TW;
 #ifdef MB_TRACE
@@ -937,7 +1024,7 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
     dw_compute<K, S, CB, TH, TW, RP, false, XT>(tile, wl, red, bv, Y, P, n, 112, 32, 0, ty0, tx0, t, tiles_sp);
     MB_TP(6);
 #ifdef MB_TRACE
-    if (blockIdx.x == 5 && blockIdx.y == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
+    if (bid.x == 5 && bid.n == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
 #endif
 }
 
@@ -946,7 +1033,7 @@ void launch_stem_dw(const float* x, const unsigned short* ws3, int plane, int Kp
                     const float* bd, XT* Y, float* P, XT* stem_out, int n, int* tiles, hipStream_t s) {
     const int tx = 112 / 16, ty = 112 / 8;
     *tiles = tx * ty;
-    hipLaunchKernelGGL(stem_dw_kernel<XT>, dim3(tx * ty, n), dim3(256), 0, s, x, ws3, plane, Kp, bs, Wd, bd, Y, P, stem_out, tx,
+    hipLaunchKernelGGL(stem_dw_kernel<XT>, dim3(tx * ty * n), dim3(256), 0, s, x, ws3, plane, Kp, bs, Wd, bd, Y, P, stem_out, tx,
                        tx * ty);
 }
 template void launch_stem_dw<float>(const float*, const unsigned short*, int, int, const float*, const float*, const float*, float*, float*, float*, int, int*, hipStream_t);
@@ -959,19 +1046,119 @@ static void dw_launch(const XT* X, const float* W, const float* b, XT* Y, float*
     const int tx = (Ho + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
     const int tiles_sp = tx * ty;
     *tiles = tiles_sp;
-    hipLaunchKernelGGL((dw_kernel<K, S, CB, TH, TW, RP, XT>), dim3(tiles_sp * (C / CB), n), dim3(256), 0,
+    hipLaunchKernelGGL((dw_kernel<K, S, CB, TH, TW, RP, XT>), dim3(tiles_sp * (C / CB) * n), dim3(256), 0,
                        s, X, W, b, Y, P, H, Ho, C, pad_lo, tx, tiles_sp);
 }
 
-template <int K, int S, int CB, int TH, int TW, int RP, int KC, int NSUB, typename XT>
+template <int K, int S, int CB, int TH, int TW, int RP, int KC, int NSUB, typename XT, int CI>
 static void mb_launch(const XT* X, int Cin, const float* We, const float* be, const float* W, const float* b,
                       XT* Y, float* P, int n, int H, int C, int pad_lo, int* tiles, hipStream_t s) {
     const int Ho = (H + S - 1) / S;
     const int tx = (Ho + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
     const int tiles_sp = tx * ty;
     *tiles = tiles_sp;
-    hipLaunchKernelGGL((mbconv_kernel<K, S, CB, TH, TW, RP, KC, NSUB, XT>), dim3(tiles_sp * (C / (CB * NSUB)), n),
+    hipLaunchKernelGGL((mbconv_kernel<K, S, CB, TH, TW, RP, KC, NSUB, XT, CI>), dim3(tiles_sp * (C / (CB * NSUB)) * n),
                        dim3(256), 0, s, X, We, be, W, b, Y, P, H, Ho, C, Cin, pad_lo, tx, tiles_sp);
+}
+
+
+// ---- 7 x 7 layers (blocks 12-15): a row per thread, no LDS tile ------------------------------------------------
+// The LDS-tile kernel runs these layers with RP = 1 (a 7 x 7 tile has no strips to give 256 threads): every output
+// costs K*K tile reads + K*K weight reads from LDS - 50 ds_read_b128 per output quad at k = 5, 2.9 GB of LDS traffic
+// per 256 crops = the whole launch (39.7 us) at LDS peak.  Here a thread owns one output ROW of CPT channels (CPT = 4:
+// 16 B of fp32; 8: 16 B of bf16, so a half-wave still moves 512 B per load): per kernel row it loads the 7 input
+// pixels and the K weight vectors (wave-contiguous 16-byte loads, all independent; the 5 threads that share an input
+// row sit in the same block and meet in L1 / L2) and keeps the 7 accumulators in registers.  Block = 8 rows (7 used)
+// x 32 channel groups = 256 threads; grid = images x (C / (32 * CPT)), image-major on one XCD like the others.
+template <int K, int CPT, typename XT>
+__global__ __launch_bounds__(256) void dw_rows7_kernel(const XT* __restrict__ X, const float* __restrict__ Wt,
+                                                       const float* __restrict__ bias, XT* __restrict__ Y,
+                                                       float* __restrict__ P, int C, int groups) {
+    constexpr int H = 7, PAD = (K - 1) / 2, NV = CPT / 4;
+    __shared__ v4f red[8 * 32 * NV];
+    const BlkId bid = blk_image_major(groups);
+    const int tid = threadIdx.x, row = tid >> 5, cl = tid & 31;
+    const int c = (bid.x * 32 + cl) * CPT;
+    const bool live = row < H && c < C;
+    const int cc = c < C ? c : 0, r = row < H ? row : 0;
+    const XT* xb = X + (size_t)bid.n * H * H * C + cc;
+    v4f acc[H][NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const v4f bv = ldg4(bias + cc + 4 * v);
+#pragma unroll
+        for (int ox = 0; ox < H; ++ox) acc[ox][v] = bv;
+    }
+    // kernel rows rolled two at a time at most: fully unrolled, hipcc hoists all K * (7 + K) loads to the top (256
+    // VGPRs at k = 5: one wave per SIMD); the loads of a row pair are independent and issue back to back
+    constexpr int KY_UNROLL = K == 3 && CPT == 4 ? 3 : (CPT == 4 ? 2 : 1);
+#pragma unroll KY_UNROLL
+    for (int ky = 0; ky < K; ++ky) {
+        const int iy = r + ky - PAD;
+        const bool ok = (unsigned)iy < (unsigned)H;
+        const XT* xr = xb + (size_t)(ok ? iy : 0) * H * C;
+        v4f in[H][NV], w[K][NV];
+#pragma unroll
+        for (int ix = 0; ix < H; ++ix)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) in[ix][v] = ld4(xr + (size_t)ix * C + 4 * v);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const v4f wv = ldg4(Wt + (size_t)(ky * K + kx) * C + cc + 4 * v);
+                w[kx][v] = ok ? wv : (v4f){0.f, 0.f, 0.f, 0.f};         // rows outside the image: TF-SAME zero padding
+            }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+            for (int ox = 0; ox < H; ++ox) {
+                const int ix = ox + kx - PAD;                            // compile-time after unrolling
+                if (ix >= 0 && ix < H)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) acc[ox][v] += in[ix][v] * w[kx][v];
+            }
+    }
+    v4f psum[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) psum[v] = (v4f){0.f, 0.f, 0.f, 0.f};
+    XT* yb = Y + ((size_t)bid.n * H * H + (size_t)r * H) * C + cc;
+#pragma unroll
+    for (int ox = 0; ox < H; ++ox)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const v4f o = swish4(acc[ox][v]);
+            if (live) st4(yb + (size_t)ox * C + 4 * v, o);
+            psum[v] += o;
+        }
+    // squeeze-excite pool: the 7 row sums of a channel group folded in row order (a fixed order)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) red[(row * 32 + cl) * NV + v] = psum[v];
+    __syncthreads();
+    if (tid < 32 && c < C) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            v4f t = red[tid * NV + v];
+#pragma unroll
+            for (int rr = 1; rr < H; ++rr) t += red[(rr * 32 + tid) * NV + v];
+            stg4(P + (size_t)bid.n * C + c + 4 * v, t);
+        }
+    }
+}
+
+template <int K, typename XT>
+static void dw_rows7_launch(const XT* X, const float* W, const float* b, XT* Y, float* P, int n, int C, int* tiles, hipStream_t s) {
+    *tiles = 1;
+    if constexpr (sizeof(XT) == 2) {
+        static const int cpt = getenv("DFD_ROWS7_CPT") ? atoi(getenv("DFD_ROWS7_CPT")) : (K == 5 ? 4 : 8);
+        if (cpt == 8) {
+            const int groups = (C + 255) / 256;
+            hipLaunchKernelGGL((dw_rows7_kernel<K, 8, XT>), dim3(groups * n), dim3(256), 0, s, X, W, b, Y, P, C, groups);
+            return;
+        }
+    }
+    const int groups = (C + 127) / 128;
+    hipLaunchKernelGGL((dw_rows7_kernel<K, 4, XT>), dim3(groups * n), dim3(256), 0, s, X, W, b, Y, P, C, groups);
 }
 
 // tile shapes per B0 depthwise layer class: (k, stride, H_in, C) -> <K,S,CB,TH,TW,RP>
@@ -997,6 +1184,13 @@ bool launch_depthwise(const XT* X, const float* W, const float* bias, XT* Y, flo
         dw_launch<KK, SS, CB, TH, TW, RP, XT>(X, W, bias, Y, P, n, H, C, pad_lo, tiles, s); \
         return true;                                                                   \
     }
+    // 7 x 7 stride-1 layers: the row-per-thread kernel (DFD_DW_ROWS7=0: the LDS-tile kernel, for A/B runs)
+    static const bool rows7 = !(getenv("DFD_DW_ROWS7") && atoi(getenv("DFD_DW_ROWS7")) == 0);
+    if (rows7 && H == 7 && stride == 1 && C % 8 == 0 && (k == 3 || k == 5) && pad_lo == (k - 1) / 2) {
+        if (k == 3) dw_rows7_launch<3, XT>(X, W, bias, Y, P, n, C, tiles, s);
+        else dw_rows7_launch<5, XT>(X, W, bias, Y, P, n, C, tiles, s);
+        return true;
+    }
     DFD_DW_TABLE(DFD_DW_DISPATCH)
 #undef DFD_DW_DISPATCH
     return false;
@@ -1020,6 +1214,28 @@ template bool launch_depthwise<bf16_t>(const bf16_t*, const float*, const float*
     OP(0, 3, 2, 28, 240, 40, 16, 7, 14, 2, 2)              \
     OP(1, 3, 2, 28, 240, 40, 16, 7, 14, 7, 2)
 
+// round 3 variants: + NT (threads per block), INS (pixel tiles enumerate only in-image pixels)
+#define DFD_MB3_TABLE(OP)                                          \
+    OP(6, 3, 1, 56, 144, 24, 16, 14, 28, 7, 1, 256, true)          \
+    OP(7, 3, 1, 56, 144, 24, 16, 28, 28, 7, 1, 512, true)          \
+    OP(8, 3, 1, 56, 144, 24, 16, 14, 28, 7, 1, 512, true)          \
+    OP(9, 3, 1, 56, 144, 24, 48, 14, 28, 7, 1, 256, true)          \
+    OP(10, 3, 1, 56, 144, 24, 16, 28, 28, 7, 1, 512, false)        \
+    OP(6, 5, 2, 56, 144, 24, 16, 7, 14, 7, 1, 256, true)           \
+    OP(7, 5, 2, 56, 144, 24, 16, 14, 14, 7, 1, 512, true)          \
+    OP(8, 5, 2, 56, 144, 24, 16, 14, 14, 2, 1, 512, true)          \
+    OP(6, 5, 1, 28, 240, 40, 16, 28, 28, 7, 2, 256, true)          \
+    OP(7, 5, 1, 28, 240, 40, 16, 28, 28, 7, 2, 512, false)         \
+    OP(8, 5, 1, 28, 240, 40, 16, 28, 28, 7, 2, 512, true)          \
+    OP(9, 5, 1, 28, 240, 40, 16, 14, 28, 7, 2, 256, true)          \
+    OP(10, 5, 1, 28, 240, 40, 16, 14, 28, 7, 2, 512, true)         \
+    OP(11, 5, 1, 28, 240, 40, 16, 14, 28, 7, 2, 512, false)        \
+    OP(12, 5, 1, 28, 240, 40, 16, 14, 28, 7, 2, 256, false)        \
+    OP(6, 3, 2, 28, 240, 40, 16, 7, 14, 2, 2, 256, true)           \
+    OP(7, 3, 2, 28, 240, 40, 16, 14, 14, 2, 2, 512, true)          \
+    OP(8, 3, 2, 28, 240, 40, 16, 14, 14, 7, 2, 512, true)          \
+    OP(9, 3, 2, 28, 240, 40, 16, 14, 14, 7, 2, 256, true)
+
 // first-generation instances still used with fp32 activations where they measure faster (blocks 1, 3, 5:
 // 248 / 183 / 85 us against 329 / 185 / 89 us of the second generation at batch 256; blocks 2 and 4 run the second
 // generation: 214 / 148 us against 263 / 164 us).  With bf16 activations the second generation wins everywhere
@@ -1042,15 +1258,15 @@ static int mb_variant(int H, int stride) {
     return e ? atoi(e) : -2;
 }
 
-template <int K, int S, int CB, int TH, int TW, int RP, int NK, typename XT>
+template <int K, int S, int CB, int TH, int TW, int RP, int NK, typename XT, int NT = 256, bool INS = false, int CI = 0>
 static void mb2_launch(const XT* X, int Cin, const unsigned short* We3, int plane, int Kp, const float* Wef, const float* be,
                        const float* W, const float* b, XT* Y, float* P, int n, int H, int C, int pad_lo, int* tiles, hipStream_t s) {
     const int Ho = (H + S - 1) / S;
     const int tx = (Ho + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
     const int tiles_sp = tx * ty;
     *tiles = tiles_sp;
-    hipLaunchKernelGGL((mbconv2_kernel<K, S, CB, TH, TW, RP, NK, XT>), dim3(tiles_sp * (C / CB), n), dim3(256), 0, s, X, We3,
-                       plane, Kp, Wef, be, W, b, Y, P, H, Ho, C, Cin, pad_lo, tx, tiles_sp);
+    hipLaunchKernelGGL((mbconv2_kernel<K, S, CB, TH, TW, RP, NK, XT, 0, NT, INS, CI>), dim3(tiles_sp * (C / CB) * n), dim3(NT), 0, s, X,
+                       We3, plane, Kp, Wef, be, W, b, Y, P, H, Ho, C, Cin, pad_lo, tx, tiles_sp);
 }
 
 template <typename XT>
@@ -1058,12 +1274,21 @@ bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int 
                          const float* Wd, const float* bd, XT* Y, float* P, int n, int H, int C, int k, int stride,
                          int pad_lo, int* tiles, hipStream_t s) {
     int var = mb_variant(H, stride);
-    if (var == -2) var = (sizeof(XT) == 4 && stride == 2) ? -1 : 0;          // default: see DFD_MB1_TABLE
+    if (var == -2) {
+        // defaults by measurement at batch 256 (profiles/mb_variants.py, round 3, us fp32 / bf16):
+        //   block 1 (112, s2): first generation 237 (second: 261) / variant 0 203
+        //   block 2 (56, s1):  variant 6 (INS) 190 (variant 0: 203) / variant 0 127
+        //   block 3 (56, s2):  first generation 158 (second: 178-254) / variant 0 117
+        //   block 4 (28, s1):  variant 12 (14 x 28 tiles) 122 (whole image: 132) / variant 7 (whole image, 512 threads) 83 (variant 0: 92)
+        //   block 5 (28, s2):  first generation 76 (second: 90) / variant 0 51
+        if (sizeof(XT) == 4) var = stride == 2 ? -1 : (H == 56 ? 6 : 12);
+        else var = (H == 28 && stride == 1) ? 7 : 0;
+    }
     if constexpr (sizeof(XT) == 4) {
         if (var == -1) {
 #define DFD_MB1_DISPATCH(KK, SS, HH, CC, CI, CB, TH, TW, RP, KC, NSUB)                                                \
     if (k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                               \
-        mb_launch<KK, SS, CB, TH, TW, RP, KC, NSUB, XT>(Xin, Cin, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);  \
+        mb_launch<KK, SS, CB, TH, TW, RP, KC, NSUB, XT, CI>(Xin, Cin, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);  \
         return true;                                                                                                \
     }
             DFD_MB1_TABLE(DFD_MB1_DISPATCH)
@@ -1073,23 +1298,30 @@ bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int 
     if (var < 0) var = 0;
 #define DFD_MB2_DISPATCH(VV, KK, SS, HH, CC, CI, CB, TH, TW, RP, NK)                                                 \
     if (var == VV && k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                  \
-        mb2_launch<KK, SS, CB, TH, TW, RP, NK, XT>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s); \
+        mb2_launch<KK, SS, CB, TH, TW, RP, NK, XT, 256, false, CI>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s); \
         return true;                                                                                                \
     }
     DFD_MB2_TABLE(DFD_MB2_DISPATCH)
 #undef DFD_MB2_DISPATCH
+#define DFD_MB3_DISPATCH(VV, KK, SS, HH, CC, CI, CB, TH, TW, RP, NK, NT, INS)                                       \
+    if (var == VV && k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                  \
+        mb2_launch<KK, SS, CB, TH, TW, RP, NK, XT, NT, INS, CI>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s); \
+        return true;                                                                                                \
+    }
+    DFD_MB3_TABLE(DFD_MB3_DISPATCH)
+#undef DFD_MB3_DISPATCH
 #ifdef DFD_MB_ABLATION
 #define DFD_ABL_CASE(A)                                                                                              \
     if (var == 20 + A && H == 56 && stride == 1) {                                                                  \
         const int tx = 2, ty = 4;                                                                                   \
         *tiles = tx * ty;                                                                                           \
-        hipLaunchKernelGGL((mbconv2_kernel<3, 1, 16, 14, 28, 7, 1, XT, A>), dim3(tx * ty * (C / 16), n), dim3(256), 0, s, Xin, \
+        hipLaunchKernelGGL((mbconv2_kernel<3, 1, 16, 14, 28, 7, 1, XT, A, 256, false, 24>), dim3(tx * ty * (C / 16) * n), dim3(256), 0, s, Xin, \
                            We3, plane, Kp, Wef, be, Wd, bd, Y, P, H, 56, C, Cin, pad_lo, tx, tx * ty);              \
         return true;                                                                                                \
     }                                                                                                               \
     if (var == 20 + A && H == 28 && stride == 1) {                                                                  \
         *tiles = 1;                                                                                                 \
-        hipLaunchKernelGGL((mbconv2_kernel<5, 1, 16, 28, 28, 7, 2, XT, A>), dim3(C / 16, n), dim3(256), 0, s, Xin,   \
+        hipLaunchKernelGGL((mbconv2_kernel<5, 1, 16, 28, 28, 7, 2, XT, A, 256, false, 40>), dim3((C / 16) * n), dim3(256), 0, s, Xin,   \
                            We3, plane, Kp, Wef, be, Wd, bd, Y, P, H, 28, C, Cin, pad_lo, 1, 1);                     \
         return true;                                                                                                \
     }
@@ -1111,6 +1343,9 @@ int mbconv_tiles(int H, int C, int k, int stride, int Cin) {
         if (tl > best) best = tl;                                                    \
     }
     DFD_MB2_TABLE(DFD_MB2_TILES)
+#define DFD_MB3_TILES(VV, KK, SS, HH, CC, CI, CB, TH, TW, RP, NK, NT, INS) DFD_MB2_TILES(VV, KK, SS, HH, CC, CI, CB, TH, TW, RP, NK)
+    DFD_MB3_TABLE(DFD_MB3_TILES)
+#undef DFD_MB3_TILES
 #undef DFD_MB2_TILES
 #define DFD_MB1_TILES(KK, SS, HH, CC, CI, CB, TH, TW, RP, KC, NSUB)                  \
     if (k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                \

@@ -208,7 +208,7 @@ int tap_out(dfd_handle* h, B0Tap* tap, const std::string& name, const XT* dev, s
         src = dev;
     }
     DFD_HIP_TRY(h, hipMemcpyAsync(tap->out, src, count * 4, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     tap->count = count;
     return DFD_OK;
 }

@@ -109,7 +109,7 @@ int dfd_comm_init(dfd_handle* h, const void* id, int rank, int world) {
 
 int dfd_comm_destroy(dfd_handle* h) {
     if (!h) return DFD_ERR_ARG;
-    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->stream) stream_sync(h);
     comm_destroy(h);
     return DFD_OK;
 }
@@ -135,7 +135,7 @@ int dfd_vote_allgather(dfd_handle* h, const void* local_records, size_t bytes_pe
     const int nrc = R->AllGather(C.send.p, C.recv.p, bytes_per_rank, kNcclInt8, C.comm, h->stream);
     if (nrc != kNcclSuccess) return fail(h, DFD_ERR_HIP, "ncclAllGather: %s", nerr(R, nrc));
     DFD_HIP_TRY(h, hipMemcpyAsync(all_records_out, C.recv.p, bytes_per_rank * C.world, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;
 }
 

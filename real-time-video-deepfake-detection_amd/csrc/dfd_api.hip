@@ -87,7 +87,7 @@ int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, in
 void destroy_impl(dfd_handle* h) {
     if (!h) return;
     hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->stream) stream_sync(h);
     comm_destroy(h);
     haar_destroy(h);
     forensic_destroy(h);
@@ -103,8 +103,10 @@ void destroy_impl(dfd_handle* h) {
         if (h->slot_free[i]) hipEventDestroy(h->slot_free[i]);
     }
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
+    if (h->jpeg_host) hipHostFree(h->jpeg_host);
     if (h->mailbox) hipHostFree(h->mailbox);
     for (char* p : h->mailbox_old) hipHostFree(p);
+    for (char* p : h->mailbox_old_prev) hipHostFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -172,7 +174,7 @@ int dfd_warmup(dfd_handle* h, int n_crops, int n_frames) {
     if (rc == DFD_OK && n_frames > 0) rc = ssd_warmup(h, n_frames);
     s6_table_set_tuning(h->gemm, false);
     if (rc) return rc;
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;
 }
 
@@ -208,7 +210,7 @@ int dfd_device_alloc(dfd_handle* h, size_t bytes, void** dptr) {
 
 int dfd_device_free(dfd_handle* h, void* dptr) {
     if (!h) return DFD_ERR_ARG;
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     DFD_HIP_TRY(h, hipFree(dptr));
     return DFD_OK;
 }
@@ -216,20 +218,20 @@ int dfd_device_free(dfd_handle* h, void* dptr) {
 int dfd_memcpy_h2d(dfd_handle* h, void* dst, const void* src, size_t bytes) {
     if (!h || (!dst && bytes) || (!src && bytes)) return h ? fail(h, DFD_ERR_ARG, "memcpy_h2d: null pointer") : DFD_ERR_ARG;
     DFD_HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;
 }
 
 int dfd_memcpy_d2h(dfd_handle* h, void* dst, const void* src, size_t bytes) {
     if (!h || (!dst && bytes) || (!src && bytes)) return h ? fail(h, DFD_ERR_ARG, "memcpy_d2h: null pointer") : DFD_ERR_ARG;
     DFD_HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;
 }
 
 int dfd_sync(dfd_handle* h) {
     if (!h) return DFD_ERR_ARG;
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;
 }
 
@@ -269,7 +271,7 @@ int dfd_classify_nchw(dfd_handle* h, const float* nchw_host, int n, float* logit
     const int rc = b0_forward(h, h->in_nchw, n, h->logits, nullptr, nullptr);
     if (rc) return rc;
     DFD_HIP_TRY(h, hipMemcpyAsync(logits_host, h->logits, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;
 }
 
@@ -282,7 +284,7 @@ int dfd_extract_features(dfd_handle* h, const float* nchw_host, int n, float* fe
     const int rc = b0_forward(h, h->in_nchw, n, nullptr, nullptr, nullptr);
     if (rc) return rc;
     DFD_HIP_TRY(h, hipMemcpyAsync(feat_host, h->feat, (size_t)n * 1280 * 4, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;
 }
 
@@ -297,7 +299,7 @@ int dfd_b0_tap(dfd_handle* h, const float* nchw_dev, int n, const char* name, fl
     tap.capacity = capacity;
     const int rc = b0_forward(h, nchw_dev, n, h->logits, &tap, nullptr);
     if (rc) return rc;
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     if (!tap.found) return fail(h, DFD_ERR_ARG, "tap: unknown stage '%s'", name);
     *count = tap.count;
     return DFD_OK;
@@ -319,7 +321,7 @@ int dfd_b0_profile_end(dfd_handle* h, float* ms_sum, const char** names, int max
     if (!h) return DFD_ERR_ARG;
     if (!ms_sum || !names || !count || !steps) return fail(h, DFD_ERR_ARG, "profile_end: null pointer");
     h->prof.enabled = false;
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     const int nsteps = h->prof_steps;
     const size_t per = nsteps > 0 ? h->prof.events.size() / nsteps : 0;   // marks per forward
     int k = 0;

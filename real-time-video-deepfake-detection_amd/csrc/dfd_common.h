@@ -88,8 +88,9 @@ struct dfd_handle {
     // dfd_analyze_frames_host: copy stream + two staging slots (uploads overlap the previous batch's compute)
     // pinned mailbox for the small host<->device transfers of the batch path (mailbox_* below)
     char* mailbox = nullptr;
-    size_t mailbox_cap = 0, mailbox_head = 0;
-    std::vector<char*> mailbox_old;
+    size_t mailbox_cap = 0, mailbox_head = 0, mailbox_lap_end = 0;
+    size_t mailbox_live = 0, mailbox_live_prev = 0;   // bytes handed out since the last / between the last two stream_sync
+    std::vector<char*> mailbox_old, mailbox_old_prev; // replaced blocks: freed two stream_syncs after their retirement
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr};
     dfd::DevBuf stage[2];
@@ -119,6 +120,8 @@ struct dfd_handle {
     bool act_bf16 = false;               // classifier activations stored as bf16 (fp32 arithmetic): configs[3]
     int bf16_planes = 3;                 // weight planes the bf16-activation GEMMs use: 3 = fp32-exact weights, 1 = bf16 weights
     dfd::DevBuf jpeg_work;               // dfd_decode_jpeg: coefficients, component planes, quantisation tables
+    void* jpeg_host = nullptr;           // pinned host buffer the entropy decoder writes the coefficients into
+    size_t jpeg_host_cap = 0;
     dfd::DevBuf tap_buf;                 // fp32 staging for taps of bf16 buffers
     std::map<const float*, unsigned short*> wsplit;   // fp32 weight tensor -> its three-plane bf16 split
     dfd::S6Table* gemm = nullptr;        // split-GEMM tile per shape (measured by dfd_warmup, heuristic otherwise)
@@ -150,6 +153,9 @@ int ensure(dfd_handle* h, DevBuf* b, size_t bytes);
 // max(upload, compute)).  A copy kernel moves them through a pinned, device-visible mailbox instead.
 //   mailbox_h2d: `src` is copied into the mailbox before the call returns (reusable at once); the device copy is enqueued.
 //   mailbox_d2h: enqueues the copy and returns the host address that holds the data once the stream is synchronised.
+// Every wait on the handle's stream goes through stream_sync: it is the point after which mailbox regions handed out
+// before the PREVIOUS sync can be reused (the host reads a d2h region right after the sync that completes it).
+hipError_t stream_sync(dfd_handle* h);
 int mailbox_h2d(dfd_handle* h, void* dst_dev, const void* src, size_t bytes);
 const void* mailbox_d2h(dfd_handle* h, const void* src_dev, size_t bytes);
 // builds h->color from the "lut.*" tensors of the blob (imgproc_api.hip)
@@ -168,7 +174,15 @@ int preprocess_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int 
                    int apply_clahe, const size_t* frame_offs = nullptr);
 // DetectionOutput of `n` frames already resized to 300x300 -> rows/count on the host
 int detect_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes,
-                     float conf_thr, int max_faces, int32_t* xywh_out, int* n_out);
+                     float conf_thr, int max_faces, int32_t* xywh_out, int* n_out, int* n_total_out = nullptr);
+// the analyzer over n consecutive frames of ONE stream (its temporal state advances n frames): frame i scored in full
+// or fast mode as full[i] says - results identical to n forensics_run calls in order
+int forensics_stream_batch_run(dfd_handle* h, int stream_id, const uint8_t* frames_dev, int n, int hh, int ww, int stride,
+                               size_t frame_bytes, const int* full, double* scores_out, double* prob_out);
+// jpeg_decode.hip: n JPEGs of one size -> packed BGR frames [n][hh][ww][3] at frames_dev (entropy decoding of the files
+// in parallel on the host pool, one coefficient upload, IDCT / colour per frame).  *hh / *ww: in = expected size or 0
+int jpeg_decode_batch_to(dfd_handle* h, const uint8_t* const* jpegs, const size_t* lens, int n, uint8_t* frames_dev_or_null,
+                         int* hh, int* ww);
 // stateless six-signal forensic probability of `n` device frames (temporal signal = first-frame value 0)
 int forensics_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes,
                         double* prob_out, double* scores_out);

@@ -149,7 +149,7 @@ int forensics_run(dfd_handle* h, int stream_id, const uint8_t* frame_dev, int hh
     }
     if (S.has_prev) DFD_HIP_TRY(h, hipMemcpyAsync(dpart, F.diff_part, sizeof dpart, hipMemcpyDeviceToHost, h->stream));
     DFD_HIP_TRY(h, hipMemcpyAsync(S.prev_gray, F.buf.gray, 65536, hipMemcpyDeviceToDevice, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     DFD_HIP_TRY(h, hipGetLastError());
 
     const double nan = std::nan("");
@@ -201,6 +201,82 @@ int forensics_run(dfd_handle* h, int stream_id, const uint8_t* frame_dev, int hh
     return DFD_OK;
 }
 
+// n consecutive frames of one stream in one launch set (POST /analyze_batch): the device statistics of all frames at
+// once (full mode kernels when any frame is full), frame 0 differenced against the stream's stored gray plane and
+// frame i against frame i - 1, then the host half of forensics_run replayed frame by frame in order - the temporal
+// deque, the frame counter and the stored plane end exactly where n single calls would leave them.
+int forensics_stream_batch_run(dfd_handle* h, int stream_id, const uint8_t* frames_dev, int n, int hh, int ww, int stride,
+                               size_t frame_bytes, const int* full, double* scores_out, double* prob_out) {
+    if (!h->has_color) return fail(h, DFD_ERR_STATE, "forensics needs the colour tables (blob packed without luts)");
+    int rc = state_init(h, n);
+    if (rc) return rc;
+    ForensicState& F = *h->forensic;
+    ForensicStream& S = F.streams[stream_id];
+    if (!S.prev_gray) {
+        DFD_HIP_TRY(h, hipMalloc(&S.prev_gray, 65536));
+        h->owned.push_back(S.prev_gray);
+    }
+    bool any_full = false;
+    for (int f = 0; f < n; ++f) any_full = any_full || full[f] != 0;
+    if ((rc = ensure(h, &F.pair_idx, (size_t)n * 4))) return rc;
+    if ((rc = ensure(h, &F.pair_part, (size_t)n * 256 * 8))) return rc;
+    std::vector<int32_t> prev(n);
+    for (int f = 0; f < n; ++f) prev[f] = f - 1;                   // frame 0: the stored plane (below)
+    if ((rc = mailbox_h2d(h, F.pair_idx.p, prev.data(), (size_t)n * 4))) return rc;
+    launch_resize_bgr(frames_dev, n, hh, ww, stride, frame_bytes, F.buf.rs, 256, 256, h->stream);
+    launch_forensics(F.buf, n, any_full, h->color, F.twiddle, h->stream);
+    const bool had_prev = S.has_prev;
+    if (had_prev) launch_absdiff(F.buf.gray, (const uint8_t*)S.prev_gray, F.diff_part, h->stream);
+    if (n > 1) launch_absdiff_pairs(F.buf.gray, (const int*)F.pair_idx.p, (double*)F.pair_part.p, n, h->stream);
+    const double* st = (const double*)mailbox_d2h(h, F.buf.stats, (size_t)n * FORENSIC_STATS * 8);
+    const double* noise = (const double*)mailbox_d2h(h, F.buf.stats_noise, (size_t)n * 64 * 8);
+    const double* ela = (const double*)mailbox_d2h(h, F.buf.stats_ela, (size_t)n * 64 * 8);
+    const double* part = (const double*)mailbox_d2h(h, F.pair_part.p, (size_t)n * 256 * 8);
+    const double* part0 = (const double*)mailbox_d2h(h, F.diff_part, 256 * 8);
+    if (!st || !noise || !ela || !part || !part0) return fail(h, DFD_ERR_HIP, "forensics: mailbox allocation failed");
+    DFD_HIP_TRY(h, hipMemcpyAsync(S.prev_gray, F.buf.gray + (size_t)(n - 1) * 65536, 65536, hipMemcpyDeviceToDevice, h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
+    DFD_HIP_TRY(h, hipGetLastError());
+    for (int f = 0; f < n; ++f) {
+        S.frame_count += 1;
+        const bool fl = full[f] != 0;
+        double sc[6], ex[10];
+        static_scores(&st[(size_t)f * FORENSIC_STATS], &noise[(size_t)f * 64], &ela[(size_t)f * 64], fl, sc, ex);
+        if (!S.has_prev) {
+            S.has_prev = true;
+        } else {
+            const double* dp = f == 0 ? part0 : part + (size_t)f * 256;
+            double sum = 0;
+            for (int i = 0; i < 256; ++i) sum += dp[i];
+            const double mean_diff = sum / 65536.0;
+            S.diffs.push_back(mean_diff);
+            if (S.diffs.size() > 30) S.diffs.pop_front();
+            if (S.diffs.size() >= 5) {
+                std::vector<double> d(S.diffs.begin(), S.diffs.end());
+                double dm;
+                const double temporal_cv = pop_std(d.data(), (int)d.size(), &dm) / (dm + 1e-10);
+                double s = 0.0;
+                if (temporal_cv > 1.5) s += 0.4; else if (temporal_cv > 1.0) s += 0.2;
+                if (mean_diff < 0.3 && S.frame_count > 10) s += 0.3;
+                else if (mean_diff < 0.8 && S.frame_count > 10) s += 0.1;
+                sc[5] = clip01(s);
+            }
+        }
+        double comb = 0.0;
+        if (fl) {
+            const double w[6] = {0.25, 0.20, 0.20, 0.15, 0.10, 0.10};
+            for (int i = 0; i < 6; ++i) comb += sc[i] * w[i];
+        } else {
+            comb += sc[0] * 0.45;
+            comb += sc[5] * 0.25;
+            comb += sc[3] * 0.30;
+        }
+        for (int i = 0; i < 6; ++i) scores_out[(size_t)f * 6 + i] = sc[i];
+        prob_out[f] = clip01(comb);
+    }
+    return DFD_OK;
+}
+
 // Stateless batch variant for throughput runs: n device frames -> six-signal probability each, the
 // temporal signal taking its first-frame value 0 (frame_analysis.py:358-360).  One launch set for all frames.
 int forensics_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes,
@@ -216,7 +292,7 @@ int forensics_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh,
     const double* noise = (const double*)mailbox_d2h(h, F.buf.stats_noise, (size_t)n * 64 * 8);
     const double* ela = (const double*)mailbox_d2h(h, F.buf.stats_ela, (size_t)n * 64 * 8);
     if (!st || !noise || !ela) return fail(h, DFD_ERR_HIP, "forensics: mailbox allocation failed");
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     DFD_HIP_TRY(h, hipGetLastError());
     const double w[6] = {0.25, 0.20, 0.20, 0.15, 0.10, 0.10};
     for (int f = 0; f < n; ++f) {
@@ -261,6 +337,7 @@ int dfd_forensic_signals_device(dfd_handle* h, const uint8_t* frames_dev, int n,
         if (prev_index[f] < -2 || (prev_index[f] == -2 && f < ns))
             return fail(h, DFD_ERR_ARG, "forensic_signals: predecessor-only frames (-2) must be the tail of the batch");
     }
+    if (ns == 0) return fail(h, DFD_ERR_ARG, "forensic_signals: every frame of the batch is predecessor-only (-2): nothing to compute");
     if (!h->has_color) return fail(h, DFD_ERR_STATE, "forensics needs the colour tables (blob packed without luts)");
     DFD_HIP_TRY(h, hipSetDevice(h->device));
     int rc = state_init(h, n);
@@ -279,7 +356,7 @@ int dfd_forensic_signals_device(dfd_handle* h, const uint8_t* frames_dev, int n,
     const double* ela = (const double*)mailbox_d2h(h, F.buf.stats_ela, nz * 64 * 8);
     const double* part = (const double*)mailbox_d2h(h, F.pair_part.p, nz * 256 * 8);
     if (!st || !noise || !ela || !part) return fail(h, DFD_ERR_HIP, "forensics: mailbox allocation failed");
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     DFD_HIP_TRY(h, hipGetLastError());
     for (int f = ns; f < n; ++f) {                           // predecessor-only frames: no signals
         for (int i = 0; i < 5; ++i) scores5_out[(size_t)f * 5 + i] = -1.0;

@@ -171,7 +171,7 @@ extern "C" int dfd_frequency_features(dfd_handle* h, const uint8_t* img, int hh,
     hipLaunchKernelGGL(minmax_norm_kernel, dim3(nb), dim3(256), 0, s, o1, part, nb);
     DFD_HIP_TRY(h, hipMemcpyAsync(out, o0, PL * 4, hipMemcpyDeviceToHost, s));
     DFD_HIP_TRY(h, hipMemcpyAsync(out + PL, o1, PL * 4, hipMemcpyDeviceToHost, s));
-    DFD_HIP_TRY(h, hipStreamSynchronize(s));
+    DFD_HIP_TRY(h, stream_sync(h));
     DFD_HIP_TRY(h, hipGetLastError());
     return DFD_OK;
 }

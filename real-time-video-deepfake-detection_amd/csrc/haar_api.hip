@@ -300,7 +300,7 @@ int haar_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride
     }
     int count = 0;
     DFD_HIP_TRY(h, hipMemcpyAsync(&count, S->count.p, 4, hipMemcpyDeviceToHost, s));
-    DFD_HIP_TRY(h, hipStreamSynchronize(s));
+    DFD_HIP_TRY(h, stream_sync(h));
     DFD_HIP_TRY(h, hipGetLastError());
     if (count > CAP) return fail(h, DFD_ERR_CAPACITY, "detect_faces_haar: %d candidate windows exceed the buffer of %d", count, CAP);
     std::vector<int> cand((size_t)count * 3);

@@ -14,24 +14,61 @@ __global__ __launch_bounds__(256) void mailbox_copy_kernel(unsigned* __restrict_
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
+hipError_t stream_sync(dfd_handle* h) {
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    // regions handed out before the previous sync have been copied from (h2d) and read by the host (d2h, read right
+    // after the sync that completed them): only the last two generations stay live
+    h->mailbox_live_prev = h->mailbox_live;
+    h->mailbox_live = 0;
+    for (char* p : h->mailbox_old_prev) hipHostFree(p);
+    h->mailbox_old_prev.swap(h->mailbox_old);
+    h->mailbox_old.clear();
+    return e;
+}
+
 static char* mailbox_alloc(dfd_handle* h, size_t bytes) {
     constexpr size_t kCap = 8u << 20;
     bytes = (bytes + 255) & ~(size_t)255;
-    // bump allocation; every entry point synchronises the stream before it returns, so a wrap-around only meets regions
-    // of earlier calls.  A call that needs more than the current block gets a new, larger one (the old blocks stay
-    // alive until the handle is destroyed: pointers handed out earlier in the same call remain valid).
-    if (!h->mailbox || bytes > h->mailbox_cap / 8) {       // a call makes at most a handful of requests
-        const size_t cap = std::max(kCap, bytes * 16);
+    // Bump allocation in a ring.  Live = what was handed out since the sync before last (mailbox_live +
+    // mailbox_live_prev bytes ending at the head, continuing below mailbox_lap_end after a wrap).  A wrap-around to
+    // offset 0 is taken only when the new region ends before the live span starts; otherwise - and for a request above
+    // an eighth of the block - a new, larger block replaces this one (the old block stays allocated until two syncs
+    // later: pointers into it remain valid).
+    const size_t live = h->mailbox_live + h->mailbox_live_prev;
+    bool grow = !h->mailbox || bytes > h->mailbox_cap / 8;
+    if (!grow) {
+        if (live > h->mailbox_head) {
+            // the live span reaches back into the previous lap: [lap_end - (live - head), lap_end)
+            if (h->mailbox_head + bytes > h->mailbox_lap_end - (live - h->mailbox_head)) grow = true;
+        } else if (h->mailbox_head + bytes > h->mailbox_cap) {
+            if (bytes <= h->mailbox_head - live) { h->mailbox_lap_end = h->mailbox_head; h->mailbox_head = 0; }
+            else grow = true;
+        }
+    }
+    if (grow && h->mailbox && bytes <= h->mailbox_cap / 8 && h->mailbox_cap >= ((size_t)256 << 20)) {
+        // a caller that never waits on the stream between requests: wait for it here rather than grow without bound
+        // (two generations retire: nothing handed out so far is still in flight; the caller's own unread d2h regions
+        // are the ones just completed and sit behind the head)
+        stream_sync(h);
+        stream_sync(h);
+        h->mailbox_lap_end = h->mailbox_head;
+        if (h->mailbox_head + bytes > h->mailbox_cap) h->mailbox_head = 0;
+        grow = false;
+    }
+    if (grow) {
+        const size_t cap = std::max(std::max(kCap, bytes * 16), h->mailbox ? h->mailbox_cap * 2 : (size_t)0);
         char* p = nullptr;
         if (hipHostMalloc((void**)&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
         if (h->mailbox) h->mailbox_old.push_back(h->mailbox);
         h->mailbox = p;
         h->mailbox_cap = cap;
         h->mailbox_head = 0;
+        h->mailbox_lap_end = 0;
+        h->mailbox_live = h->mailbox_live_prev = 0;                // the live span stayed behind in the old block
     }
-    if (h->mailbox_head + bytes > h->mailbox_cap) h->mailbox_head = 0;
     char* p = h->mailbox + h->mailbox_head;
     h->mailbox_head += bytes;
+    h->mailbox_live += bytes;
     return p;
 }
 
@@ -46,7 +83,7 @@ int mailbox_h2d(dfd_handle* h, void* dst_dev, const void* src, size_t bytes) {
     char* p = mailbox_alloc(h, bytes);
     if (!p) {                                               // larger than the mailbox: the DMA path
         DFD_HIP_TRY(h, hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, h->stream));
-        DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        DFD_HIP_TRY(h, stream_sync(h));
         return DFD_OK;
     }
     memcpy(p, src, bytes);
@@ -64,7 +101,7 @@ const void* mailbox_d2h(dfd_handle* h, const void* src_dev, size_t bytes) {
 
 int ensure(dfd_handle* h, DevBuf* b, size_t bytes) {
     if (bytes <= b->cap) return DFD_OK;
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     if (b->p) {
         DFD_HIP_TRY(h, hipFree(b->p));
         for (auto& o : h->owned)
@@ -275,7 +312,7 @@ int analyze_frame_resident(dfd_handle* h, int stream_id, int hh, int ww, int str
         if ((rc = preprocess_on_device(h, fd, hh, ww, stride, xywh_out + (size_t)start * 4, m, apply_clahe))) return rc;
         if ((rc = b0_forward(h, h->in_nchw, m, h->logits, nullptr, nullptr))) return rc;
         DFD_HIP_TRY(h, hipMemcpyAsync(logits_out + start, h->logits, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
-        DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        DFD_HIP_TRY(h, stream_sync(h));
         for (int i = 0; i < m; ++i)
             if (!h->crop_valid[i]) logits_out[start + i] = NAN;      // MTCNN found no face in this crop
     }
@@ -307,7 +344,7 @@ int dfd_tta_augment(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int strid
     launch_tta_augment((const uint8_t*)h->frame_buf.p, hh, ww, stride, flip ? 1 : 0, (float)brightness, M, (uint8_t*)h->u8_out.p,
                        h->stream);
     DFD_HIP_TRY(h, hipMemcpyAsync(out, h->u8_out.p, (size_t)hh * ww * 3, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;
 }
 
@@ -320,7 +357,7 @@ int dfd_resize_bgr(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride
     if ((rc = ensure(h, &h->u8_out, (size_t)dh * dw * 3))) return rc;
     launch_resize_bgr((const uint8_t*)h->frame_buf.p, 1, hh, ww, stride, 0, (uint8_t*)h->u8_out.p, dh, dw, h->stream);
     DFD_HIP_TRY(h, hipMemcpyAsync(out, h->u8_out.p, (size_t)dh * dw * 3, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;
 }
 
@@ -343,7 +380,7 @@ int dfd_preprocess_face_quality(dfd_handle* h, const uint8_t* bgr, int hh, int w
     launch_clahe((const uint8_t*)h->frame_buf.p, stride, (const CropDesc*)h->desc_buf.p, 1, (uint8_t*)h->lab_buf.p,
                  (uint8_t*)h->lut_buf.p, (uint8_t*)h->crop_buf.p, h->color, mp, h->stream);
     DFD_HIP_TRY(h, hipMemcpyAsync(out, h->crop_buf.p, (size_t)hh * ww * 3, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;
 }
 
@@ -356,7 +393,7 @@ int dfd_preprocess_crops(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int 
     if (rc) return rc;
     if ((rc = preprocess_on_device(h, (const uint8_t*)h->frame_buf.p, hh, ww, stride, xywh, n, apply_clahe))) return rc;
     DFD_HIP_TRY(h, hipMemcpyAsync(nchw_out, h->in_nchw, (size_t)n * 3 * 224 * 224 * 4, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;
 }
 
@@ -370,7 +407,7 @@ int dfd_classify_crops(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int st
     if ((rc = preprocess_on_device(h, (const uint8_t*)h->frame_buf.p, hh, ww, stride, xywh, n, apply_clahe))) return rc;
     if ((rc = b0_forward(h, h->in_nchw, n, h->logits, nullptr, nullptr))) return rc;
     DFD_HIP_TRY(h, hipMemcpyAsync(logits_out, h->logits, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     for (int i = 0; i < n; ++i)
         if (!h->crop_valid[i]) logits_out[i] = NAN;      // MTCNN found no face in this crop
     return DFD_OK;

@@ -18,6 +18,10 @@ __device__ __forceinline__ v4f swish4(v4f v) {
 }
 __device__ __forceinline__ v4f ldg4(const float* p) { return *reinterpret_cast<const v4f*>(p); }
 __device__ __forceinline__ void stg4(float* p, v4f v) { *reinterpret_cast<v4f*>(p) = v; }
+// 16 / 8 bytes from a 4-byte aligned address (global memory takes dword-aligned dwordx4 / dwordx2 loads)
+typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float v2f_u __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ v4f ldg4u(const float* p) { return *reinterpret_cast<const v4f_u*>(p); }
 
 // Activation storage type XT = float (fp32 path) or bf16_t ("bf16_activations": every activation tensor that
 // reaches HBM is bf16, all arithmetic and every accumulator stays fp32).  ld4 / st4 move 4 consecutive channels
@@ -70,6 +74,7 @@ __device__ __forceinline__ void split8(const v4f lo, const v4f hi, bf8& s0, bf8&
 // its use and the wait names the registers it releases.
 typedef float sf16 __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f ldg2(const float* p) { return *reinterpret_cast<const v2f_u*>(p); }
 template <int BYTE_OFF>
 __device__ __forceinline__ sf16 sload16(const float* p) {
     sf16 v;

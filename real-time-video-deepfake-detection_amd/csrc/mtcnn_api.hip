@@ -313,7 +313,7 @@ struct Cascade {
         const float* p = (const float*)mailbox_d2h(h, dev, floats * 4);
         if (!p) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
         DFD_HIP_TRY(h, hipGetLastError());
-        DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        DFD_HIP_TRY(h, stream_sync(h));
         std::copy(p, p + floats, out->begin());
         return DFD_OK;
     }
@@ -406,12 +406,12 @@ struct Cascade {
             // through the mailbox; the atomic append order is restored to (level, y, x) by sorting on the cell
             const unsigned* pc = (const unsigned*)mailbox_d2h(h, d_count, 4);
             if (!pc) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
-            DFD_HIP_TRY(h, hipStreamSynchronize(s));
+            DFD_HIP_TRY(h, stream_sync(h));
             const size_t nc = std::min<size_t>(*pc, (size_t)cells);
             if (nc) {
                 const MtCand* pr = (const MtCand*)mailbox_d2h(h, d_cand, nc * sizeof(MtCand));
                 if (!pr) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
-                DFD_HIP_TRY(h, hipStreamSynchronize(s));
+                DFD_HIP_TRY(h, stream_sync(h));
                 cands.assign(pr, pr + nc);
             }
             std::sort(cands.begin(), cands.end(), [](const MtCand& a, const MtCand& b) { return a.cell < b.cell; });
@@ -539,7 +539,7 @@ struct Cascade {
             const float* rr = (const float*)mailbox_d2h(h, S->reg.p, (size_t)m * 16);
             if (!pp || !rr) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
             DFD_HIP_TRY(h, hipGetLastError());
-            DFD_HIP_TRY(h, hipStreamSynchronize(s));
+            DFD_HIP_TRY(h, stream_sync(h));
             prob->insert(prob->end(), pp, pp + m);
             reg->insert(reg->end(), rr, rr + (size_t)m * 4);
         }
@@ -739,7 +739,7 @@ int mtcnn_align_batch_device(dfd_handle* h, const MtImage* imgs, int n, uint8_t*
     if ((rc = ensure(h, &S->tmp, std::max<size_t>(tmp_bytes, 16)))) return rc;
     launch_mt_extract_faces((const MtFaceJob*)S->bnd.p, n, (const int*)S->coef.p, faces_out, (uint8_t*)S->tmp.p, s);
     DFD_HIP_TRY(h, hipGetLastError());
-    DFD_HIP_TRY(h, hipStreamSynchronize(s));          // `tables` / `jobs` (host) feed the copies above
+    DFD_HIP_TRY(h, stream_sync(h));          // `tables` / `jobs` (host) feed the copies above
     return DFD_OK;
 }
 
@@ -789,7 +789,7 @@ int dfd_mtcnn_align(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int strid
         if ((rc = ensure(h, &h->mtcnn->in, 3 * 160 * 160 * 4))) return rc;
         launch_mt_face_chw(mtcnn_face_dev(h), (float*)h->mtcnn->in.p, 160 * 160, h->stream);
         DFD_HIP_TRY(h, hipMemcpyAsync(face_chw_out, h->mtcnn->in.p, 3 * 160 * 160 * 4, hipMemcpyDeviceToHost, h->stream));
-        DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        DFD_HIP_TRY(h, stream_sync(h));
     }
     return DFD_OK;
 }

@@ -58,8 +58,97 @@ int dfd_analyze_batch_device(dfd_handle* h, const uint8_t* frames_dev, int n, in
         const float* lg = (const float*)mailbox_d2h(h, h->logits, (size_t)m * 4);
         if (!lg) return fail(h, DFD_ERR_HIP, "analyze_batch: mailbox allocation failed");
         DFD_HIP_TRY(h, hipGetLastError());
-        DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        DFD_HIP_TRY(h, stream_sync(h));
         for (int i = 0; i < m; ++i) logits[start + i] = h->crop_valid[i] ? lg[i] : NAN;      // NaN: MTCNN found no face in this crop
+    }
+    int k = 0;
+    for (int f = 0; f < n; ++f)
+        for (int i = 0; i < n_faces_out[f]; ++i) logits_out[(size_t)f * max_faces + i] = logits[k++];
+    return DFD_OK;
+}
+
+
+// ---- POST /analyze_batch: n consecutive frames of ONE stream in one call -----------------------------------------
+// The per-frame flow of dfd_analyze_frame / dfd_analyze_jpeg (reference backend_server.py:147-164: forensics with the
+// stream's temporal state and the caller's full / fast schedule, detector - SSD or the Haar fallback - and the first
+// max_faces faces of every frame classified), with every stage batched over the request's frames: the JPEG parts are
+// entropy-decoded in parallel on the host pool and turned into frames on the device (raw BGR parts are uploaded),
+// then ONE forensic launch set, ONE detector pass, ONE classifier batch.  Results equal n single calls in order.
+// data[i] / len[i]: the bytes of a JPEG (len[i] > 0) or a packed BGR frame of hh x ww (len[i] = 0).
+int dfd_analyze_stream_batch(dfd_handle* h, int stream_id, int n, const uint8_t* const* data, const size_t* len, int hh, int ww,
+                             const int* full_forensics, float conf_thr, int max_faces, int apply_clahe, double* scores_out,
+                             double* forensic_prob_out, int32_t* xywh_out, int* n_faces_out, int* n_detected_out,
+                             float* logits_out, int* height_out, int* width_out) {
+    if (!h) return DFD_ERR_ARG;
+    if (n <= 0 || !data || !len || !full_forensics || max_faces <= 0 || !scores_out || !forensic_prob_out || !xywh_out ||
+        !n_faces_out || !logits_out)
+        return fail(h, DFD_ERR_ARG, "analyze_stream_batch: bad pointer or count");
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    int rc;
+    // frame size: from the JPEG headers when there is a JPEG part, else the caller's
+    std::vector<const uint8_t*> jp;
+    std::vector<size_t> jl;
+    std::vector<int> jidx;
+    for (int i = 0; i < n; ++i) {
+        if (!data[i]) return fail(h, DFD_ERR_ARG, "analyze_stream_batch: frame %d is null", i);
+        if (len[i]) { jp.push_back(data[i]); jl.push_back(len[i]); jidx.push_back(i); }
+    }
+    if (jp.size() != (size_t)n && (hh <= 0 || ww <= 0)) return fail(h, DFD_ERR_ARG, "analyze_stream_batch: raw frames need hh and ww");
+    if (!jp.empty() && (rc = jpeg_decode_batch_to(h, jp.data(), jl.data(), (int)jp.size(), nullptr, &hh, &ww))) return rc;
+    if (height_out) *height_out = hh;
+    if (width_out) *width_out = ww;
+    const int stride = ww * 3;
+    const size_t frame_bytes = (size_t)hh * stride;
+    if ((rc = ensure(h, &h->stage[0], (size_t)n * frame_bytes))) return rc;
+    uint8_t* frames = static_cast<uint8_t*>(h->stage[0].p);
+    for (int i = 0; i < n; ++i)
+        if (!len[i]) DFD_HIP_TRY(h, hipMemcpyAsync(frames + (size_t)i * frame_bytes, data[i], frame_bytes, hipMemcpyHostToDevice, h->stream));
+    if (!jp.empty()) {
+        if (jp.size() == (size_t)n) {
+            if ((rc = jpeg_decode_batch_to(h, jp.data(), jl.data(), n, frames, &hh, &ww))) return rc;
+        } else {                                                     // mixed request: the JPEG parts one by one into their slots
+            for (size_t k = 0; k < jp.size(); ++k)
+                if ((rc = jpeg_decode_batch_to(h, &jp[k], &jl[k], 1, frames + (size_t)jidx[k] * frame_bytes, &hh, &ww))) return rc;
+        }
+    }
+    if ((rc = forensics_stream_batch_run(h, stream_id, frames, n, hh, ww, stride, frame_bytes, full_forensics, scores_out,
+                                         forensic_prob_out)))
+        return rc;
+    for (int f = 0; f < n; ++f) n_faces_out[f] = 0;
+    if (n_detected_out) for (int f = 0; f < n; ++f) n_detected_out[f] = 0;
+    h->last_detections = 0;
+    if ((!h->ssd && !h->haar) || hh < 30 || ww < 30) return DFD_OK;
+    std::vector<int> total(n, 0);
+    rc = h->ssd ? detect_batch_run(h, frames, n, hh, ww, stride, frame_bytes, conf_thr, max_faces, xywh_out, n_faces_out, total.data())
+                : DFD_ERR_STATE;
+    if (rc) {                                                        // reference face_detection.py:58-66
+        if (!h->haar) return rc;
+        for (int f = 0; f < n; ++f)
+            if ((rc = haar_run(h, frames + (size_t)f * frame_bytes, hh, ww, stride, 1.1f, 5, 30, xywh_out + (size_t)f * max_faces * 4,
+                               max_faces, &n_faces_out[f], nullptr, &total[f])))
+                return rc;
+    }
+    if (n_detected_out) for (int f = 0; f < n; ++f) n_detected_out[f] = total[f];
+    h->last_detections = total[n - 1];
+    std::vector<int32_t> boxes;
+    std::vector<size_t> offs;
+    for (int f = 0; f < n; ++f)
+        for (int i = 0; i < n_faces_out[f]; ++i) {
+            for (int c = 0; c < 4; ++c) boxes.push_back(xywh_out[((size_t)f * max_faces + i) * 4 + c]);
+            offs.push_back((size_t)f * frame_bytes);
+        }
+    const int ncrops = (int)offs.size();
+    std::vector<float> logits(ncrops);
+    for (int start = 0; start < ncrops; start += h->max_batch) {
+        const int m = std::min(h->max_batch, ncrops - start);
+        if ((rc = preprocess_run(h, frames, hh, ww, stride, boxes.data() + (size_t)start * 4, m, apply_clahe, offs.data() + start)))
+            return rc;
+        if ((rc = b0_forward(h, h->in_nchw, m, h->logits, nullptr, nullptr))) return rc;
+        const float* lg = (const float*)mailbox_d2h(h, h->logits, (size_t)m * 4);
+        if (!lg) return fail(h, DFD_ERR_HIP, "analyze_stream_batch: mailbox allocation failed");
+        DFD_HIP_TRY(h, hipGetLastError());
+        DFD_HIP_TRY(h, stream_sync(h));
+        for (int i = 0; i < m; ++i) logits[start + i] = h->crop_valid[i] ? lg[i] : NAN;
     }
     int k = 0;
     for (int f = 0; f < n; ++f)
@@ -127,7 +216,7 @@ int dfd_analyze_frames_host(dfd_handle* h, const uint8_t* frames_host, int n_tot
         if (rc) return rc;
         DFD_HIP_TRY(h, hipEventRecord(h->slot_free[slot], h->stream));
     }
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;
 }
 

@@ -282,7 +282,7 @@ int ssd_forward(dfd_handle* h, const uint8_t* in300, int n, const char* tap_name
         const size_t cnt = (size_t)n * t.size * t.size * t.c;
         if (cnt > tap_cap) return fail(h, DFD_ERR_ARG, "detector tap '%s' needs %zu floats", tap_name, cnt);
         DFD_HIP_TRY(h, hipMemcpyAsync(tap_out, ptr(name), cnt * 4, hipMemcpyDeviceToHost, s));
-        DFD_HIP_TRY(h, hipStreamSynchronize(s));
+        DFD_HIP_TRY(h, stream_sync(h));
         *tap_count = cnt;
         tapped = true;
         return DFD_OK;
@@ -353,7 +353,7 @@ int ssd_forward(dfd_handle* h, const uint8_t* in300, int n, const char* tap_name
         const size_t cnt = (size_t)n * S->n_priors * (tn == "boxes" ? 4 : 1);
         if (cnt > tap_cap) return fail(h, DFD_ERR_ARG, "detector tap '%s' needs %zu floats", tap_name, cnt);
         DFD_HIP_TRY(h, hipMemcpyAsync(tap_out, srcp, cnt * 4, hipMemcpyDeviceToHost, s));
-        DFD_HIP_TRY(h, hipStreamSynchronize(s));
+        DFD_HIP_TRY(h, stream_sync(h));
         *tap_count = cnt;
     }
     DFD_HIP_TRY(h, hipGetLastError());
@@ -371,7 +371,7 @@ int ssd_warmup(dfd_handle* h, int n) {
     uint32_t st = 12345u;
     for (size_t i = 0; i < bytes; ++i) { st = st * 1664525u + 1013904223u; pat[i] = (uint8_t)(50 + ((st >> 24) * 150 >> 8)); }
     DFD_HIP_TRY(h, hipMemcpyAsync(h->ssd->in_u8.p, pat.data(), bytes, hipMemcpyHostToDevice, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     return ssd_forward(h, (const uint8_t*)h->ssd->in_u8.p, n, nullptr, nullptr, 0, nullptr);
 }
 
@@ -418,15 +418,16 @@ int detect_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stri
     int cnt = 0;
     DFD_HIP_TRY(h, hipMemcpyAsync(&cnt, h->ssd->count.p, 4, hipMemcpyDeviceToHost, h->stream));
     DFD_HIP_TRY(h, hipMemcpyAsync(rows, h->ssd->rows.p, sizeof rows, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     *n_out = ssd_postprocess(rows, cnt, hh, ww, conf_thr, xywh_out, conf_out, max_out, &h->last_detections);
     return DFD_OK;
 }
 
 // the same for n frames resident in HBM (frame f at frames_dev + f * frame_bytes): one launch set
 int detect_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes,
-                     float conf_thr, int max_faces, int32_t* xywh_out, int* n_out) {
+                     float conf_thr, int max_faces, int32_t* xywh_out, int* n_out, int* n_total_out) {
     for (int f = 0; f < n; ++f) n_out[f] = 0;
+    if (n_total_out) for (int f = 0; f < n; ++f) n_total_out[f] = 0;
     if (hh < 30 || ww < 30) return DFD_OK;
     if (!h->ssd || !h->ssd->ready) return fail(h, DFD_ERR_STATE, "detector weights were not packed into the blob (weights.pack_all)");
     int rc;
@@ -438,10 +439,10 @@ int detect_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, in
     const float* rows = (const float*)mailbox_d2h(h, h->ssd->rows.p, (size_t)n * SSD_KEEP * 5 * 4);
     if (!cnt || !rows) return fail(h, DFD_ERR_HIP, "detect_batch: mailbox allocation failed");
     DFD_HIP_TRY(h, hipGetLastError());
-    DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
     for (int f = 0; f < n; ++f)
         n_out[f] = ssd_postprocess(rows + (size_t)f * SSD_KEEP * 5, cnt[f], hh, ww, conf_thr,
-                                   xywh_out + (size_t)f * max_faces * 4, nullptr, max_faces);
+                                   xywh_out + (size_t)f * max_faces * 4, nullptr, max_faces, n_total_out ? n_total_out + f : nullptr);
     return DFD_OK;
 }
 
@@ -484,10 +485,10 @@ int dfd_ssd_tap(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride, c
         if ((rc = ssd_forward(h, (const uint8_t*)h->ssd->in_u8.p, 1, nullptr, nullptr, 0, nullptr))) return rc;
         int cnt = 0;
         DFD_HIP_TRY(h, hipMemcpyAsync(&cnt, h->ssd->count.p, 4, hipMemcpyDeviceToHost, h->stream));
-        DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        DFD_HIP_TRY(h, stream_sync(h));
         if ((size_t)cnt * 5 > capacity) return fail(h, DFD_ERR_ARG, "ssd_tap: capacity");
         DFD_HIP_TRY(h, hipMemcpyAsync(out, h->ssd->rows.p, (size_t)cnt * 20, hipMemcpyDeviceToHost, h->stream));
-        DFD_HIP_TRY(h, hipStreamSynchronize(h->stream));
+        DFD_HIP_TRY(h, stream_sync(h));
         *count = (size_t)cnt * 5;
         return DFD_OK;
     }

@@ -316,6 +316,56 @@ class DeepfakeDetector:
                 'temporal_average': float(tr.get_temporal_average()), 'stability_score': float(tr.get_stability_score()),
                 'frame_count': self.frame_count}
 
+    def analyze_request_batch(self, items):
+        """`analyze_request` for several consecutive frames of this stream in ONE library call (POST /analyze_batch):
+        `items` are JPEG bytes and / or BGR frames of one size.  The GPU work of all frames is batched
+        (dfd_analyze_stream_batch); the frame counter, the full / fast forensic schedule (reference
+        deepfake_detection.py:509-512) and the votes (backend_server.py:166-176,205-211) advance frame by frame in
+        request order, so the responses equal those of len(items) single requests.  Raises DfdError (-7 / -1) BEFORE
+        any state has moved when a JPEG part is not decodable on the device path or the sizes differ."""
+        n = len(items)
+        full = [(self.frame_count + i) % self.full_forensic_interval == 0 for i in range(n)]
+        with self._lock:
+            if self.handle.has_detector or self.handle.has_haar:
+                res, shape = self.handle.analyze_stream_batch(items, full, stream_id=self.frame_analyzer.stream_id,
+                                                              confidence_threshold=0.5, max_faces=1)
+            else:                                                   # no detector of either kind: forensics only, frame by frame
+                res, shape = [], None
+                for it, fl in zip(items, full):
+                    fr = self.handle.decode_jpeg(it) if isinstance(it, (bytes, bytearray)) else np.ascontiguousarray(it)
+                    scores, prob, _ = self.handle.forensics(fr, full=fl, stream_id=self.frame_analyzer.stream_id)
+                    res.append((scores, prob, [], [], 0))
+                    shape = fr.shape[:2]
+            first_number = self.frame_analyzer.frame_count - n + 1
+        out = []
+        small = shape[0] < 30 or shape[1] < 30
+        tr = self.temporal_tracker
+        for i, (scores, fprob, faces, logits, n_detected) in enumerate(res):
+            self.last_frame_forensic_result = {'scores': scores, 'fake_probability': fprob,
+                                               'analysis_type': 'frame_forensic' if full[i] else 'frame_forensic_fast',
+                                               'frame_number': first_number + i}
+            self.frame_count += 1
+            fake_prob = None
+            if len(faces) > 0 and not small:
+                x, y, w, h = faces[0]
+                fake_prob = self._finish_face(logits[0], h, w)
+            if fake_prob is not None:
+                tr.update(fake_prob)
+                out.append({'success': True, 'analysis_mode': 'face+frame', 'faces_detected': 0 if small else n_detected,
+                            'fake_probability': float(fake_prob), 'face_probability': float(fake_prob),
+                            'frame_forensic_probability': float(fprob), 'real_probability': float(1 - fake_prob),
+                            'confidence_level': tr.get_confidence_level(), 'temporal_average': float(tr.get_temporal_average()),
+                            'stability_score': float(tr.get_stability_score()), 'frame_count': self.frame_count,
+                            'face_bbox': {'x': int(x), 'y': int(y), 'width': int(w), 'height': int(h)}})
+                continue
+            tr.update(fprob)
+            out.append({'success': True, 'analysis_mode': 'frame_only', 'faces_detected': 0 if small else n_detected,
+                        'fake_probability': float(fprob), 'frame_forensic_probability': float(fprob),
+                        'real_probability': float(1 - fprob), 'confidence_level': tr.get_confidence_level(),
+                        'temporal_average': float(tr.get_temporal_average()), 'stability_score': float(tr.get_stability_score()),
+                        'frame_count': self.frame_count})
+        return out
+
     def _last_face_count(self, frame, faces):
         """`faces_detected` of the server response counts ALL detections (backend_server.py:181); the fused call
         classified only the first and the library remembers how many there were."""

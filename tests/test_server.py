@@ -136,6 +136,7 @@ def test_analyze_batch_equals_consecutive_single_requests(client, pkg, b0_handle
         srv._last_request_time = 0.0
         singles.append(_post(client, p).get_json())
     client.post("/reset")
+    srv._last_request_time = 0.0                     # /analyze_batch sits behind the same 100 ms limiter as /analyze
     r = client.post("/analyze_batch", data={"frame": [(io.BytesIO(p), f"f{i}.jpg") for i, p in enumerate(payloads)]},
                     content_type="multipart/form-data")
     assert r.status_code == 200, r.get_data()
@@ -145,4 +146,58 @@ def test_analyze_batch_equals_consecutive_single_requests(client, pkg, b0_handle
         for k in ("analysis_mode", "faces_detected", "fake_probability", "frame_forensic_probability", "confidence_level",
                   "frame_count"):
             assert got[k] == want[k], k
+    srv._last_request_time = 0.0
     assert client.post("/analyze_batch").status_code == 400
+    assert client.post("/analyze_batch").status_code == 429                  # rate limited like /analyze
+    srv._last_request_time = 0.0
+    too_many = {"frame": [(io.BytesIO(payloads[0]), f"f{i}.jpg") for i in range(srv.MAX_BATCH_FRAMES + 1)]}
+    assert client.post("/analyze_batch", data=too_many, content_type="multipart/form-data").status_code == 400
+
+
+@pytest.mark.gpu
+def test_request_batch_equals_singles_and_costs_less_than_three_singles(pkg, b0_handle):
+    """an 8-frame /analyze_batch body must be ONE batched device pass - responses equal to 8 single
+    /analyze requests (JPEG parts, device decode) and wall time under 3x one single request."""
+    import time
+
+    D = pkg.deepfake_detection.DeepfakeDetector
+    frames = [F.natural_like(480, 640, 60 + i) if i % 4 != 3 else F.blank_frame(640, 480) for i in range(8)]
+    payloads = [_encode(f, "JPEG", quality=85) for f in frames]
+
+    def singles():
+        det = D(use_tta=False, num_tta_augmentations=1, detection_threshold=0.55, handle=b0_handle)
+        out, ts = [], []
+        for p in payloads:
+            t = time.perf_counter()
+            out.append(det.analyze_request(jpeg=p))
+            ts.append(time.perf_counter() - t)
+        return out, ts
+
+    def batch():
+        det = D(use_tta=False, num_tta_augmentations=1, detection_threshold=0.55, handle=b0_handle)
+        t = time.perf_counter()
+        out = det.analyze_request_batch(payloads)
+        return out, time.perf_counter() - t
+
+    singles(), batch()                                             # warm-up: buffers, GEMM tiles of both batch sizes
+    want, ts = singles()
+    got, tb = batch()
+    assert got == want
+    assert sum(r['analysis_mode'] == 'face+frame' for r in got) >= 4 and sum(r['analysis_mode'] == 'frame_only' for r in got) >= 2
+    single = sorted(ts)[len(ts) // 2]
+    print(f"batch of 8: {tb * 1e3:.2f} ms; one single request: {single * 1e3:.2f} ms (8 singles {sum(ts) * 1e3:.2f} ms)")
+    assert tb < 3 * single, (tb, single)
+    # raw frames and JPEG parts mixed in one call, and the Pillow-decoded frames alone, give the same responses
+    decoded = [np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(p)).convert("RGB"))[..., ::-1]) for p in payloads]
+    det = D(use_tta=False, num_tta_augmentations=1, detection_threshold=0.55, handle=b0_handle)
+    mixed = [decoded[i] if i % 2 else payloads[i] for i in range(8)]
+    assert det.analyze_request_batch(mixed) == want
+    det = D(use_tta=False, num_tta_augmentations=1, detection_threshold=0.55, handle=b0_handle)
+    assert det.analyze_request_batch(decoded[:3]) + det.analyze_request_batch(decoded[3:]) == want
+    # a part of another size is refused before anything moves
+    det = D(use_tta=False, num_tta_augmentations=1, detection_threshold=0.55, handle=b0_handle)
+    odd = _encode(F.natural_like(240, 320, 5), "JPEG", quality=85)
+    with pytest.raises(pkg._lib.DfdError):
+        det.analyze_request_batch([payloads[0], odd])
+    assert det.frame_count == 0 and det.frame_analyzer.frame_count == 0
+    assert det.analyze_request(jpeg=payloads[0]) == want[0]
