@@ -318,26 +318,57 @@ def stream_frame(base, t):
     return f
 
 
-def config5_streams(h, rank, world, dist, local_rank, waves=32, n_streams=8, verify_frames=12, lookahead=8):
+def config5_streams(h, rank, world, dist, local_rank, waves=32, n_streams=8, verify_frames=None, lookahead=8,
+                    size=(1080, 1920)):
     """BASELINE.json configs[4] / SURVEY 8(d) Config 5: 8 seeded 1080p streams (seeds 100-107), frame t of every
     stream on rank t % G (weak scaling: 8 frames per GPU per wave), per wave ONE all-gather of 80-byte records
     (dfd_vote_allgather = ncclAllGather over RCCL through the C ABI; torch.distributed as a fallback) inside the
     timed loop, then every rank replays temporal forensic signal + votes in frame order.  After the timed loop rank 0
-    recomputes the single-GPU sequence for a prefix of the frames and requires identical verdict sequences."""
+    recomputes the single-GPU sequence of ALL frames and requires identical verdict sequences.  `h` only needs the
+    handle methods used here (tests/test_streams.py drives this function at world 2 over gloo with a CPU stand-in, so
+    the --gpus N branch has run somewhere before the driver's first multi-GPU launch)."""
     import torch
 
     from rtdfd_amd import streams as S
 
-    Hh, Ww = 1080, 1920
-    bases = [np.random.default_rng(100 + s).integers(50, 200, (Hh, Ww, 3), dtype=np.uint8) for s in range(n_streams)]
-    transport, note = "rccl", None
-    try:
-        cid = [h.comm_unique_id() if rank == 0 else None]
+    Hh, Ww = size
+    on_gpu = torch.cuda.is_available()
+
+    def fence():                                                 # barrier + device sync on both sides of the timed region
+        h.sync()
         if dist is not None:
-            dist.broadcast_object_list(cid, src=0)
-        h.comm_init(cid[0], rank, world)
-    except Exception as e:                                       # noqa: BLE001 - any failure -> documented fallback
-        transport, note = ("torch" if world > 1 else "local"), f"dfd_comm_init failed: {e}"
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    bases = [np.random.default_rng(100 + s).integers(50, 200, (Hh, Ww, 3), dtype=np.uint8) for s in range(n_streams)]
+    # RCCL through the C ABI, or - decided by ALL ranks together - the documented torch.distributed fallback: rank 0's
+    # id (or its failure) is broadcast either way, and the ranks agree on the outcome of comm_init with a MIN all-reduce
+    # (a rank that fell back on its own would leave the others inside a collective that never completes; found by the
+    # world-2 CPU rehearsal of this function, tests/test_streams.py)
+    transport, note = "rccl", None
+    cid = [None]
+    if rank == 0:
+        try:
+            cid = [h.comm_unique_id()]
+        except Exception as e:                                   # noqa: BLE001
+            cid = [None]
+            note = f"dfd_comm_unique_id failed: {e}"
+    if dist is not None:
+        dist.broadcast_object_list(cid, src=0)
+    ok = cid[0] is not None
+    if ok:
+        try:
+            h.comm_init(cid[0], rank, world)
+        except Exception as e:                                   # noqa: BLE001 - any failure -> documented fallback
+            ok, note = False, f"dfd_comm_init failed: {e}"
+    if dist is not None:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{local_rank}" if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if not ok:
+        transport = "torch" if world > 1 else "local"
+        note = note or "dfd_comm_init failed on another rank"
     sh = S.ShardedStreams(h, n_streams, rank, world, transport=transport)
     h.warmup(min(n_streams * lookahead, h.max_batch), n_streams * lookahead)     # GEMM tiles of this batch shape (untimed)
 
@@ -361,44 +392,38 @@ def config5_streams(h, rank, world, dist, local_rank, waves=32, n_streams=8, ver
         staged.append((h.alloc(arr.nbytes).upload(arr), items))
     # untimed warm-up on a throw-away driver (workspace growth, first-use costs), incl. one collective
     warm = S.ShardedStreams(h, n_streams, rank, world, transport=transport)
-    for block in warm.local_records_waves(staged[0][0].ptr, Hh, Ww, staged[0][1]):
-        warm.finish_wave(block)
-    h.sync()
-    if dist is not None:
-        dist.barrier()
-        torch.cuda.synchronize()
+    warm.finish_waves(warm.local_records_waves(staged[0][0].ptr, Hh, Ww, staged[0][1]))
+    fence()
     seq = {s: [] for s in range(n_streams)}
     t0 = time.perf_counter()
     for fd, items in staged:
-        for block in sh.local_records_waves(fd.ptr, Hh, Ww, items):            # one device pass for `lookahead` waves
-            out = sh.finish_wave(block)                                          # one collective per wave, in wave order
+        blocks = sh.local_records_waves(fd.ptr, Hh, Ww, items)                 # one device pass for `lookahead` waves
+        for out in sh.finish_waves(blocks):                                      # one collective per wave, in wave order
             for s, rows in out.items():
                 seq[s] += [(r['frame'], r['confidence_level'], r['fake_probability']) for r in rows]
-    h.sync()
-    if dist is not None:
-        dist.barrier()
-        torch.cuda.synchronize()
+    fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if on_gpu else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     for fd, _ in staged:
         fd.free()
     frames = waves * world * n_streams
-    res = {"workload": f"{n_streams} seeded 1080p streams (seeds 100-107), frame t on rank t % {world}; per wave: SSD detect + "
+    res = {"workload": f"{n_streams} seeded {Hh}x{Ww} streams (seeds 100-107), frame t on rank t % {world}; per wave: SSD detect + "
                        "faces[0] -> CLAHE -> 224 -> B0, six forensic signals (temporal from recomputed gray(t-1)), one "
                        "all-gather of 80-byte records, replay of temporal score + votes on every rank; the frames of "
-                       f"{lookahead} consecutive waves share one device batch (look-ahead), the exchange stays per wave",
+                       f"{lookahead} consecutive waves share one device batch (look-ahead) and one dfd_vote_allgather_waves call "
+                       "(one upload / download / stream wait per group), the exchange itself stays one all-gather per wave",
            "frames_per_s": round(frames / dt, 1), "ms_per_wave": round(dt / waves * 1e3, 3), "waves": waves,
            "frames_per_wave_per_gpu": n_streams, "lookahead_waves": lookahead, "transport": transport,
-           "collective": "dfd_vote_allgather (ncclAllGather, RCCL)" if transport == "rccl" else transport,
+           "collective": "dfd_vote_allgather_waves (one ncclAllGather per wave, RCCL)" if transport == "rccl" else transport,
            "record_bytes": S.RECORD_FLOATS * 8, "bytes_gathered_per_wave": S.RECORD_FLOATS * 8 * n_streams * world}
     if note:
         res["transport_note"] = note
-    # verdict-sequence equality with the single-GPU sequence (rank 0, untimed, a prefix of the frames)
+    # verdict-sequence equality with the single-GPU sequence (rank 0, untimed): every frame unless verify_frames caps it
     if rank == 0:
-        nver = min(verify_frames, waves * world)
+        nver = waves * world if verify_frames is None else min(verify_frames, waves * world)
         one = S.ShardedStreams(h, n_streams, 0, 1, transport="local")
         truth = {s: [] for s in range(n_streams)}
         for t in range(nver):

@@ -343,6 +343,9 @@ int dfd_comm_init(dfd_handle* h, const void* id, int rank, int world);
 int dfd_comm_destroy(dfd_handle* h);
 int dfd_comm_info(const dfd_handle* h, int* rank, int* world);      /* world = 0: no communicator */
 int dfd_vote_allgather(dfd_handle* h, const void* local_records, size_t bytes_per_rank, void* all_records_out);
+/* `waves` consecutive waves in one call: one upload of [waves][bytes_per_rank], one ncclAllGather PER WAVE (slot w of
+ * all_records_out = [world][bytes_per_rank] of wave w), one download, one stream wait. */
+int dfd_vote_allgather_waves(dfd_handle* h, const void* local_records, int waves, size_t bytes_per_rank, void* all_records_out);
 
 #ifdef __cplusplus
 }

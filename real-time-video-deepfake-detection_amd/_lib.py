@@ -107,6 +107,7 @@ SIGNATURES = {
     "dfd_comm_destroy": (C.c_int, [C.c_void_p]),
     "dfd_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dfd_vote_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dfd_vote_allgather_waves": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "dfd_b0_profile_begin": (C.c_int, [C.c_void_p]),
     "dfd_b0_profile_end": (C.c_int, [C.c_void_p, c_float_p, C.POINTER(C.c_char_p), C.c_int,
                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -621,6 +622,16 @@ class Handle:
             raise DfdError(-5, "vote_allgather: no communicator (comm_init)")
         out = np.empty((world,) + a.shape, a.dtype)
         self._check(self._lib.dfd_vote_allgather(self._p, _ptr(a), a.nbytes, _ptr(out)))
+        return out
+
+    def vote_allgather_waves(self, local: np.ndarray) -> np.ndarray:
+        """(waves, *block) of this rank -> (waves, world, *block): one all-gather per wave, one upload / download / wait"""
+        a = np.ascontiguousarray(local)
+        _, world = self.comm_info()
+        if world <= 0:
+            raise DfdError(-5, "vote_allgather_waves: no communicator (comm_init)")
+        out = np.empty((a.shape[0], world) + a.shape[1:], a.dtype)
+        self._check(self._lib.dfd_vote_allgather_waves(self._p, _ptr(a), a.shape[0], a.nbytes // a.shape[0], _ptr(out)))
         return out
 
     @property

@@ -139,4 +139,32 @@ int dfd_vote_allgather(dfd_handle* h, const void* local_records, size_t bytes_pe
     return DFD_OK;
 }
 
+// The record blocks of `waves` consecutive waves in one call: ONE upload, one ncclAllGather per wave (wave w gathers
+// [world][bytes_per_rank] into slot w - the collective the frame order needs stays per wave), ONE download and ONE
+// stream wait.  With look-ahead batching (streams.py) a rank has the records of its next L waves before the first
+// exchange, so the per-wave upload + wait of dfd_vote_allgather (two PCIe latencies and a drained stream per wave)
+// is paid once per L waves; the gathered bytes and their order are the same.
+int dfd_vote_allgather_waves(dfd_handle* h, const void* local_records, int waves, size_t bytes_per_rank, void* all_records_out) {
+    if (!h) return DFD_ERR_ARG;
+    if (!local_records || !all_records_out || bytes_per_rank == 0 || waves <= 0)
+        return fail(h, DFD_ERR_ARG, "vote_allgather_waves: null pointer, no waves or empty record block");
+    if (!h->comm) return fail(h, DFD_ERR_STATE, "vote_allgather_waves: no communicator (dfd_comm_init)");
+    CommState& C = *h->comm;
+    Rccl* R = rccl();
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    int rc;
+    const size_t out_per_wave = bytes_per_rank * C.world;
+    if ((rc = ensure(h, &C.send, bytes_per_rank * waves))) return rc;
+    if ((rc = ensure(h, &C.recv, out_per_wave * waves))) return rc;
+    DFD_HIP_TRY(h, hipMemcpyAsync(C.send.p, local_records, bytes_per_rank * waves, hipMemcpyHostToDevice, h->stream));
+    for (int w = 0; w < waves; ++w) {
+        const int nrc = R->AllGather(static_cast<const char*>(C.send.p) + (size_t)w * bytes_per_rank,
+                                     static_cast<char*>(C.recv.p) + (size_t)w * out_per_wave, bytes_per_rank, kNcclInt8, C.comm, h->stream);
+        if (nrc != kNcclSuccess) return fail(h, DFD_ERR_HIP, "ncclAllGather (wave %d of %d): %s", w, waves, nerr(R, nrc));
+    }
+    DFD_HIP_TRY(h, hipMemcpyAsync(all_records_out, C.recv.p, out_per_wave * waves, hipMemcpyDeviceToHost, h->stream));
+    DFD_HIP_TRY(h, stream_sync(h));
+    return DFD_OK;
+}
+
 }  // extern "C"

@@ -214,7 +214,7 @@ private:
     HostPool() {
         const char* cap = getenv("DFD_HOST_THREADS");
         const int hw = (int)std::thread::hardware_concurrency();
-        int nt = std::min(cap ? std::max(atoi(cap), 1) : 12, std::max(hw / 2, 1));
+        int nt = std::min(cap ? std::max(atoi(cap), 1) : 16, std::max(hw / 2, 1));
         for (int t = 1; t < nt; ++t) workers_.emplace_back([this] { loop(); });
     }
     ~HostPool() {

@@ -128,6 +128,17 @@ def exchange(block: np.ndarray, transport: str = "local", handle=None, group=Non
     raise ValueError(f"unknown transport {transport!r}")
 
 
+def exchange_waves(blocks: Sequence[np.ndarray], transport: str = "local", handle=None, group=None) -> List[np.ndarray]:
+    """The record blocks of consecutive waves -> per wave the (world * capacity, 10) records of all ranks.  "rccl": ONE
+    library call (dfd_vote_allgather_waves: one upload, an ncclAllGather per wave, one download, one wait); the other
+    transports exchange wave by wave."""
+    if transport == "rccl" and len(blocks) > 1:
+        stacked = np.ascontiguousarray(np.stack(blocks), np.float64)
+        out = handle.vote_allgather_waves(stacked)                    # (waves, world, capacity, 10)
+        return [out[w].reshape(-1, RECORD_FLOATS) for w in range(len(blocks))]
+    return [exchange(b, transport, handle, group) for b in blocks]
+
+
 def replay_all(replicas: Sequence[StreamReplica], records: np.ndarray) -> Dict[int, List[dict]]:
     """Feed gathered records (unused slots have stream < 0) to the replicas in (frame, stream) order."""
     rows = [r for r in records if r[F_STREAM] >= 0]
@@ -143,11 +154,24 @@ class ShardedStreams:
     """Per-rank driver.  A wave = one frame of every stream on every rank (frame index wave * G + rank)."""
 
     def __init__(self, handle, n_streams: int, rank: int = 0, world: int = 1, transport: Optional[str] = None,
-                 detection_threshold: float = 0.55, group=None):
+                 detection_threshold: float = 0.55, group=None, calibrator=None):
         self.h, self.n_streams, self.rank, self.world, self.group = handle, n_streams, rank, world, group
         self.transport = transport or ("local" if world == 1 else "torch")
         self.replicas = [StreamReplica(detection_threshold) for _ in range(n_streams)]
-        self._calib_heur = None
+        # `DeepfakeDetector.calibrator` of the single-GPU flow (reference deepfake_detection.py:336-342,445-455): a
+        # deployment with weights/calibrator.pkl must vote the same sharded and unsharded
+        self.calibrator = calibrator
+
+    def face_probability(self, logit, h: int, w: int) -> float:
+        """sigmoid -> calibration -> +0.10 for crops under 80 px -> clip: `DeepfakeDetector._finish_face`
+        (reference deepfake_detection.py:397-398,445-455,489-502)"""
+        p = _sigmoid32(logit)
+        if self.calibrator is not None:
+            try:
+                p = self.calibrator.predict_proba([[p]])[0][1]
+            except Exception:                                       # reference :454-455
+                pass
+        return float(np.clip(p + (0.10 if (h < 80 or w < 80) else 0.0), 0, 1))
 
     def frame_of(self, wave: int) -> int:
         return wave * self.world + self.rank
@@ -186,7 +210,7 @@ class ShardedStreams:
                     x, y, w, h = boxes[i][0]
                     lg = logits[i][0]
                     if not np.isnan(lg):
-                        p = float(np.clip(_sigmoid32(lg) + (0.10 if (h < 80 or w < 80) else 0.0), 0, 1))   # :445-455,489-502
+                        p = self.face_probability(lg, h, w)
                 block[j] = (stream, frame, p, mdiff[i], *scores[i], len(boxes[i]))
                 i += 1
             blocks.append(block)
@@ -195,3 +219,8 @@ class ShardedStreams:
     def finish_wave(self, block: np.ndarray) -> Dict[int, List[dict]]:
         """collective: exchange + replay; identical return value on every rank"""
         return replay_all(self.replicas, exchange(block, self.transport, self.h, self.group))
+
+    def finish_waves(self, blocks: Sequence[np.ndarray]) -> List[Dict[int, List[dict]]]:
+        """collective: the exchanges of consecutive waves (one all-gather per wave, batched into one library call on
+        the RCCL transport), then the replays in wave order; identical return value on every rank"""
+        return [replay_all(self.replicas, rec) for rec in exchange_waves(blocks, self.transport, self.h, self.group)]

@@ -133,3 +133,133 @@ def test_sharded_streams_equal_single_process(pkg, world):
         assert hist == [list(r.tracker.score_history) for r in reps]          # bit-identical doubles
         assert diffs == [list(r.diffs) for r in reps]
     assert any(lv in ("FAKE", "REAL") for v in seq.values() for lv in v)
+
+
+# ---- bench.py's own multi-rank driver (configs[4]) on CPU ranks --------------------------------------------------
+class _CpuStandInHandle:
+    """The handle methods `bench.config5_streams` / `streams.ShardedStreams` use, computed on the CPU from the frame
+    bytes alone (so a frame gives the same record on whichever rank it lands): no RCCL (comm_init raises -> the
+    documented torch.distributed fallback), boxes / logits / forensic scores are cheap deterministic functions of the
+    pixels.  Test infrastructure: it exercises the DRIVER (staging order, look-ahead groups, predecessor layout,
+    exchange + replay, the all-frames verification) - the kernels have their own GPU tests."""
+    max_batch = 64
+
+    class _Buf:
+        def __init__(self, store, nbytes):
+            self.store, self.ptr = store, id(self)
+            self.store[self.ptr] = None
+
+        def upload(self, arr):
+            self.store[self.ptr] = np.array(arr, copy=True)
+            return self
+
+        def free(self):
+            self.store.pop(self.ptr, None)
+
+    def __init__(self):
+        self.store = {}
+
+    def comm_unique_id(self):
+        raise RuntimeError("no RCCL on a CPU rank")
+
+    def comm_init(self, *a):
+        raise RuntimeError("no RCCL on a CPU rank")
+
+    def warmup(self, *a):
+        pass
+
+    def sync(self):
+        pass
+
+    def alloc(self, nbytes):
+        return self._Buf(self.store, nbytes)
+
+    def analyze_batch_device(self, ptr, m, height, width, forced_boxes=None, confidence_threshold=0.5, max_faces=1,
+                             with_forensics=False):
+        fr = self.store[ptr]
+        boxes, logits = [], []
+        for i in range(m):
+            v = int(fr[i, ::7, ::5].astype(np.int64).sum())
+            if v % 5 == 0:                                          # "no face" in a fifth of the frames
+                boxes.append([])
+                logits.append(np.zeros(0, np.float32))
+            else:
+                boxes.append([(v % 50, v % 40, 60 + v % 90, 70 + v % 60)])
+                logits.append(np.asarray([((v % 2001) - 1000) / 400.0], np.float32))
+        return boxes, logits, None
+
+    def forensic_signals_device(self, ptr, n, height, width, prev_index):
+        fr = self.store[ptr]
+        gray = fr[:n].astype(np.float64).mean(axis=3)
+        scores = np.zeros((n, 5))
+        mdiff = np.full(n, -1.0)
+        for i in range(n):
+            if prev_index[i] == -2:
+                scores[i] = -1.0
+                continue
+            m = gray[i].mean()
+            scores[i] = [(int(m * 10) % 5) * 0.2, (int(m * 7) % 4) * 0.25, (int(m * 3) % 3) * 0.5, (int(m * 11) % 5) * 0.2, 0.25]
+            if prev_index[i] >= 0:
+                mdiff[i] = float(np.abs(gray[i] - gray[prev_index[i]]).mean())
+        return scores, mdiff
+
+
+def _bench_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = bench.config5_streams(_CpuStandInHandle(), rank, world, dist, rank, waves=6, n_streams=3, lookahead=4, size=(320, 352))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_config5_driver_runs_at_world_2_over_gloo(pkg):
+    """`python bench.py --gpus N` takes the config5 branch for the first time on the driver's 8-GPU
+    node - here the same function runs at world 2 (gloo, CPU stand-in for the handle): the staged look-ahead groups,
+    the predecessor layout, `finish_waves`, the MAX-over-ranks timing and the verification of EVERY frame against the
+    single-process sequence all execute, and the sharded verdicts equal the unsharded ones."""
+    import bench
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0 = results[0]
+    assert r0["transport"] == "torch" and "failed" in r0["transport_note"]
+    assert r0["verdicts_equal_single_gpu"] is True and r0["verified_frames_per_stream"] == 12      # 6 waves x 2 ranks: all
+    assert r0["waves"] == 6 and r0["frames_per_s"] > 0 and "error" not in r0
+    assert any(lv in ("FAKE", "REAL") for lv in r0["verdicts_stream0"])
+    # the same driver unsharded gives the same verdict sequence for stream 0
+    one = bench.config5_streams(_CpuStandInHandle(), 0, 1, None, 0, waves=12, n_streams=3, lookahead=4, size=(320, 352))
+    assert one["verdicts_stream0"] == r0["verdicts_stream0"] and one["transport"] == "local"
+
+
+def test_sharded_streams_apply_the_calibrator(pkg):
+    """ADVICE / VERDICT r2: `DeepfakeDetector.calibrator` (reference deepfake_detection.py:445-455) must act on the
+    sharded path too, else a deployment with calibrator.pkl votes differently sharded vs single-GPU."""
+    S = pkg.streams
+
+    class Cal:
+        def predict_proba(self, x):
+            p = x[0][0]
+            return [[1 - p * 0.5, p * 0.5]]
+
+    plain = S.ShardedStreams(None, 1)
+    cal = S.ShardedStreams(None, 1, calibrator=Cal())
+    det = pkg.deepfake_detection.DeepfakeDetector.__new__(pkg.deepfake_detection.DeepfakeDetector)
+    det.calibrator = Cal()
+    for lg, hh, ww in ((0.3, 120, 90), (-1.2, 60, 200), (2.5, 79, 79)):
+        assert cal.face_probability(lg, hh, ww) == float(det._finish_face(np.float32(lg), hh, ww))
+        assert plain.face_probability(lg, hh, ww) != cal.face_probability(lg, hh, ww)
