@@ -16,6 +16,11 @@ export TMPDIR=/tmp
 python3 profiles/b0_profile_driver.py > "$OUT/warm_fp32.log" 2>&1 || exit 1
 B0_BF16=1 python3 profiles/b0_profile_driver.py > "$OUT/warm_bf16.log" 2>&1 || exit 1
 python3 bench.py --steps 20 --warmup 5 --no-e2e --no-streams --no-cpu-baseline > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err" || exit 1
+# the MTCNN / e2e drivers once un-profiled too: their handles warm up other batch shapes, and a shape missing from the
+# tile cache is measured inside the profiled process (round 2's MTCNN table was dominated by those tuning launches)
+MT_FRAMES=64 python3 profiles/mtcnn_profile_driver.py > "$OUT/warm_mtcnn64.log" 2>&1 || exit 1
+MT_DENSE=1 python3 profiles/mtcnn_profile_driver.py > "$OUT/warm_mtcnn_dense.log" 2>&1 || exit 1
+E2E_STEPS=2 python3 profiles/e2e_profile_driver.py > "$OUT/warm_e2e.log" 2>&1 || exit 1
 cd /tmp
 run() { name=$1; shift; rocprofv3 "$@" > "$OUT/$name.log" 2>&1 || { echo "rocprofv3 $name failed"; tail -5 "$OUT/$name.log"; exit 1; }; }
 run stats_bench --kernel-trace --stats -d "$OUT/stats_bench" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-e2e --no-streams --no-cpu-baseline

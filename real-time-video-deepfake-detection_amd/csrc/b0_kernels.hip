@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const XT* __
 // (round 3) fp32 only, exactly Cin / 4 MFMAs per pixel tile: lane k-group q supplies the NM = Cin / 4 consecutive
 // channels q * NM .. of its pixel (see mbconv2_kernel); KC = 16-byte registers per tile and lane = ceil(NM / 4).
 template <int K, int S, int CB, int TH, int TW, int RP, int KC, int NSUB, typename XT, int CI>
-__global__ __launch_bounds__(256, 3) void mbconv_kernel(const XT* __restrict__ X,
+__global__ __launch_bounds__(256, ((S == 1 && (((TH - 1) * S + K) * ((TW - 1) * S + K) + 63) / 64 * KC > 12) ? 2 : 3)) void mbconv_kernel(const XT* __restrict__ X,
                                                      const float* __restrict__ We,
                                                      const float* __restrict__ be,
                                                      const float* __restrict__ Wt,
@@ -639,11 +639,21 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const XT* __restrict__ X
                 v4f acc[NTB];                                    // starts at the folded-BN bias: no add in the epilogue
 #pragma unroll
                 for (int nt = 0; nt < NTB; ++nt) acc[nt] = bex[nt];
+                if constexpr (NTB == 1) {                        // two independent MFMA chains over the K steps (see mbconv2_kernel)
+                    v4f acc1 = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < NM; ++i)
+                    for (int i = 0; i < NM; ++i) {
+                        if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0][i / 4][i % 4], xf[it][i / 4][i % 4], acc1, 0, 0, 0);
+                        else acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0][i / 4][i % 4], xf[it][i / 4][i % 4], acc[0], 0, 0, 0);
+                    }
+                    acc[0] += acc1;
+                } else {
 #pragma unroll
-                    for (int nt = 0; nt < NTB; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i / 4][i % 4], xf[it][i / 4][i % 4], acc[nt], 0, 0, 0);
+                    for (int i = 0; i < NM; ++i)
+#pragma unroll
+                        for (int nt = 0; nt < NTB; ++nt)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][i / 4][i % 4], xf[it][i / 4][i % 4], acc[nt], 0, 0, 0);
+                }
                 const int p = mt * 16 + j;
                 const int iy = iy0 + p / IW, ix = ix0 + p % IW;
                 const bool inside = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H;
@@ -694,8 +704,8 @@ __global__ __launch_bounds__(256, 3) void mbconv_kernel(const XT* __restrict__ X
 //     old value had to be copied aside, the copy landed in the loop latch behind `s_waitcnt vmcnt(0)` (ISA), and every
 //     4-tile iteration drained the whole ring - an s_memtime trace put 64 % of block 4's time in that loop.
 template <int K, int S, int CB, int TH, int TW, int RP, int NK, typename XT, int ABL = 0, int NT = 256, bool INS = false,
-          int CI = 0>
-__global__ __launch_bounds__(NT, (NT == 256 ? 2 : 4)) void mbconv2_kernel(const XT* __restrict__ X,
+          int CI = 0, int MINB = (NT == 256 ? 2 : 4)>
+__global__ __launch_bounds__(NT, MINB) void mbconv2_kernel(const XT* __restrict__ X,
                                                       const unsigned short* __restrict__ We3, int plane, int Kp,
                                                       const float* __restrict__ Wef,
                                                       const float* __restrict__ be,
@@ -780,7 +790,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 4)) void mbconv2_kernel(const 
     // Activation tiles are requested RD tiles ahead (register ring, the tile loop is unrolled by RD): with one tile
     // ahead every iteration ended in an exposed L2 round trip - the ablation runs put the expand phase of block 2
     // at 155 us of a 232 us launch with MFMAs and swish together accounting for 44 of them.
-    constexpr int RD = NIT < (64 / (4 * KC)) ? NIT : (64 / (4 * KC));
+    constexpr int RDMAX = MINB >= 4 && NT == 256 ? 3 : 64 / (4 * KC);       // tighter register budget: a shorter ring
+    constexpr int RD = NIT < RDMAX ? NIT : RDMAX;
     XTile ring[RD];
     // Request order = wait order.  The block's constants (expand rows as MFMA A operands: lane = channel row j,
     // k-group q; folded-BN biases; depthwise taps and bias) go FIRST, the activation ring after them: vmcnt retires in
@@ -1241,10 +1252,21 @@ template bool launch_depthwise<bf16_t>(const bf16_t*, const float*, const float*
 // generation: 214 / 148 us against 263 / 164 us).  With bf16 activations the second generation wins everywhere
 // (229 / 128 / 124 / 99 / 53 us against 263 / 179 / 152 / 151 / 62 us).
 // (k, stride, H, C, Cin) -> <K,S,CB,TH,TW,RP, KC = ceil(Cin/16), NSUB = channel chunks per block>
-#define DFD_MB1_TABLE(OP)                           \
-    OP(3, 2, 112, 96, 16, 32, 8, 8, 2, 1, 3)        \
-    OP(5, 2, 56, 144, 24, 16, 7, 14, 2, 2, 3)       \
-    OP(3, 2, 28, 240, 40, 16, 7, 14, 2, 3, 1)
+#define DFD_MB1_TABLE(OP)                               \
+    OP(-1, 3, 2, 112, 96, 16, 32, 8, 8, 2, 1, 3)        \
+    OP(-1, 5, 2, 56, 144, 24, 16, 7, 14, 2, 2, 3)       \
+    OP(-3, 5, 2, 56, 144, 24, 16, 7, 14, 2, 2, 9)       \
+    OP(-1, 3, 2, 28, 240, 40, 16, 7, 14, 2, 3, 1)       \
+    OP(-3, 3, 2, 28, 240, 40, 16, 7, 14, 2, 3, 3)       \
+    OP(-4, 3, 2, 28, 240, 40, 16, 7, 14, 2, 3, 5)       \
+    OP(-5, 3, 2, 28, 240, 40, 16, 7, 14, 7, 3, 1)       \
+    OP(-1, 5, 1, 28, 240, 40, 16, 14, 28, 7, 3, 3)      \
+    OP(-3, 5, 1, 28, 240, 40, 16, 14, 28, 7, 3, 5)      \
+    OP(-4, 5, 1, 28, 240, 40, 16, 7, 28, 7, 3, 5)       \
+    OP(-5, 5, 1, 28, 240, 40, 16, 14, 14, 7, 3, 5)      \
+    OP(-1, 3, 1, 56, 144, 24, 16, 14, 28, 7, 2, 3)      \
+    OP(-3, 3, 1, 56, 144, 24, 16, 14, 28, 7, 2, 9)      \
+    OP(-4, 3, 1, 56, 144, 24, 16, 14, 14, 7, 2, 9)
 
 // ablation builds of the default tiles of blocks 2 and 4 (variant 20 + ABL): where does the time go?
 //   1 no MFMAs, 2 no swish on the expanded tile, 3 no depthwise phase, 4 no swish after the depthwise conv, 5 no stores
@@ -1258,14 +1280,15 @@ static int mb_variant(int H, int stride) {
     return e ? atoi(e) : -2;
 }
 
-template <int K, int S, int CB, int TH, int TW, int RP, int NK, typename XT, int NT = 256, bool INS = false, int CI = 0>
+template <int K, int S, int CB, int TH, int TW, int RP, int NK, typename XT, int NT = 256, bool INS = false, int CI = 0,
+          int MINB = (NT == 256 ? 2 : 4)>
 static void mb2_launch(const XT* X, int Cin, const unsigned short* We3, int plane, int Kp, const float* Wef, const float* be,
                        const float* W, const float* b, XT* Y, float* P, int n, int H, int C, int pad_lo, int* tiles, hipStream_t s) {
     const int Ho = (H + S - 1) / S;
     const int tx = (Ho + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
     const int tiles_sp = tx * ty;
     *tiles = tiles_sp;
-    hipLaunchKernelGGL((mbconv2_kernel<K, S, CB, TH, TW, RP, NK, XT, 0, NT, INS, CI>), dim3(tiles_sp * (C / CB) * n), dim3(NT), 0, s, X,
+    hipLaunchKernelGGL((mbconv2_kernel<K, S, CB, TH, TW, RP, NK, XT, 0, NT, INS, CI, MINB>), dim3(tiles_sp * (C / CB) * n), dim3(NT), 0, s, X,
                        We3, plane, Kp, Wef, be, W, b, Y, P, H, Ho, C, Cin, pad_lo, tx, tiles_sp);
 }
 
@@ -1279,15 +1302,16 @@ bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int 
         //   block 1 (112, s2): first generation 237 (second: 261) / variant 0 203
         //   block 2 (56, s1):  variant 6 (INS) 190 (variant 0: 203) / variant 0 127
         //   block 3 (56, s2):  first generation 158 (second: 178-254) / variant 0 117
-        //   block 4 (28, s1):  variant 12 (14 x 28 tiles) 122 (whole image: 132) / variant 7 (whole image, 512 threads) 83 (variant 0: 92)
-        //   block 5 (28, s2):  first generation 76 (second: 90) / variant 0 51
-        if (sizeof(XT) == 4) var = stride == 2 ? -1 : (H == 56 ? 6 : 12);
+        //   block 4 (28, s1):  variant 13 (14 x 28 tiles, four blocks per CU: 100 VGPRs, ring of 3) 115 (three blocks: 121;
+        //                      whole image: 132) / variant 7 (whole image, 512 threads) 83 (variant 0: 92)
+        //   block 5 (28, s2):  first generation, 3 channel chunks per block 69 (1 chunk: 78; second generation: 93) / variant 0 51
+        if (sizeof(XT) == 4) var = stride == 2 ? (H == 28 ? -3 : -1) : (H == 56 ? 6 : 13);
         else var = (H == 28 && stride == 1) ? 7 : 0;
     }
     if constexpr (sizeof(XT) == 4) {
-        if (var == -1) {
-#define DFD_MB1_DISPATCH(KK, SS, HH, CC, CI, CB, TH, TW, RP, KC, NSUB)                                                \
-    if (k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                               \
+        if (var <= -1) {
+#define DFD_MB1_DISPATCH(VV, KK, SS, HH, CC, CI, CB, TH, TW, RP, KC, NSUB)                                            \
+    if (var == VV && k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                  \
         mb_launch<KK, SS, CB, TH, TW, RP, KC, NSUB, XT, CI>(Xin, Cin, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);  \
         return true;                                                                                                \
     }
@@ -1310,6 +1334,19 @@ bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int 
     }
     DFD_MB3_TABLE(DFD_MB3_DISPATCH)
 #undef DFD_MB3_DISPATCH
+    // four blocks per CU (128 VGPRs, ring of 3): more waves in different phases on a SIMD
+    if (var == 13 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {
+        mb2_launch<5, 1, 16, 14, 28, 7, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
+        return true;
+    }
+    if (var == 14 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {
+        mb2_launch<5, 1, 16, 7, 28, 7, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
+        return true;
+    }
+    if (var == 13 && k == 3 && stride == 1 && H == 56 && C == 144 && Cin == 24) {
+        mb2_launch<3, 1, 16, 14, 28, 7, 1, XT, 256, true, 24, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
+        return true;
+    }
 #ifdef DFD_MB_ABLATION
 #define DFD_ABL_CASE(A)                                                                                              \
     if (var == 20 + A && H == 56 && stride == 1) {                                                                  \
@@ -1347,13 +1384,14 @@ int mbconv_tiles(int H, int C, int k, int stride, int Cin) {
     DFD_MB3_TABLE(DFD_MB3_TILES)
 #undef DFD_MB3_TILES
 #undef DFD_MB2_TILES
-#define DFD_MB1_TILES(KK, SS, HH, CC, CI, CB, TH, TW, RP, KC, NSUB)                  \
+#define DFD_MB1_TILES(VV, KK, SS, HH, CC, CI, CB, TH, TW, RP, KC, NSUB)              \
     if (k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                \
         const int tl = ((Ho + TW - 1) / TW) * ((Ho + TH - 1) / TH);                  \
         if (tl > best) best = tl;                                                    \
     }
     DFD_MB1_TABLE(DFD_MB1_TILES)
 #undef DFD_MB1_TILES
+    if (k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40 && best < 4) best = 4;      // variant 14: 7 x 28 tiles
     return best;
 }
 

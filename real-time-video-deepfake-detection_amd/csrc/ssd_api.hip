@@ -292,10 +292,19 @@ int ssd_forward(dfd_handle* h, const uint8_t* in300, int n, const char* tap_name
         const SsdTensor& dst = S->t[L.name];
         const std::string q = std::string("ssd.") + L.name;
         switch (L.kind) {
-            case SK_CONV1:
-                launch_ssd_conv1(in300, W_(q + ".w", 147 * 32), W_(q + ".b", 32), ptr(L.name), n, S->in_scale, S->in_shift,
-                                 L.relu, s);
+            case SK_CONV1: {
+                // the matrix-pipe kernel (DFD_SSD_CONV1_MFMA=0: the thread-per-pixel kernel, for A/B runs)
+                static const bool mfma = !(getenv("DFD_SSD_CONV1_MFMA") && atoi(getenv("DFD_SSD_CONV1_MFMA")) == 0);
+                const float* wc = W_(q + ".w", 147 * 32);
+                const unsigned short* w3 = mfma ? split_weights(h, wc, 32, 147, true) : nullptr;
+                if (mfma && !w3) return DFD_ERR_HIP;
+                if (mfma)
+                    launch_ssd_conv1_mfma(in300, w3, (int)split_weights_count(32, 147), 192, W_(q + ".b", 32), ptr(L.name), n,
+                                          S->in_scale, S->in_shift, L.relu, s);
+                else
+                    launch_ssd_conv1(in300, wc, W_(q + ".b", 32), ptr(L.name), n, S->in_scale, S->in_shift, L.relu, s);
                 break;
+            }
             case SK_AFFINE:
                 launch_channel_affine(ptr(L.src), W_(q + ".scale", L.cout), W_(q + ".shift", L.cout), nullptr, ptr(L.name),
                                       (long long)n * src.size * src.size, L.cout, L.relu, s);

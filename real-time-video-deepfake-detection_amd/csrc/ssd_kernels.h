@@ -19,6 +19,9 @@ struct SsdHeads {
 // it as 0 (Caffe pads the transformed blob)
 void launch_ssd_conv1(const uint8_t* img, const float* w, const float* b, float* y, int n, const float in_scale[3],
                       const float in_shift[3], bool relu, hipStream_t s);
+// the same convolution on the bf16 MFMA against the three exact weight planes [32][Kp] of split_weights(w, 32, 147, transposed)
+void launch_ssd_conv1_mfma(const uint8_t* img, const unsigned short* w3, int plane, int Kp, const float* b, float* y, int n,
+                           const float in_scale[3], const float in_shift[3], bool relu, hipStream_t s);
 // y = [relu](x * scale[c] + shift[c]) (scale/shift may be null: 1 / 0) (+ add, before the relu); NHWC fp32, C % 4 == 0:
 // a BatchNorm+Scale(+ReLU) that cannot be folded into a convolution (pre-activation ResNet), or an Eltwise SUM
 void launch_channel_affine(const float* x, const float* scale, const float* shift, const float* add, float* y,

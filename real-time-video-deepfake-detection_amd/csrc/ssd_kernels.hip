@@ -97,6 +97,130 @@ void launch_ssd_conv1(const uint8_t* img, const float* w, const float* b, float*
                        in_scale[0], in_scale[1], in_scale[2], in_shift[0], in_shift[1], in_shift[2], relu ? 1 : 0);
 }
 
+// ---- conv1 on the matrix pipe (round 3) ------------------------------------------------------------------------
+// The 7x7x3 -> 32 stride-2 convolution as a GEMM on v_mfma_f32_16x16x32_bf16, like the classifier's stem: D[co][pixel]
+// = sum_k W[co][k] * X[k][pixel], k = (ky * 7 + kx) * 3 + ci = ky * 21 + (the 21 consecutive bytes of an image row),
+// K = 147 in 5 steps of 32 (the weight planes are zero beyond 147).  Weights: the handle's three bf16 planes (exact
+// split).  Input: u8 * scale + shift; with the reference's blobFromImage parameters (scale 1, integer means 104 / 177 /
+// 123, face_detection.py:76-79) that is an integer of magnitude <= 255 - ONE exact bf16 term, three products per
+// K-step (EXACT); any other input transform (a folded data-layer BatchNorm, caffe_io) takes the three-term split, six
+// products.  Block = 8 output rows x 16 columns: the 21 x 37 x 3 input patch is transformed once into an fp32 LDS
+// patch (0 outside the image: Caffe pads the mean-subtracted blob), each wave gathers the B operand of its two 16-pixel
+// rows from it (lane = pixel, 8 consecutive k), and the A fragments of a K-step serve both rows.  The thread-per-pixel
+// kernel above issued 147 x 16 FMAs per thread behind scalar weight loads: 195-240 us per 64 frames, VALU-bound.
+template <bool EXACT>
+__global__ __launch_bounds__(256) void ssd_conv1_mfma_kernel(const uint8_t* __restrict__ img, const unsigned short* __restrict__ w3,
+                                                             int plane, int Kp, const float* __restrict__ bias,
+                                                             float* __restrict__ y, float sb, float sg, float sr, float hb,
+                                                             float hg, float hr, int relu) {
+    constexpr int TH = 8, TW = 16, PH = 2 * TH + 5, PW = (2 * TW + 5) * 3, PWP = PW + 1;      // 21 rows x 111 (+1) floats
+    __shared__ float patch[PH * PWP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+    const int n = blockIdx.z, ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
+    const uint8_t* src = img + (size_t)n * 300 * 300 * 3;
+    const int r0 = 2 * ty0 - 3, c0 = (2 * tx0 - 3) * 3;                  // patch origin in the image (row, byte column)
+    const float sc[3] = {sb, sg, sr}, sh[3] = {hb, hg, hr};
+    // patch: clamped unconditional byte loads, all in flight before the first LDS store
+    constexpr int NEL = PH * PW, NLD = (NEL + 255) / 256;
+    float pv[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + k * 256 < NEL ? tid + k * 256 : NEL - 1;
+        const int r = i / PW, cb = i - r * PW;
+        const int iy = r0 + r, ib = c0 + cb;                              // byte column: pixel ib / 3, channel ib % 3
+        const bool inside = (unsigned)iy < 300u && (unsigned)ib < 900u;
+        const int ci = (ib + 900) % 3;
+        const float v = (float)src[(size_t)(inside ? iy : 0) * 900 + (inside ? ib : 0)] * sc[ci] + sh[ci];
+        pv[k] = inside ? v : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + k * 256 < NEL ? tid + k * 256 : NEL - 1;
+        const int r = i / PW;
+        patch[r * PWP + (i - r * PW)] = pv[k];
+    }
+    // per-lane patch offsets of the 8 k values of each K-step (k >= 147: offset 0, zero weights)
+    int koff[5][8];
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = s5 * 32 + 8 * q + e, kc = k < 147 ? k : 0;
+            const int ky = kc / 21;
+            koff[s5][e] = ky * PWP + (kc - ky * 21);
+        }
+    const v4f b0 = *reinterpret_cast<const v4f*>(bias + 4 * q), b1 = *reinterpret_cast<const v4f*>(bias + 16 + 4 * q);
+    __syncthreads();
+    v4f acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { acc[t][0] = b0; acc[t][1] = b1; }
+    const unsigned short* wrow = w3 + (size_t)j * Kp + 8 * q;
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+        bf8 wf[2][3];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                wf[nt][pl] = *reinterpret_cast<const bf8*>(wrow + (size_t)pl * plane + (size_t)nt * 16 * Kp + s5 * 32);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int py = wave * 2 + t;                                 // tile row of this wave's t-th pixel row
+            const float* pp = &patch[(2 * py) * PWP + (2 * j) * 3];
+            v4f lo, hi;
+            lo.x = pp[koff[s5][0]]; lo.y = pp[koff[s5][1]]; lo.z = pp[koff[s5][2]]; lo.w = pp[koff[s5][3]];
+            hi.x = pp[koff[s5][4]]; hi.y = pp[koff[s5][5]]; hi.z = pp[koff[s5][6]]; hi.w = pp[koff[s5][7]];
+            if constexpr (EXACT) {
+                bf8 x0;
+                x0[0] = (__bf16)lo.x; x0[1] = (__bf16)lo.y; x0[2] = (__bf16)lo.z; x0[3] = (__bf16)lo.w;
+                x0[4] = (__bf16)hi.x; x0[5] = (__bf16)hi.y; x0[6] = (__bf16)hi.z; x0[7] = (__bf16)hi.w;
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl)                           // smallest weight terms first
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][pl], x0, acc[t][nt], 0, 0, 0);
+            } else {
+                bf8 x0, x1, x2;
+                split8(lo, hi, x0, x1, x2);
+                const bf8* xs[3] = {&x0, &x1, &x2};
+                const int wsel[6] = {2, 1, 0, 1, 0, 0}, xsel[6] = {0, 1, 2, 0, 1, 0};          // smallest terms first
+#pragma unroll
+                for (int p6 = 0; p6 < 6; ++p6)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][wsel[p6]], *xs[xsel[p6]], acc[t][nt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int oy = ty0 + wave * 2 + t, ox = tx0 + j;
+        if (oy < 150 && ox < 150) {
+            float* yp = y + (((size_t)n * 150 + oy) * 150 + ox) * 32;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                v4f v = acc[t][nt];
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<v4f*>(yp + nt * 16 + 4 * q) = v;
+            }
+        }
+    }
+}
+
+void launch_ssd_conv1_mfma(const uint8_t* img, const unsigned short* w3, int plane, int Kp, const float* b, float* y, int n,
+                           const float in_scale[3], const float in_shift[3], bool relu, hipStream_t s) {
+    bool exact = true;
+    for (int c = 0; c < 3; ++c)
+        exact = exact && in_scale[c] == 1.f && in_shift[c] == (float)(int)in_shift[c] && in_shift[c] >= -255.f && in_shift[c] <= 0.f;
+    const dim3 grid((150 + 15) / 16, (150 + 7) / 8, n);
+    if (exact)
+        hipLaunchKernelGGL(ssd_conv1_mfma_kernel<true>, grid, dim3(256), 0, s, img, w3, plane, Kp, b, y, in_scale[0], in_scale[1],
+                           in_scale[2], in_shift[0], in_shift[1], in_shift[2], relu ? 1 : 0);
+    else
+        hipLaunchKernelGGL(ssd_conv1_mfma_kernel<false>, grid, dim3(256), 0, s, img, w3, plane, Kp, b, y, in_scale[0], in_scale[1],
+                           in_scale[2], in_shift[0], in_shift[1], in_shift[2], relu ? 1 : 0);
+}
+
 // ------------------------------------------------------------------- per-channel affine / add
 __global__ __launch_bounds__(256) void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* __restrict__ add,
@@ -219,43 +343,93 @@ __device__ __forceinline__ float jaccard(const float* a, const float* b) {
     return inter / (box_area(a) + box_area(b) - inter);
 }
 
-// one 1024-thread block per image; key = score bits (positive floats order like uints) in the high
-// word, ~index in the low word, sorted descending => score desc, index asc (stable order)
+// One 1024-thread block per image; key = score bits (positive floats order like uints) in the high word, ~index in the
+// low word: descending keys = score desc, index asc (Caffe's stable order).
+//   1. priors above the confidence threshold -> keys; a 2048-bin histogram of the scores' leading bits finds the bin
+//      that holds the top_k-th score, and only the keys at or above it are sorted (round 2 sorted every valid prior:
+//      on a detector with many weak responses that was the full 16384-slot bitonic network, 105 barrier stages);
+//   2. bitonic sort of those (a power of two >= 512), top_k = 400 candidates;
+//   3. greedy NMS as a bitmask: all 400 x 400 overlap tests at once into 400 x 7 64-bit words, then ONE wave walks the
+//      candidates in order with the `removed` set in registers (lane w = word w) - the 400 block-wide barriers of the
+//      one-candidate-at-a-time loop were most of the kernel (192 us per 64 frames at VALU 0.01 busy).
+// Same tests on the same values in the same order: rows identical to the round-2 kernel.
 __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ prob,
                                                        int n_priors, float conf_thr, double nms_thr, int keep_top_k,
                                                        float* __restrict__ rows, int* __restrict__ count) {
+    constexpr int WORDS = (NMS_TOPK + 63) / 64, SEL_CAP = 4096, MASK_AT = 512;
     __shared__ unsigned long long key[NMS_SORT];
+    __shared__ unsigned long long ckey[NMS_TOPK];
     __shared__ float cand[NMS_TOPK][4];
-    __shared__ unsigned char dead[NMS_TOPK];
     __shared__ int kept[NMS_TOPK];
-    __shared__ int n_kept;
-    const int tid = threadIdx.x, img = blockIdx.x;
+    __shared__ int hist[2048];
+    __shared__ int n_kept, n_valid, n_sel, cut_bin;
+    static_assert(MASK_AT + NMS_TOPK * WORDS <= NMS_SORT, "the overlap words live in the sort buffer");
+    const int tid = threadIdx.x, img = blockIdx.x, lane = tid & 63;
     const float* pr = prob + (size_t)img * n_priors;
-    // priors above the confidence threshold are appended to the front of key[] (any order: the keys are unique and the
-    // sort below orders them), then only the next power of two above their number is sorted - a few hundred for a
-    // trained detector instead of all 16384 slots (105 barrier-separated bitonic stages down to ~40)
-    __shared__ int n_valid;
-    if (tid == 0) n_valid = 0;
+    if (tid == 0) { n_valid = 0; n_sel = 0; n_kept = 0; cut_bin = 0; }
+    for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
     unsigned long long mine[NMS_SORT / 1024];
+    __syncthreads();
+    int local = 0;
 #pragma unroll
     for (int r = 0; r < NMS_SORT / 1024; ++r) {
         const int i = tid + r * 1024;
         unsigned long long k = 0ull;
         if (i < n_priors) {
             const float p = pr[i];
-            if (p > conf_thr) k = ((unsigned long long)__float_as_uint(p) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+            if (p > conf_thr) {
+                k = ((unsigned long long)__float_as_uint(p) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+                unsigned bin = __float_as_uint(p) >> 19;             // sign 0: 12 significant bits, monotone in p
+                atomicAdd(&hist[bin < 2047u ? bin : 2047u], 1);
+                ++local;
+            }
         }
         mine[r] = k;
     }
+    if (local) atomicAdd(&n_valid, local);
     __syncthreads();
+    // the lowest bin whose suffix count reaches top_k (all keys when fewer are valid): wave 0, 32 bins per lane
+    if (tid < 64) {
+        int mysum = 0;
+        for (int b2 = 0; b2 < 32; ++b2) mysum += hist[lane * 32 + b2];
+        int suffix = mysum;                                         // inclusive suffix sum over lanes (lane 63 = top bins)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_down(suffix, off);
+            if (lane + off < 64) suffix += v;
+        }
+        const int above = suffix - mysum;                           // keys in the bins above this lane's
+        if (above < NMS_TOPK && suffix >= NMS_TOPK) {               // the top_k-th key falls into this lane's bins
+            int acc = above, b2 = 31;
+            for (; b2 >= 0; --b2) {
+                acc += hist[lane * 32 + b2];
+                if (acc >= NMS_TOPK) break;
+            }
+            cut_bin = lane * 32 + (b2 < 0 ? 0 : b2);
+        }
+    }
+    __syncthreads();
+    const unsigned cut = n_valid > NMS_TOPK ? (unsigned)cut_bin : 0u;
+    // selected keys to the front of key[] (any order: unique keys, the sort orders them)
+    int sel_local = 0;
 #pragma unroll
     for (int r = 0; r < NMS_SORT / 1024; ++r)
-        if (mine[r] != 0ull) key[atomicAdd(&n_valid, 1)] = mine[r];
+        if (mine[r] != 0ull) {
+            unsigned bin = (unsigned)(mine[r] >> 51);                // = score bits >> 19
+            bin = bin < 2047u ? bin : 2047u;
+            if (bin >= cut) ++sel_local; else mine[r] = 0ull;
+        }
+    int base = 0;
+    if (sel_local) base = atomicAdd(&n_sel, sel_local);
+#pragma unroll
+    for (int r = 0; r < NMS_SORT / 1024; ++r)
+        if (mine[r] != 0ull) key[base++] = mine[r];
     __syncthreads();
-    int sort_n = 2;
-    while (sort_n < n_valid) sort_n <<= 1;
-    if (sort_n < NMS_TOPK) sort_n = 512;                   // the candidate scan below reads the first NMS_TOPK slots
-    for (int i = n_valid + tid; i < sort_n; i += 1024) key[i] = 0ull;
+    const int nsel = n_sel;                                         // >= min(n_valid, top_k); a crowded cut bin can make it large
+    (void)SEL_CAP;
+    int sort_n = 512;
+    while (sort_n < nsel) sort_n <<= 1;
+    for (int i = nsel + tid; i < sort_n; i += 1024) key[i] = 0ull;
     __syncthreads();
     for (int size = 2; size <= sort_n; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -267,32 +441,53 @@ __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__
             }
             __syncthreads();
         }
-    // candidates: first min(top_k, #valid) keys
-    int ncand = 0;
+    // candidates: the first min(top_k, #valid) keys, with their boxes
+    const int ncand = nsel < NMS_TOPK ? nsel : NMS_TOPK;
     for (int i = tid; i < NMS_TOPK; i += 1024) {
-        dead[i] = 0;
-        if (key[i] != 0ull) {
-            const unsigned idx = 0xFFFFFFFFu - (unsigned)(key[i] & 0xFFFFFFFFull);
+        const unsigned long long k = i < ncand ? key[i] : 0ull;
+        ckey[i] = k;
+        if (k != 0ull) {
+            const unsigned idx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
             const float* b = boxes + ((size_t)img * n_priors + idx) * 4;
             cand[i][0] = b[0]; cand[i][1] = b[1]; cand[i][2] = b[2]; cand[i][3] = b[3];
         }
     }
-    if (tid == 0) n_kept = 0;
-    __syncthreads();
-    ncand = n_valid < NMS_TOPK ? n_valid : NMS_TOPK;                // the valid keys sort to the front
-    for (int i = 0; i < ncand; ++i) {
-        if (!dead[i]) {                                             // uniform: all threads read the same flag
-            if (tid == 0) kept[n_kept++] = i;
-            for (int j = i + 1 + tid; j < ncand; j += 1024)
-                if (!dead[j] && (double)jaccard(cand[i], cand[j]) > nms_thr) dead[j] = 1;
+    __syncthreads();                                                // key[] beyond the candidates is free from here on
+    // overlap words: bit (j & 63) of ovl[i][j >> 6] = candidate j > i overlaps candidate i above the threshold
+    unsigned long long* ovl = key + MASK_AT;
+    for (int item = tid; item < ncand * WORDS; item += 1024) {
+        const int i = item / WORDS, w = item - i * WORDS;
+        unsigned long long bits = 0ull;
+        const int j0 = w * 64;
+        if (j0 + 63 > i) {
+            for (int b2 = 0; b2 < 64; ++b2) {
+                const int j = j0 + b2;
+                if (j > i && j < ncand && (double)jaccard(cand[i], cand[j]) > nms_thr) bits |= 1ull << b2;
+            }
         }
-        __syncthreads();
+        ovl[item] = bits;
     }
+    __syncthreads();
+    if (tid < 64) {                                                 // one wave: lane w holds word w of the removed set
+        unsigned long long removed = 0ull;
+        int nk = 0;
+        for (int i = 0; i < ncand; ++i) {
+            const unsigned long long wi = __shfl(removed, i >> 6);
+            const unsigned long long row = lane < WORDS ? ovl[i * WORDS + lane] : 0ull;      // independent of `removed`: pipelines
+            if (!((wi >> (i & 63)) & 1ull)) {                       // wave-uniform
+                if (lane == 0) kept[nk] = i;
+                ++nk;
+                removed |= row;
+            }
+        }
+        if (lane == 0) n_kept = nk;
+    }
+    __syncthreads();
     const int nk = n_kept < keep_top_k ? n_kept : keep_top_k;
     for (int r = tid; r < nk; r += 1024) {
         const int i = kept[r];
         float* o = rows + ((size_t)img * keep_top_k + r) * 5;
-        o[0] = __uint_as_float((unsigned)(key[i] >> 32));
+        o[0] = __uint_as_float((unsigned)(ckey[i] >> 32));
         o[1] = cand[i][0]; o[2] = cand[i][1]; o[3] = cand[i][2]; o[4] = cand[i][3];
     }
     if (tid == 0) count[img] = nk;
