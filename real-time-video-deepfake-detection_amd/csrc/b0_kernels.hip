@@ -1339,6 +1339,18 @@ bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int 
         mb2_launch<5, 1, 16, 14, 28, 7, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
         return true;
     }
+    if (var == 15 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {
+        mb2_launch<5, 1, 16, 14, 28, 7, 2, XT, 256, true, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
+        return true;
+    }
+    if (var == 16 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {
+        mb2_launch<5, 1, 16, 14, 28, 14, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
+        return true;
+    }
+    if (var == 17 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {
+        mb2_launch<5, 1, 16, 14, 28, 4, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
+        return true;
+    }
     if (var == 14 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {
         mb2_launch<5, 1, 16, 7, 28, 7, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
         return true;

@@ -109,35 +109,45 @@ void launch_ssd_conv1(const uint8_t* img, const float* w, const float* b, float*
 // rows from it (lane = pixel, 8 consecutive k), and the A fragments of a K-step serve both rows.  The thread-per-pixel
 // kernel above issued 147 x 16 FMAs per thread behind scalar weight loads: 195-240 us per 64 frames, VALU-bound.
 template <bool EXACT>
-__global__ __launch_bounds__(256) void ssd_conv1_mfma_kernel(const uint8_t* __restrict__ img, const unsigned short* __restrict__ w3,
+__global__ __launch_bounds__(256, 3) void ssd_conv1_mfma_kernel(const uint8_t* __restrict__ img, const unsigned short* __restrict__ w3,
                                                              int plane, int Kp, const float* __restrict__ bias,
                                                              float* __restrict__ y, float sb, float sg, float sr, float hb,
                                                              float hg, float hr, int relu) {
-    constexpr int TH = 8, TW = 16, PH = 2 * TH + 5, PW = (2 * TW + 5) * 3, PWP = PW + 1;      // 21 rows x 111 (+1) floats
+    constexpr int TH = 32, TW = 16, RPW = TH / 4, PH = 2 * TH + 5, PW = (2 * TW + 5) * 3, PWP = PW + 1;      // 69 rows x 111 (+1) floats
     __shared__ float patch[PH * PWP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
     const int n = blockIdx.z, ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
     const uint8_t* src = img + (size_t)n * 300 * 300 * 3;
     const int r0 = 2 * ty0 - 3, c0 = (2 * tx0 - 3) * 3;                  // patch origin in the image (row, byte column)
     const float sc[3] = {sb, sg, sr}, sh[3] = {hb, hg, hr};
-    // patch: clamped unconditional byte loads, all in flight before the first LDS store
-    constexpr int NEL = PH * PW, NLD = (NEL + 255) / 256;
-    float pv[NLD];
+    // patch: aligned dword loads (the row segment starts 3 bytes before the patch: c0 - 3 = 96 * blockIdx.x - 12 is a
+    // multiple of 4), clamped and unconditional, all in flight before the first LDS store; 29 dwords cover the 111 bytes
+    // of a row.  (One byte per load - 30 loads and 30 modulo-3 per thread - was a third of the block's time.)
+    constexpr int DW = 29, NEL = PH * DW, NLD = (NEL + 255) / 256;
+    unsigned pv[NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int i = tid + k * 256 < NEL ? tid + k * 256 : NEL - 1;
-        const int r = i / PW, cb = i - r * PW;
-        const int iy = r0 + r, ib = c0 + cb;                              // byte column: pixel ib / 3, channel ib % 3
-        const bool inside = (unsigned)iy < 300u && (unsigned)ib < 900u;
-        const int ci = (ib + 900) % 3;
-        const float v = (float)src[(size_t)(inside ? iy : 0) * 900 + (inside ? ib : 0)] * sc[ci] + sh[ci];
-        pv[k] = inside ? v : 0.f;
+        const int r = i / DW, d = i - r * DW;
+        const int iy = r0 + r, ib = c0 - 3 + 4 * d;                      // first byte column of the dword
+        const bool inside = (unsigned)iy < 300u && ib >= 0 && ib < 900;
+        pv[k] = *reinterpret_cast<const unsigned*>(src + (size_t)(inside ? iy : 0) * 900 + (inside ? ib : 0));
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int i = tid + k * 256 < NEL ? tid + k * 256 : NEL - 1;
-        const int r = i / PW;
-        patch[r * PWP + (i - r * PW)] = pv[k];
+        const int r = i / DW, d = i - r * DW;
+        const int iy = r0 + r, ib0 = c0 - 3 + 4 * d;
+        const bool row_in = (unsigned)iy < 300u;
+        int ci = (ib0 + 900) % 3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ib = ib0 + e, pc = 4 * d + e - 3;                  // patch column of this byte
+            const bool inside = row_in && ib >= 0 && ib < 900;
+            const float v = (float)((pv[k] >> (8 * e)) & 0xFFu) * sc[ci] + sh[ci];
+            if (pc >= 0 && pc < PW) patch[r * PWP + pc] = inside ? v : 0.f;
+            ci = ci == 2 ? 0 : ci + 1;
+        }
     }
     // per-lane patch offsets of the 8 k values of each K-step (k >= 147: offset 0, zero weights)
     int koff[5][8];
@@ -151,9 +161,9 @@ __global__ __launch_bounds__(256) void ssd_conv1_mfma_kernel(const uint8_t* __re
         }
     const v4f b0 = *reinterpret_cast<const v4f*>(bias + 4 * q), b1 = *reinterpret_cast<const v4f*>(bias + 16 + 4 * q);
     __syncthreads();
-    v4f acc[2][2];
+    v4f acc[RPW][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { acc[t][0] = b0; acc[t][1] = b1; }
+    for (int t = 0; t < RPW; ++t) { acc[t][0] = b0; acc[t][1] = b1; }
     const unsigned short* wrow = w3 + (size_t)j * Kp + 8 * q;
 #pragma unroll
     for (int s5 = 0; s5 < 5; ++s5) {
@@ -164,8 +174,8 @@ __global__ __launch_bounds__(256) void ssd_conv1_mfma_kernel(const uint8_t* __re
             for (int pl = 0; pl < 3; ++pl)
                 wf[nt][pl] = *reinterpret_cast<const bf8*>(wrow + (size_t)pl * plane + (size_t)nt * 16 * Kp + s5 * 32);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int py = wave * 2 + t;                                 // tile row of this wave's t-th pixel row
+        for (int t = 0; t < RPW; ++t) {
+            const int py = wave * RPW + t;                               // tile row of this wave's t-th pixel row
             const float* pp = &patch[(2 * py) * PWP + (2 * j) * 3];
             v4f lo, hi;
             lo.x = pp[koff[s5][0]]; lo.y = pp[koff[s5][1]]; lo.z = pp[koff[s5][2]]; lo.w = pp[koff[s5][3]];
@@ -193,8 +203,8 @@ __global__ __launch_bounds__(256) void ssd_conv1_mfma_kernel(const uint8_t* __re
         }
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int oy = ty0 + wave * 2 + t, ox = tx0 + j;
+    for (int t = 0; t < RPW; ++t) {
+        const int oy = ty0 + wave * RPW + t, ox = tx0 + j;
         if (oy < 150 && ox < 150) {
             float* yp = y + (((size_t)n * 150 + oy) * 150 + ox) * 32;
 #pragma unroll
@@ -212,7 +222,7 @@ void launch_ssd_conv1_mfma(const uint8_t* img, const unsigned short* w3, int pla
     bool exact = true;
     for (int c = 0; c < 3; ++c)
         exact = exact && in_scale[c] == 1.f && in_shift[c] == (float)(int)in_shift[c] && in_shift[c] >= -255.f && in_shift[c] <= 0.f;
-    const dim3 grid((150 + 15) / 16, (150 + 7) / 8, n);
+    const dim3 grid((150 + 15) / 16, (150 + 31) / 32, n);
     if (exact)
         hipLaunchKernelGGL(ssd_conv1_mfma_kernel<true>, grid, dim3(256), 0, s, img, w3, plane, Kp, b, y, in_scale[0], in_scale[1],
                            in_scale[2], in_shift[0], in_shift[1], in_shift[2], relu ? 1 : 0);
@@ -336,6 +346,16 @@ constexpr int NMS_TOPK = 400;
 __device__ __forceinline__ float box_area(const float* b) {
     return (b[2] < b[0] || b[3] < b[1]) ? 0.f : (b[2] - b[0]) * (b[3] - b[1]);
 }
+// the same decision `(double)jaccard(a, b) > thr` with the areas given and the division avoided where the answer is
+// clear: q = inter * rcp(union) is within a few ulp of the quotient, so only |q - thr| <= 1e-5 takes the division
+__device__ __forceinline__ bool jaccard_above(const v4f a, float area_a, const v4f b, float area_b, float thr_f, double thr) {
+    if (b.x > a.z || b.z < a.x || b.y > a.w || b.w < a.y) return 0.0 > thr;
+    const float ix = fminf(a.z, b.z) - fmaxf(a.x, b.x), iy = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+    const float inter = ix * iy, uni = area_a + area_b - inter;
+    const float q = inter * __builtin_amdgcn_rcpf(uni);
+    if (fabsf(q - thr_f) > 1e-5f && uni > 0.f) return q > thr_f;
+    return (double)(inter / uni) > thr;
+}
 __device__ __forceinline__ float jaccard(const float* a, const float* b) {
     if (b[0] > a[2] || b[2] < a[0] || b[1] > a[3] || b[3] < a[1]) return 0.f;
     const float ix = fminf(a[2], b[2]) - fmaxf(a[0], b[0]), iy = fminf(a[3], b[3]) - fmaxf(a[1], b[1]);
@@ -353,20 +373,49 @@ __device__ __forceinline__ float jaccard(const float* a, const float* b) {
 //      candidates in order with the `removed` set in registers (lane w = word w) - the 400 block-wide barriers of the
 //      one-candidate-at-a-time loop were most of the kernel (192 us per 64 frames at VALU 0.01 busy).
 // Same tests on the same values in the same order: rows identical to the round-2 kernel.
+// score -> 2048 linear bins (monotone: p * 2048 is exact), and inside one bin 2048 sub-bins of width 2^-22
+__device__ __forceinline__ int nms_bin(float p) { const int b = (int)(p * 2048.f); return b < 0 ? 0 : (b > 2047 ? 2047 : b); }
+__device__ __forceinline__ int nms_sub(float p, int bin) {
+    const int b = (int)((p * 2048.f - (float)bin) * 2048.f);         // exact for p in (0, 1]: 24-bit significand
+    return b < 0 ? 0 : (b > 2047 ? 2047 : b);
+}
+// the lowest bin of hist[2048] whose suffix count (+ `above`) reaches `need`: wave 0, 32 bins per lane.  -> cut bin and the
+// number of keys in the bins above it; (-1, total) when the whole histogram holds fewer than `need`
+__device__ __forceinline__ void nms_cut(const int* hist, int lane, int above0, int need, int* cut, int* above_cut) {
+    int mysum = 0;
+    for (int b2 = 0; b2 < 32; ++b2) mysum += hist[lane * 32 + b2];
+    int suffix = mysum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_down(suffix, off);
+        if (lane + off < 64) suffix += v;
+    }
+    const int above = above0 + suffix - mysum;
+    if (above < need && above + mysum >= need) {
+        int acc = above, b2 = 31;
+        for (; b2 >= 0; --b2) {
+            if (acc + hist[lane * 32 + b2] >= need) break;
+            acc += hist[lane * 32 + b2];
+        }
+        *cut = lane * 32 + (b2 < 0 ? 0 : b2);
+        *above_cut = acc;
+    }
+}
+
 __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ prob,
                                                        int n_priors, float conf_thr, double nms_thr, int keep_top_k,
                                                        float* __restrict__ rows, int* __restrict__ count) {
     constexpr int WORDS = (NMS_TOPK + 63) / 64, SEL_CAP = 4096, MASK_AT = 512;
     __shared__ unsigned long long key[NMS_SORT];
     __shared__ unsigned long long ckey[NMS_TOPK];
-    __shared__ float cand[NMS_TOPK][4];
+    __shared__ __attribute__((aligned(16))) float cand[NMS_TOPK][4];
     __shared__ int kept[NMS_TOPK];
     __shared__ int hist[2048];
-    __shared__ int n_kept, n_valid, n_sel, cut_bin;
+    __shared__ int n_kept, n_valid, n_sel, cut_bin, cut_above, cut_sub;
     static_assert(MASK_AT + NMS_TOPK * WORDS <= NMS_SORT, "the overlap words live in the sort buffer");
     const int tid = threadIdx.x, img = blockIdx.x, lane = tid & 63;
     const float* pr = prob + (size_t)img * n_priors;
-    if (tid == 0) { n_valid = 0; n_sel = 0; n_kept = 0; cut_bin = 0; }
+    if (tid == 0) { n_valid = 0; n_sel = 0; n_kept = 0; }
     for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
     unsigned long long mine[NMS_SORT / 1024];
     __syncthreads();
@@ -379,8 +428,7 @@ __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__
             const float p = pr[i];
             if (p > conf_thr) {
                 k = ((unsigned long long)__float_as_uint(p) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
-                unsigned bin = __float_as_uint(p) >> 19;             // sign 0: 12 significant bits, monotone in p
-                atomicAdd(&hist[bin < 2047u ? bin : 2047u], 1);
+                atomicAdd(&hist[nms_bin(p)], 1);
                 ++local;
             }
         }
@@ -388,37 +436,41 @@ __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__
     }
     if (local) atomicAdd(&n_valid, local);
     __syncthreads();
-    // the lowest bin whose suffix count reaches top_k (all keys when fewer are valid): wave 0, 32 bins per lane
-    if (tid < 64) {
-        int mysum = 0;
-        for (int b2 = 0; b2 < 32; ++b2) mysum += hist[lane * 32 + b2];
-        int suffix = mysum;                                         // inclusive suffix sum over lanes (lane 63 = top bins)
+    // two-level select: the bin that holds the top_k-th score, then (a second histogram over that bin's keys) the sub-bin
+    if (tid == 0) { cut_bin = -1; cut_above = 0; cut_sub = -1; }
+    __syncthreads();
+    if (tid < 64 && n_valid > NMS_TOPK) nms_cut(hist, lane, 0, NMS_TOPK, &cut_bin, &cut_above);
+    __syncthreads();
+    const int cb = cut_bin, ca = cut_above;
+    for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
+    __syncthreads();
+    if (cb >= 0) {
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_down(suffix, off);
-            if (lane + off < 64) suffix += v;
-        }
-        const int above = suffix - mysum;                           // keys in the bins above this lane's
-        if (above < NMS_TOPK && suffix >= NMS_TOPK) {               // the top_k-th key falls into this lane's bins
-            int acc = above, b2 = 31;
-            for (; b2 >= 0; --b2) {
-                acc += hist[lane * 32 + b2];
-                if (acc >= NMS_TOPK) break;
+        for (int r = 0; r < NMS_SORT / 1024; ++r)
+            if (mine[r] != 0ull) {
+                const float p = __uint_as_float((unsigned)(mine[r] >> 32));
+                if (nms_bin(p) == cb) atomicAdd(&hist[nms_sub(p, cb)], 1);
             }
-            cut_bin = lane * 32 + (b2 < 0 ? 0 : b2);
-        }
     }
     __syncthreads();
-    const unsigned cut = n_valid > NMS_TOPK ? (unsigned)cut_bin : 0u;
+    if (tid < 64 && cb >= 0) {
+        int dummy = 0;
+        nms_cut(hist, lane, ca, NMS_TOPK, &cut_sub, &dummy);
+    }
+    __syncthreads();
+    const int cs = cut_sub;
     // selected keys to the front of key[] (any order: unique keys, the sort orders them)
     int sel_local = 0;
 #pragma unroll
     for (int r = 0; r < NMS_SORT / 1024; ++r)
-        if (mine[r] != 0ull) {
-            unsigned bin = (unsigned)(mine[r] >> 51);                // = score bits >> 19
-            bin = bin < 2047u ? bin : 2047u;
-            if (bin >= cut) ++sel_local; else mine[r] = 0ull;
+        if (mine[r] != 0ull && cb >= 0) {
+            const float p = __uint_as_float((unsigned)(mine[r] >> 32));
+            const int bin = nms_bin(p);
+            const bool take = bin > cb || (bin == cb && nms_sub(p, cb) >= cs);
+            if (!take) mine[r] = 0ull;
         }
+#pragma unroll
+    for (int r = 0; r < NMS_SORT / 1024; ++r) sel_local += mine[r] != 0ull ? 1 : 0;
     int base = 0;
     if (sel_local) base = atomicAdd(&n_sel, sel_local);
 #pragma unroll
@@ -453,31 +505,55 @@ __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__
         }
     }
     __syncthreads();                                                // key[] beyond the candidates is free from here on
-    // overlap words: bit (j & 63) of ovl[i][j >> 6] = candidate j > i overlaps candidate i above the threshold
+    // overlap words: bit (j & 63) of ovl[i][j >> 6] = candidate j > i overlaps candidate i above the threshold.  A wave
+    // takes a row i, its lanes 64 consecutive j: one box per lane (conflict-free 16-byte LDS reads), one ballot per word.
+    // (One thread per (row, word) with a 64-step loop read boxes 1 KB apart from every lane - the same LDS bank - and
+    // took 153k of the kernel's 270k cycles.)
     unsigned long long* ovl = key + MASK_AT;
-    for (int item = tid; item < ncand * WORDS; item += 1024) {
-        const int i = item / WORDS, w = item - i * WORDS;
-        unsigned long long bits = 0ull;
-        const int j0 = w * 64;
-        if (j0 + 63 > i) {
-            for (int b2 = 0; b2 < 64; ++b2) {
-                const int j = j0 + b2;
-                if (j > i && j < ncand && (double)jaccard(cand[i], cand[j]) > nms_thr) bits |= 1ull << b2;
+    {
+        const int wave = tid >> 6;
+        const float thr_f = (float)nms_thr;
+        for (int i = wave; i < ncand; i += 16) {
+            const v4f bi = *reinterpret_cast<const v4f*>(cand[i]);
+            const float ai = box_area(cand[i]);
+            for (int w = i >> 6; w < WORDS; ++w) {
+                const int j = w * 64 + lane;
+                const int jc = j < ncand ? j : i;
+                const v4f bj = *reinterpret_cast<const v4f*>(cand[jc]);
+                const float b4[4] = {bj.x, bj.y, bj.z, bj.w};
+                const bool hit = j > i && j < ncand && jaccard_above(bi, ai, bj, box_area(b4), thr_f, nms_thr);
+                const unsigned long long bits = __ballot(hit);
+                if (lane == 0) ovl[i * WORDS + w] = bits;
             }
+            if (lane < (i >> 6)) ovl[i * WORDS + lane] = 0ull;        // words entirely below the diagonal
         }
-        ovl[item] = bits;
     }
     __syncthreads();
     if (tid < 64) {                                                 // one wave: lane w holds word w of the removed set
         unsigned long long removed = 0ull;
         int nk = 0;
-        for (int i = 0; i < ncand; ++i) {
-            const unsigned long long wi = __shfl(removed, i >> 6);
-            const unsigned long long row = lane < WORDS ? ovl[i * WORDS + lane] : 0ull;      // independent of `removed`: pipelines
-            if (!((wi >> (i & 63)) & 1ull)) {                       // wave-uniform
-                if (lane == 0) kept[nk] = i;
-                ++nk;
-                removed |= row;
+        for (int w = 0; w * 64 < ncand; ++w) {
+            // the word that covers candidates 64 w .. 64 w + 63, wave-uniform (two readlanes: no LDS round trip)
+            unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(removed >> 32), w) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)(removed & 0xFFFFFFFFull), w);
+            for (int b0 = 0; b0 < 64 && w * 64 + b0 < ncand; b0 += 8) {
+                unsigned long long rows8[8];                        // eight rows requested together: one LDS latency per eight steps
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = w * 64 + b0 + e;
+                    rows8[e] = (lane < WORDS && i < ncand) ? ovl[i * WORDS + lane] : 0ull;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int b2 = b0 + e, i = w * 64 + b2;
+                    if (i < ncand && !((cur >> b2) & 1ull)) {       // wave-uniform
+                        if (lane == 0) kept[nk] = i;
+                        ++nk;
+                        removed |= rows8[e];
+                        cur |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(rows8[e] >> 32), w) << 32) |
+                               (unsigned)__builtin_amdgcn_readlane((int)(rows8[e] & 0xFFFFFFFFull), w);
+                    }
+                }
             }
         }
         if (lane == 0) n_kept = nk;
