@@ -11,6 +11,21 @@ typedef __bf16 bf16_t;
 
 enum Act { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_PRELU = 3 };   // PRELU: bias points at [N bias][N slope]
 
+// Squeeze-excite finished inside the depthwise-family launch: the block that completes an image's pool partials last
+// (an agent-scope counter per image) computes mean -> FC(c_se) + swish -> FC(C) + sigmoid and writes gate[n][C] - the
+// separate se_kernel launch (16 per forward, ~9 us each plus a launch gap on either side) goes away.
+// counter == null: off (launch_se does it) - the default: measured at batch 256 the fused form is SLOWER (3.59 vs 3.04 ms
+// per step).  The gate is three dependent L2 round trips (pool partials -> FC1 -> FC2) wherever it runs; inside the
+// depthwise launch it adds the agent-scope acquire (~2-7 us on a CU that holds several blocks) in front of them and runs
+// on 4-8 waves instead of 16, and the launch cannot end before the last image's tail has.  Option "fuse_se" keeps it testable.
+struct SeTail {
+    const float *w1 = nullptr, *b1 = nullptr, *w2t = nullptr, *b2 = nullptr;
+    float* gate = nullptr;
+    unsigned* counter = nullptr;     // [n images], zero between launches (the last block of an image resets its entry)
+    float inv_hw = 0.f;
+    int c_se = 0;
+};
+
 // stem: 3x3 stride-2 conv, NCHW (n,3,224,224) -> NHWC (n,112,112,32), folded BN + swish.
 template <typename XT>
 void launch_stem(const float* x_nchw, const float* w /*[3][3][3][32]*/, const float* b,
@@ -23,7 +38,7 @@ void launch_stem(const float* x_nchw, const float* w /*[3][3][3][32]*/, const fl
 // runs on the bf16 MFMA with split-precision operands, K = 27 padded to 32)
 template <typename XT>
 void launch_stem_dw(const float* x_nchw, const unsigned short* ws3, int plane, int Kp, const float* bs, const float* Wd,
-                    const float* bd, XT* Y, float* P, XT* stem_out, int n, int* tiles, hipStream_t s);
+                    const float* bd, XT* Y, float* P, XT* stem_out, int n, int* tiles, hipStream_t s, const SeTail& se = SeTail());
 
 // pointwise conv as GEMM: Y[m][o] = act( sum_k X[m][k]*gate[m/HW][k] * W[o][k] + b[o] ) + R[m][o]
 // gate / R may be null.  X rows have stride K, Y/R rows stride N.
@@ -78,7 +93,7 @@ bool launch_conv_gemm_split(S6Table* tab, const XT* X, const unsigned short* W3,
 template <typename XT>
 bool launch_depthwise(const XT* X, const float* W /*[k][k][C]*/, const float* bias, XT* Y,
                       float* P, int n, int H, int C, int k, int stride, int pad_lo,
-                      int* tiles, hipStream_t s);
+                      int* tiles, hipStream_t s, const SeTail& se = SeTail());
 int depthwise_tiles(int H, int C, int k, int stride);
 // MBConv front half in one kernel: 1x1 expand (+BN+swish) computed per LDS halo tile on the bf16 MFMA with
 // split-precision operands (We3 = the three bf16 planes of We [C][Cin] from launch_split_weights, `plane`
@@ -87,7 +102,7 @@ int depthwise_tiles(int H, int C, int k, int stride);
 template <typename XT>
 bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int plane, int Kp, const float* Wef, const float* be,
                          const float* Wd, const float* bd, XT* Y, float* P, int n, int H, int C, int k, int stride,
-                         int pad_lo, int* tiles, hipStream_t s);
+                         int pad_lo, int* tiles, hipStream_t s, const SeTail& se = SeTail());
 int mbconv_tiles(int H, int C, int k, int stride, int Cin);      // largest pool-tile count of the fused variants, -1: none
 
 // squeeze-excite gate: mean over tiles*pixels -> FC(c_se)+swish -> FC(C)+sigmoid.

@@ -399,6 +399,79 @@ __device__ __forceinline__ BlkId blk_image_major(int bpi) {
 // Measured: it pays where the writes were 8-way conflicted (CG = 8 fused kernel, block 1: 0.263 -> 0.250 ms); at
 // CG = 4 and in the kernels whose producers were conflict-free anyway the per-tap index arithmetic of the reads
 // (no more base + immediate offsets) costs more than the conflicts did (+8 %), so SWZ is on for that one only.
+// ---- squeeze-excite tail ----------------------------------------------------------------------------------------------
+// Called by every thread of a depthwise-family block after its pool partials P[n][tile][c0 ..] are stored (by lanes of
+// wave 0, with agent-scope write-through stores).  Hand-off (MI355X_MICROARCH.md, Workgroup dispatch / Valid forms):
+//   producer  sc1 stores of the partials -> the storing wave's s_waitcnt vmcnt(0) -> ONE lane's agent-scope atomic add on the
+//             image's counter (same wave: the add comes after the wait);
+//   consumer  the block whose add returned bpi - 1 is the last of the image: workgroup barrier -> agent-scope ACQUIRE by
+//             every wave -> s_waitcnt vmcnt(0) -> barrier -> sc1 loads of all partials (several blocks per CU here, so the
+//             acquire stays although stores and loads are both sc1).
+// The last block resets the counter (the next launch on the stream starts from 0), reduces the tiles in index order
+// (four interleaved partial sums, then a fixed fold: the result does not depend on which block came last), and runs the
+// two FCs with the block's NT threads.  `lds`: >= C + 64 floats of the block's LDS that nobody reads any more.
+template <int NT>
+__device__ __forceinline__ void se_tail(const SeTail& T, const float* __restrict__ P, int n, int C, int bpi, int tiles, float* lds) {
+    if (!T.counter) return;                                            // kernel argument: uniform
+    __shared__ int se_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64;
+    if (tid < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // wave 0's partial-sum stores have been acknowledged
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(T.counter + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            se_last = old == (unsigned)(bpi - 1) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (!se_last) return;
+    if (tid == 0) __hip_atomic_store(T.counter + n, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* mean = lds;
+    float* z = lds + ((C + 15) & ~15);
+    const unsigned* p = reinterpret_cast<const unsigned*>(P + (size_t)n * tiles * C);
+    for (int c = tid; c < C; c += NT) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int t = 0;
+        for (; t + 3 < tiles; t += 4) {
+            s0 += __uint_as_float(__hip_atomic_load(p + (size_t)t * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            s1 += __uint_as_float(__hip_atomic_load(p + (size_t)(t + 1) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            s2 += __uint_as_float(__hip_atomic_load(p + (size_t)(t + 2) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            s3 += __uint_as_float(__hip_atomic_load(p + (size_t)(t + 3) * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        for (; t < tiles; ++t) s0 += __uint_as_float(__hip_atomic_load(p + (size_t)t * C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        mean[c] = ((s0 + s1) + (s2 + s3)) * T.inv_hw;
+    }
+    __syncthreads();
+    // FC1 + swish: wave w takes outputs w, w + NW, ...; the lanes stride over the channels, butterfly fold
+    for (int o = wave; o < T.c_se; o += NW) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += mean[c] * T.w1[(size_t)o * C + c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) z[o] = swish1(s + T.b1[o]);
+    }
+    __syncthreads();
+    // FC2 + sigmoid: a thread per channel
+    for (int c = tid; c < C; c += NT) {
+        float s = T.b2[c];
+        for (int o = 0; o < T.c_se; ++o) s += z[o] * T.w2t[(size_t)o * C + c];
+        T.gate[(size_t)n * C + c] = sigmoid1(s);
+    }
+}
+
+// pool partials leave the CU with agent-scope write-through stores (sc1): whichever block of the image runs the
+// squeeze-excite tail reads them with sc1 loads
+__device__ __forceinline__ void stg4_agent(float* p, v4f v) {
+    unsigned* u = reinterpret_cast<unsigned*>(p);
+    __hip_atomic_store(u, __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(u + 1, __float_as_uint(v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(u + 2, __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(u + 3, __float_as_uint(v.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int CG, bool SWZ>
 __device__ __forceinline__ int tile_unit(int p, int c) {
     if constexpr (SWZ && CG >= 8) return p * CG + (c ^ (p & 7));
@@ -477,7 +550,7 @@ __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* 
         if (tid < CG) {
             v4f v = (red[tid] + red[CG + tid]) + (red[2 * CG + tid] + red[3 * CG + tid]);
             if constexpr (NW == 8) v += (red[4 * CG + tid] + red[5 * CG + tid]) + (red[6 * CG + tid] + red[7 * CG + tid]);
-            stg4(P + ((size_t)n * tiles_sp + t) * C + c0 + 4 * tid, v);
+            stg4_agent(P + ((size_t)n * tiles_sp + t) * C + c0 + 4 * tid, v);
         }
     } else {
         // any CG: every (slot, channel quad) partial through LDS, folded in slot order (a fixed order)
@@ -486,7 +559,7 @@ __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* 
         if (tid < CG) {
             v4f v = red[tid];
             for (int sl = 1; sl < NSLOT; ++sl) v += red[sl * CG + tid];
-            stg4(P + ((size_t)n * tiles_sp + t) * C + c0 + 4 * tid, v);
+            stg4_agent(P + ((size_t)n * tiles_sp + t) * C + c0 + 4 * tid, v);
         }
     }
 }
@@ -497,7 +570,7 @@ __global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const XT* __
                                                  const float* __restrict__ bias,
                                                  XT* __restrict__ Y, float* __restrict__ P,
                                                  int H, int Ho, int C, int pad_lo, int tiles_x,
-                                                 int tiles_sp) {
+                                                 int tiles_sp, SeTail se) {
     using Sh = DwShape<K, S, CB, TH, TW>;
     constexpr int CG = Sh::CG, IH = Sh::IH, IW = Sh::IW;
     __shared__ v4f tile[IH * IW * CG];
@@ -537,6 +610,7 @@ __global__ __launch_bounds__(256, (RP >= 4 ? 2 : 4)) void dw_kernel(const XT* __
     }
     __syncthreads();
     dw_compute<K, S, CB, TH, TW, RP, false, XT>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
+    se_tail<256>(se, P, n, C, tiles_sp * (C / CB), tiles_sp, reinterpret_cast<float*>(tile));
 }
 
 // MBConv front half in ONE kernel (blocks 1-5): X is the block INPUT [n][H][H][Cin]; for every
@@ -557,7 +631,7 @@ __global__ __launch_bounds__(256, ((S == 1 && (((TH - 1) * S + K) * ((TW - 1) * 
                                                      const float* __restrict__ bias,
                                                      XT* __restrict__ Y, float* __restrict__ P,
                                                      int H, int Ho, int C, int Cin, int pad_lo,
-                                                     int tiles_x, int tiles_sp) {
+                                                     int tiles_x, int tiles_sp, SeTail se) {
     using Sh = DwShape<K, S, CB, TH, TW>;
     constexpr int CG = Sh::CG, IH = Sh::IH, IW = Sh::IW;
     constexpr int NTB = CB / 16;                        // 16-channel MFMA row tiles per chunk
@@ -670,6 +744,7 @@ __global__ __launch_bounds__(256, ((S == 1 && (((TH - 1) * S + K) * ((TW - 1) * 
         dw_compute<K, S, CB, TH, TW, RP, (CG >= 8), XT>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
         MB_TP(6);
     }
+    se_tail<256>(se, P, n, C, tiles_sp * (C / (CB * NSUB)), tiles_sp, reinterpret_cast<float*>(tile));
 #ifdef MB_TRACE
     if (H == MB_TRACE_H && S == MB_TRACE_S && bid.x == 5 && bid.n == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
 #endif
@@ -713,7 +788,7 @@ __global__ __launch_bounds__(NT, MINB) void mbconv2_kernel(const XT* __restrict_
                                                       const float* __restrict__ bias,
                                                       XT* __restrict__ Y, float* __restrict__ P,
                                                       int H, int Ho, int C, int Cin, int pad_lo,
-                                                      int tiles_x, int tiles_sp) {
+                                                      int tiles_x, int tiles_sp, SeTail se) {
     using Sh = DwShape<K, S, CB, TH, TW>;
     constexpr int CG = Sh::CG, IH = Sh::IH, IW = Sh::IW;
     constexpr int NTB = CB / 16;                        // 16-channel MFMA row tiles of the chunk
@@ -905,6 +980,7 @@ __global__ __launch_bounds__(NT, MINB) void mbconv2_kernel(const XT* __restrict_
         if (tid < CG) stg4(P + ((size_t)n * tiles_sp + t) * C + c0 + 4 * tid, tile[tid] + bv);
     } else {
         dw_compute<K, S, CB, TH, TW, RP, SWZ, XT, ABL, NT>(tile, wl, red, bv, Y, P, n, Ho, C, c0, ty0, tx0, t, tiles_sp);
+        se_tail<NT>(se, P, n, C, tiles_sp * (C / CB), tiles_sp, reinterpret_cast<float*>(tile));
     }
     MB_TP(6);
 #ifdef MB_TRACE
@@ -923,7 +999,7 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
                                                       const float* __restrict__ bs, const float* __restrict__ Wt,
                                                       const float* __restrict__ bias, XT* __restrict__ Y,
                                                       float* __restrict__ P, XT* __restrict__ stem_out,
-                                                      int tiles_x, int tiles_sp) {
+                                                      int tiles_x, int tiles_sp, SeTail se) {
     constexpr int K = 3, S = 1, CB = 32, TH = 8, TW = 16, RP = 4, CG = 8;
     constexpr int IH = TH + 2, IW = TW + 2;                 // 10 x 18 stem pixels
     constexpr int PH = (IH - 1) * 2 + 3, PW = (IW - 1) * 2 + 3, PWP = PW + 1;   // 21 x 37 input patch
@@ -1033,6 +1109,7 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
     __syncthreads();
     MB_TP(5);
     dw_compute<K, S, CB, TH, TW, RP, false, XT>(tile, wl, red, bv, Y, P, n, 112, 32, 0, ty0, tx0, t, tiles_sp);
+    se_tail<256>(se, P, n, 32, tiles_sp, tiles_sp, reinterpret_cast<float*>(tile));
     MB_TP(6);
 #ifdef MB_TRACE
     if (bid.x == 5 && bid.n == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
@@ -1041,35 +1118,35 @@ __global__ __launch_bounds__(256, 3) void stem_dw_kernel(const float* __restrict
 
 template <typename XT>
 void launch_stem_dw(const float* x, const unsigned short* ws3, int plane, int Kp, const float* bs, const float* Wd,
-                    const float* bd, XT* Y, float* P, XT* stem_out, int n, int* tiles, hipStream_t s) {
+                    const float* bd, XT* Y, float* P, XT* stem_out, int n, int* tiles, hipStream_t s, const SeTail& se) {
     const int tx = 112 / 16, ty = 112 / 8;
     *tiles = tx * ty;
     hipLaunchKernelGGL(stem_dw_kernel<XT>, dim3(tx * ty * n), dim3(256), 0, s, x, ws3, plane, Kp, bs, Wd, bd, Y, P, stem_out, tx,
-                       tx * ty);
+                       tx * ty, se);
 }
-template void launch_stem_dw<float>(const float*, const unsigned short*, int, int, const float*, const float*, const float*, float*, float*, float*, int, int*, hipStream_t);
-template void launch_stem_dw<bf16_t>(const float*, const unsigned short*, int, int, const float*, const float*, const float*, bf16_t*, float*, bf16_t*, int, int*, hipStream_t);
+template void launch_stem_dw<float>(const float*, const unsigned short*, int, int, const float*, const float*, const float*, float*, float*, float*, int, int*, hipStream_t, const SeTail&);
+template void launch_stem_dw<bf16_t>(const float*, const unsigned short*, int, int, const float*, const float*, const float*, bf16_t*, float*, bf16_t*, int, int*, hipStream_t, const SeTail&);
 
 template <int K, int S, int CB, int TH, int TW, int RP, typename XT>
 static void dw_launch(const XT* X, const float* W, const float* b, XT* Y, float* P, int n,
-                      int H, int C, int pad_lo, int* tiles, hipStream_t s) {
+                      int H, int C, int pad_lo, int* tiles, hipStream_t s, const SeTail& se) {
     const int Ho = (H + S - 1) / S;
     const int tx = (Ho + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
     const int tiles_sp = tx * ty;
     *tiles = tiles_sp;
     hipLaunchKernelGGL((dw_kernel<K, S, CB, TH, TW, RP, XT>), dim3(tiles_sp * (C / CB) * n), dim3(256), 0,
-                       s, X, W, b, Y, P, H, Ho, C, pad_lo, tx, tiles_sp);
+                       s, X, W, b, Y, P, H, Ho, C, pad_lo, tx, tiles_sp, se);
 }
 
 template <int K, int S, int CB, int TH, int TW, int RP, int KC, int NSUB, typename XT, int CI>
 static void mb_launch(const XT* X, int Cin, const float* We, const float* be, const float* W, const float* b,
-                      XT* Y, float* P, int n, int H, int C, int pad_lo, int* tiles, hipStream_t s) {
+                      XT* Y, float* P, int n, int H, int C, int pad_lo, int* tiles, hipStream_t s, const SeTail& se) {
     const int Ho = (H + S - 1) / S;
     const int tx = (Ho + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
     const int tiles_sp = tx * ty;
     *tiles = tiles_sp;
     hipLaunchKernelGGL((mbconv_kernel<K, S, CB, TH, TW, RP, KC, NSUB, XT, CI>), dim3(tiles_sp * (C / (CB * NSUB)) * n),
-                       dim3(256), 0, s, X, We, be, W, b, Y, P, H, Ho, C, Cin, pad_lo, tx, tiles_sp);
+                       dim3(256), 0, s, X, We, be, W, b, Y, P, H, Ho, C, Cin, pad_lo, tx, tiles_sp, se);
 }
 
 
@@ -1084,9 +1161,9 @@ static void mb_launch(const XT* X, int Cin, const float* We, const float* be, co
 template <int K, int CPT, typename XT>
 __global__ __launch_bounds__(256) void dw_rows7_kernel(const XT* __restrict__ X, const float* __restrict__ Wt,
                                                        const float* __restrict__ bias, XT* __restrict__ Y,
-                                                       float* __restrict__ P, int C, int groups) {
+                                                       float* __restrict__ P, int C, int groups, SeTail se) {
     constexpr int H = 7, PAD = (K - 1) / 2, NV = CPT / 4;
-    __shared__ v4f red[8 * 32 * NV];
+    __shared__ v4f red[8 * 32 * NV > 320 ? 8 * 32 * NV : 320];             // >= 1280 floats: the squeeze-excite tail's scratch
     const BlkId bid = blk_image_major(groups);
     const int tid = threadIdx.x, row = tid >> 5, cl = tid & 31;
     const int c = (bid.x * 32 + cl) * CPT;
@@ -1152,24 +1229,27 @@ __global__ __launch_bounds__(256) void dw_rows7_kernel(const XT* __restrict__ X,
             v4f t = red[tid * NV + v];
 #pragma unroll
             for (int rr = 1; rr < H; ++rr) t += red[(rr * 32 + tid) * NV + v];
-            stg4(P + (size_t)bid.n * C + c + 4 * v, t);
+            stg4_agent(P + (size_t)bid.n * C + c + 4 * v, t);
         }
     }
+    __syncthreads();                                                   // red[] is the tail's scratch from here on
+    se_tail<256>(se, P, bid.n, C, groups, 1, reinterpret_cast<float*>(red));
 }
 
 template <int K, typename XT>
-static void dw_rows7_launch(const XT* X, const float* W, const float* b, XT* Y, float* P, int n, int C, int* tiles, hipStream_t s) {
+static void dw_rows7_launch(const XT* X, const float* W, const float* b, XT* Y, float* P, int n, int C, int* tiles, hipStream_t s,
+                            const SeTail& se) {
     *tiles = 1;
     if constexpr (sizeof(XT) == 2) {
         static const int cpt = getenv("DFD_ROWS7_CPT") ? atoi(getenv("DFD_ROWS7_CPT")) : (K == 5 ? 4 : 8);
         if (cpt == 8) {
             const int groups = (C + 255) / 256;
-            hipLaunchKernelGGL((dw_rows7_kernel<K, 8, XT>), dim3(groups * n), dim3(256), 0, s, X, W, b, Y, P, C, groups);
+            hipLaunchKernelGGL((dw_rows7_kernel<K, 8, XT>), dim3(groups * n), dim3(256), 0, s, X, W, b, Y, P, C, groups, se);
             return;
         }
     }
     const int groups = (C + 127) / 128;
-    hipLaunchKernelGGL((dw_rows7_kernel<K, 4, XT>), dim3(groups * n), dim3(256), 0, s, X, W, b, Y, P, C, groups);
+    hipLaunchKernelGGL((dw_rows7_kernel<K, 4, XT>), dim3(groups * n), dim3(256), 0, s, X, W, b, Y, P, C, groups, se);
 }
 
 // tile shapes per B0 depthwise layer class: (k, stride, H_in, C) -> <K,S,CB,TH,TW,RP>
@@ -1189,25 +1269,25 @@ static void dw_rows7_launch(const XT* X, const float* W, const float* b, XT* Y, 
 
 template <typename XT>
 bool launch_depthwise(const XT* X, const float* W, const float* bias, XT* Y, float* P, int n,
-                      int H, int C, int k, int stride, int pad_lo, int* tiles, hipStream_t s) {
+                      int H, int C, int k, int stride, int pad_lo, int* tiles, hipStream_t s, const SeTail& se) {
 #define DFD_DW_DISPATCH(KK, SS, HH, CC, CB, TH, TW, RP)                                \
     if (k == KK && stride == SS && H == HH && C == CC) {                               \
-        dw_launch<KK, SS, CB, TH, TW, RP, XT>(X, W, bias, Y, P, n, H, C, pad_lo, tiles, s); \
+        dw_launch<KK, SS, CB, TH, TW, RP, XT>(X, W, bias, Y, P, n, H, C, pad_lo, tiles, s, se); \
         return true;                                                                   \
     }
     // 7 x 7 stride-1 layers: the row-per-thread kernel (DFD_DW_ROWS7=0: the LDS-tile kernel, for A/B runs)
     static const bool rows7 = !(getenv("DFD_DW_ROWS7") && atoi(getenv("DFD_DW_ROWS7")) == 0);
     if (rows7 && H == 7 && stride == 1 && C % 8 == 0 && (k == 3 || k == 5) && pad_lo == (k - 1) / 2) {
-        if (k == 3) dw_rows7_launch<3, XT>(X, W, bias, Y, P, n, C, tiles, s);
-        else dw_rows7_launch<5, XT>(X, W, bias, Y, P, n, C, tiles, s);
+        if (k == 3) dw_rows7_launch<3, XT>(X, W, bias, Y, P, n, C, tiles, s, se);
+        else dw_rows7_launch<5, XT>(X, W, bias, Y, P, n, C, tiles, s, se);
         return true;
     }
     DFD_DW_TABLE(DFD_DW_DISPATCH)
 #undef DFD_DW_DISPATCH
     return false;
 }
-template bool launch_depthwise<float>(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int*, hipStream_t);
-template bool launch_depthwise<bf16_t>(const bf16_t*, const float*, const float*, bf16_t*, float*, int, int, int, int, int, int, int*, hipStream_t);
+template bool launch_depthwise<float>(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int*, hipStream_t, const SeTail&);
+template bool launch_depthwise<bf16_t>(const bf16_t*, const float*, const float*, bf16_t*, float*, int, int, int, int, int, int, int*, hipStream_t, const SeTail&);
 
 // expand (1x1 + BN + swish) fused into the depthwise kernel; only the five large-spatial MBConv
 // blocks (1..5) are instantiated: there the expanded tensor dominates HBM traffic and C_in <= 48.
@@ -1283,19 +1363,20 @@ static int mb_variant(int H, int stride) {
 template <int K, int S, int CB, int TH, int TW, int RP, int NK, typename XT, int NT = 256, bool INS = false, int CI = 0,
           int MINB = (NT == 256 ? 2 : 4)>
 static void mb2_launch(const XT* X, int Cin, const unsigned short* We3, int plane, int Kp, const float* Wef, const float* be,
-                       const float* W, const float* b, XT* Y, float* P, int n, int H, int C, int pad_lo, int* tiles, hipStream_t s) {
+                       const float* W, const float* b, XT* Y, float* P, int n, int H, int C, int pad_lo, int* tiles, hipStream_t s,
+                       const SeTail& se) {
     const int Ho = (H + S - 1) / S;
     const int tx = (Ho + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
     const int tiles_sp = tx * ty;
     *tiles = tiles_sp;
     hipLaunchKernelGGL((mbconv2_kernel<K, S, CB, TH, TW, RP, NK, XT, 0, NT, INS, CI, MINB>), dim3(tiles_sp * (C / CB) * n), dim3(NT), 0, s, X,
-                       We3, plane, Kp, Wef, be, W, b, Y, P, H, Ho, C, Cin, pad_lo, tx, tiles_sp);
+                       We3, plane, Kp, Wef, be, W, b, Y, P, H, Ho, C, Cin, pad_lo, tx, tiles_sp, se);
 }
 
 template <typename XT>
 bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int plane, int Kp, const float* Wef, const float* be,
                          const float* Wd, const float* bd, XT* Y, float* P, int n, int H, int C, int k, int stride,
-                         int pad_lo, int* tiles, hipStream_t s) {
+                         int pad_lo, int* tiles, hipStream_t s, const SeTail& se) {
     int var = mb_variant(H, stride);
     if (var == -2) {
         // defaults by measurement at batch 256 (profiles/mb_variants.py, round 3, us fp32 / bf16):
@@ -1312,7 +1393,7 @@ bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int 
         if (var <= -1) {
 #define DFD_MB1_DISPATCH(VV, KK, SS, HH, CC, CI, CB, TH, TW, RP, KC, NSUB)                                            \
     if (var == VV && k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                  \
-        mb_launch<KK, SS, CB, TH, TW, RP, KC, NSUB, XT, CI>(Xin, Cin, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);  \
+        mb_launch<KK, SS, CB, TH, TW, RP, KC, NSUB, XT, CI>(Xin, Cin, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s, se);  \
         return true;                                                                                                \
     }
             DFD_MB1_TABLE(DFD_MB1_DISPATCH)
@@ -1322,41 +1403,41 @@ bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int 
     if (var < 0) var = 0;
 #define DFD_MB2_DISPATCH(VV, KK, SS, HH, CC, CI, CB, TH, TW, RP, NK)                                                 \
     if (var == VV && k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                  \
-        mb2_launch<KK, SS, CB, TH, TW, RP, NK, XT, 256, false, CI>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s); \
+        mb2_launch<KK, SS, CB, TH, TW, RP, NK, XT, 256, false, CI>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s, se); \
         return true;                                                                                                \
     }
     DFD_MB2_TABLE(DFD_MB2_DISPATCH)
 #undef DFD_MB2_DISPATCH
 #define DFD_MB3_DISPATCH(VV, KK, SS, HH, CC, CI, CB, TH, TW, RP, NK, NT, INS)                                       \
     if (var == VV && k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                  \
-        mb2_launch<KK, SS, CB, TH, TW, RP, NK, XT, NT, INS, CI>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s); \
+        mb2_launch<KK, SS, CB, TH, TW, RP, NK, XT, NT, INS, CI>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s, se); \
         return true;                                                                                                \
     }
     DFD_MB3_TABLE(DFD_MB3_DISPATCH)
 #undef DFD_MB3_DISPATCH
     // four blocks per CU (128 VGPRs, ring of 3): more waves in different phases on a SIMD
     if (var == 13 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {
-        mb2_launch<5, 1, 16, 14, 28, 7, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
+        mb2_launch<5, 1, 16, 14, 28, 7, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s, se);
         return true;
     }
     if (var == 15 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {
-        mb2_launch<5, 1, 16, 14, 28, 7, 2, XT, 256, true, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
+        mb2_launch<5, 1, 16, 14, 28, 7, 2, XT, 256, true, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s, se);
         return true;
     }
     if (var == 16 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {
-        mb2_launch<5, 1, 16, 14, 28, 14, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
+        mb2_launch<5, 1, 16, 14, 28, 14, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s, se);
         return true;
     }
     if (var == 17 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {
-        mb2_launch<5, 1, 16, 14, 28, 4, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
+        mb2_launch<5, 1, 16, 14, 28, 4, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s, se);
         return true;
     }
     if (var == 14 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {
-        mb2_launch<5, 1, 16, 7, 28, 7, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
+        mb2_launch<5, 1, 16, 7, 28, 7, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s, se);
         return true;
     }
     if (var == 13 && k == 3 && stride == 1 && H == 56 && C == 144 && Cin == 24) {
-        mb2_launch<3, 1, 16, 14, 28, 7, 1, XT, 256, true, 24, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s);
+        mb2_launch<3, 1, 16, 14, 28, 7, 1, XT, 256, true, 24, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s, se);
         return true;
     }
 #ifdef DFD_MB_ABLATION
@@ -1365,13 +1446,13 @@ bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int 
         const int tx = 2, ty = 4;                                                                                   \
         *tiles = tx * ty;                                                                                           \
         hipLaunchKernelGGL((mbconv2_kernel<3, 1, 16, 14, 28, 7, 1, XT, A, 256, false, 24>), dim3(tx * ty * (C / 16) * n), dim3(256), 0, s, Xin, \
-                           We3, plane, Kp, Wef, be, Wd, bd, Y, P, H, 56, C, Cin, pad_lo, tx, tx * ty);              \
+                           We3, plane, Kp, Wef, be, Wd, bd, Y, P, H, 56, C, Cin, pad_lo, tx, tx * ty, se);          \
         return true;                                                                                                \
     }                                                                                                               \
     if (var == 20 + A && H == 28 && stride == 1) {                                                                  \
         *tiles = 1;                                                                                                 \
         hipLaunchKernelGGL((mbconv2_kernel<5, 1, 16, 28, 28, 7, 2, XT, A, 256, false, 40>), dim3((C / 16) * n), dim3(256), 0, s, Xin,   \
-                           We3, plane, Kp, Wef, be, Wd, bd, Y, P, H, 28, C, Cin, pad_lo, 1, 1);                     \
+                           We3, plane, Kp, Wef, be, Wd, bd, Y, P, H, 28, C, Cin, pad_lo, 1, 1, se);                 \
         return true;                                                                                                \
     }
     DFD_MB2_ABL(DFD_ABL_CASE)
@@ -1379,8 +1460,8 @@ bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int 
 #endif
     return false;
 }
-template bool launch_mbconv_front<float>(const float*, int, const unsigned short*, int, int, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int*, hipStream_t);
-template bool launch_mbconv_front<bf16_t>(const bf16_t*, int, const unsigned short*, int, int, const float*, const float*, const float*, const float*, bf16_t*, float*, int, int, int, int, int, int, int*, hipStream_t);
+template bool launch_mbconv_front<float>(const float*, int, const unsigned short*, int, int, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int*, hipStream_t, const SeTail&);
+template bool launch_mbconv_front<bf16_t>(const bf16_t*, int, const unsigned short*, int, int, const float*, const float*, const float*, const float*, bf16_t*, float*, int, int, int, int, int, int, int*, hipStream_t, const SeTail&);
 
 // SE pool partial-sum tiles of a fused launch (the workspace is sized for the largest count over all variants)
 int mbconv_tiles(int H, int C, int k, int stride, int Cin) {

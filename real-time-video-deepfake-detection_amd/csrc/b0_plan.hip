@@ -236,6 +236,18 @@ static int b0_forward_t(dfd_handle* h, const float* x, int n, float* logits_dev,
     XT* const expbuf = reinterpret_cast<XT*>(h->expbuf);
     XT* const dwbuf = reinterpret_cast<XT*>(h->dwbuf);
     XT* const headbuf = reinterpret_cast<XT*>(h->headbuf);
+    // squeeze-excite inside the depthwise-family launch (option "fuse_se"): the last block of an image writes the gate
+    auto se_of = [&](const B0Block& b) {
+        SeTail t;
+        if (h->fuse_se && h->se_counter) {
+            t.w1 = b.se_w1; t.b1 = b.se_b1; t.w2t = b.se_w2; t.b2 = b.se_b2;
+            t.gate = h->gate; t.counter = h->se_counter;
+            t.inv_hw = 1.0f / (float)(b.h_out * b.h_out);
+            t.c_se = b.c_se;
+        }
+        return t;
+    };
+    const bool se_fused = h->fuse_se && h->se_counter;
     mk.mark("start");
     // block 0 has no expand conv: its depthwise input IS the stem output, so the two fuse (option "fuse_stem")
     const bool stem_fused = h->fuse_stem && P.blocks[0].expand == 1;
@@ -245,7 +257,7 @@ static int b0_forward_t(dfd_handle* h, const float* x, int n, float* logits_dev,
         const unsigned short* ws3 = split_weights(h, P.stem_w, 32, 27, true);          // [ky][kx][ci][co] = [27][32], transposed
         if (!ws3) return DFD_ERR_HIP;
         launch_stem_dw<XT>(x, ws3, (int)split_weights_count(32, 27), 64, P.stem_b, P.blocks[0].dw_w, P.blocks[0].dw_b, dwbuf,
-                           h->pool, want_stem ? io0 : (XT*)nullptr, n, &stem_tiles, s);
+                           h->pool, want_stem ? io0 : (XT*)nullptr, n, &stem_tiles, s, se_of(P.blocks[0]));
         mk.mark("b0.dw");                               // stem + depthwise of block 0 in one launch
     } else {
         launch_stem<XT>(x, P.stem_w, P.stem_b, io0, n, s);
@@ -266,7 +278,7 @@ static int b0_forward_t(dfd_handle* h, const float* x, int n, float* logits_dev,
             !(we3 = split_weights(h, b.exp_w, b.c_exp, b.c_in))) return DFD_ERR_HIP;
         if (we3 && launch_mbconv_front<XT>(cur, b.c_in, we3, (int)split_weights_count(b.c_exp, b.c_in), (b.c_in + 63) / 64 * 64,
                                            b.exp_w, b.exp_b, b.dw_w, b.dw_b, dwbuf, h->pool, n, b.h_in, b.c_exp,
-                                           b.kernel, b.stride, b.pad_lo, &tiles, s)) {
+                                           b.kernel, b.stride, b.pad_lo, &tiles, s, se_of(b))) {
             fused = true;
             mk.mark(layer_name(bi, "dw"));            // expand + depthwise in one launch
             if (tap && tap->name && q + ".exp" == tap->name)
@@ -284,14 +296,16 @@ static int b0_forward_t(dfd_handle* h, const float* x, int n, float* logits_dev,
             tiles = stem_tiles;
         } else if (!fused) {
             if (!launch_depthwise<XT>(dw_in, b.dw_w, b.dw_b, dwbuf, h->pool, n, b.h_in, b.c_exp, b.kernel,
-                                      b.stride, b.pad_lo, &tiles, s))
+                                      b.stride, b.pad_lo, &tiles, s, se_of(b)))
                 return fail(h, DFD_ERR_STATE, "no depthwise kernel for block %d", bi);
             mk.mark(layer_name(bi, "dw"));
         }
         if ((rc = tap_out(h, tap, q + ".dw", dwbuf, (size_t)m_out * b.c_exp))) return rc;
-        launch_se(h->pool, tiles, 1.0f / (float)(b.h_out * b.h_out), b.se_w1, b.se_b1, b.se_w2, b.se_b2,
-                  h->gate, n, b.c_exp, b.c_se, s);
-        mk.mark(layer_name(bi, "se"));
+        if (!se_fused) {
+            launch_se(h->pool, tiles, 1.0f / (float)(b.h_out * b.h_out), b.se_w1, b.se_b1, b.se_w2, b.se_b2,
+                      h->gate, n, b.c_exp, b.c_se, s);
+            mk.mark(layer_name(bi, "se"));
+        }
         if ((rc = tap_out(h, tap, q + ".gate", h->gate, (size_t)n * b.c_exp))) return rc;
         if ((rc = pointwise_t<XT>(h, dwbuf, b.proj_w, b.proj_b, h->gate, b.skip ? cur : (const XT*)nullptr, nxt, m_out,
                                   b.c_exp, b.c_out, b.h_out * b.h_out, ACT_NONE))) return rc;

@@ -37,6 +37,7 @@ int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, in
     h->max_batch = max_batch;
     if (const char* e = getenv("DFD_FUSE_EXPAND")) h->fuse_expand = atoi(e) != 0;
     if (const char* e = getenv("DFD_FUSE_STEM")) h->fuse_stem = atoi(e) != 0;
+    if (const char* e = getenv("DFD_FUSE_SE")) h->fuse_se = atoi(e) != 0;
     if (const char* e = getenv("DFD_SPLIT_GEMM")) h->split_gemm = atoi(e) != 0;
     if (const char* e = getenv("DFD_BF16_ACTIVATIONS")) h->act_bf16 = atoi(e) != 0;
     h->gemm = s6_table_create();
@@ -81,6 +82,13 @@ int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, in
     if ((rc = dev_alloc(h, nb * 512 * 4, &h->fc1))) return rc;
     if ((rc = dev_alloc(h, nb * 256 * 4, &h->fc2))) return rc;
     if ((rc = dev_alloc(h, nb * 4, &h->logits))) return rc;
+    {   // per-image arrival counters of the squeeze-excite tail: zero between launches (self-cleaning)
+        float* c = nullptr;
+        if ((rc = dev_alloc(h, nb * 4, &c))) return rc;
+        h->se_counter = reinterpret_cast<unsigned*>(c);
+        DFD_HIP_TRY(h, hipMemsetAsync(h->se_counter, 0, nb * 4, h->stream));
+        DFD_HIP_TRY(h, stream_sync(h));
+    }
     return DFD_OK;
 }
 
@@ -145,6 +153,7 @@ int dfd_max_batch(const dfd_handle* h) { return h ? h->max_batch : DFD_ERR_ARG; 
 int dfd_set_option(dfd_handle* h, const char* name, int value) {
     if (!h || !name) return DFD_ERR_ARG;
     if (strcmp(name, "fuse_expand") == 0) { h->fuse_expand = value != 0; return DFD_OK; }
+    if (strcmp(name, "fuse_se") == 0) { h->fuse_se = value != 0; return DFD_OK; }
     if (strcmp(name, "fuse_stem") == 0) { h->fuse_stem = value != 0; return DFD_OK; }
     if (strcmp(name, "split_gemm") == 0) { h->split_gemm = value != 0; return DFD_OK; }
     if (strcmp(name, "mtcnn") == 0) { h->use_mtcnn = value != 0; return DFD_OK; }

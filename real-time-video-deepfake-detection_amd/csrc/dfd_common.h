@@ -116,6 +116,9 @@ struct dfd_handle {
     bool use_mtcnn = true;                    // classify paths align each crop with the cascade when the blob has one
     bool fuse_stem = true;               // stem conv computed inside block 0's depthwise kernel
     bool fuse_expand = true;             // MBConv blocks 1-5: expand conv computed inside the depthwise kernel
+    bool fuse_se = false;                // squeeze-excite gate computed by the last block of each image inside the depthwise launch
+                                         // (measured slower than the separate launch: DESIGN.md section 5, round 3; kept as an option)
+    unsigned* se_counter = nullptr;      // [max_batch] arrival counters of that hand-off (zero between launches)
     bool split_gemm = true;              // 1x1 / k x k convs on the bf16x3-split MFMA path (gemm_split.hip)
     bool act_bf16 = false;               // classifier activations stored as bf16 (fp32 arithmetic): configs[3]
     int bf16_planes = 3;                 // weight planes the bf16-activation GEMMs use: 3 = fp32-exact weights, 1 = bf16 weights

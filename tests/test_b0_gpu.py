@@ -171,3 +171,30 @@ def test_split_gemm_matches_fp32_mfma_and_oracle(b0_handle, ref):
     for mode in (0, 1):
         assert np.abs(got[mode]["logits"] - y.reshape(-1)).max() <= LOGIT_TOL, mode
     assert np.abs(got[0]["logits"] - got[1]["logits"]).max() <= 5e-5
+
+
+def test_fused_squeeze_excite_tail_matches_the_separate_launch(pkg, b0_handle, seeded_sd):
+    """Option "fuse_se": the last depthwise block of each image (agent-scope counter hand-off) computes the gate instead
+    of se_kernel.  Off by default (slower); the hand-off protocol is still held to the oracle here:
+    every gate and the logits within the fp32 bar, identical run to run and across batch positions."""
+    rs = np.random.RandomState(77)
+    x = (rs.randn(5, 3, 224, 224) * 0.8).astype(np.float32)
+    taps = {}
+    want = b0_ref.forward(pkg.weights.to_torch(seeded_sd), torch.from_numpy(x), taps).numpy()
+    base = b0_handle.classify(x)
+    b0_handle.set_option("fuse_se", 1)
+    try:
+        got = b0_handle.classify(x)
+        assert np.abs(got - want).max() <= 1e-3 and np.abs(got - base).max() <= 1e-5
+        assert np.array_equal(b0_handle.classify(x), got)
+        assert np.array_equal(b0_handle.classify(x[3:4]), got[3:4])
+        xd = b0_handle.alloc(x.nbytes).upload(x)
+        try:
+            for i in (0, 4, 9, 12, 15):
+                w = taps[f"b{i}.gate"].numpy().reshape(-1)
+                g = b0_handle.tap(xd.ptr, 5, f"b{i}.gate", w.size)
+                assert np.abs(g - w).max() <= 1e-4, i
+        finally:
+            xd.free()
+    finally:
+        b0_handle.set_option("fuse_se", 0)
