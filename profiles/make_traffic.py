@@ -68,7 +68,7 @@ def main():
         wr = w.get(k, [0.0, 1])[0] * 1024 / forwards
         rows.append({"kernel": k.split("(")[0], "launches_per_forward": f[k][1] / forwards,
                      "fetch_bytes_per_forward": fe, "write_bytes_per_forward": wr})
-        if "dw_kernel" in k or "mbconv" in k:             # fused stem/expand + depthwise launches are depthwise launches
+        if "dw_kernel" in k or "mbconv" in k or "dw_rows7" in k:             # fused stem/expand + depthwise launches are depthwise launches
             dw_bytes += fe + wr
     here = os.path.dirname(os.path.abspath(__file__))
     json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {forwards} forwards of batch 256 ({tag})",

@@ -190,14 +190,33 @@ __device__ __forceinline__ int mt_find(const long long* __restrict__ pre, int n,
     return lo;
 }
 
+// The item that holds element t, searched only between the items of the block's first and last element (lohi[0..1],
+// found by two threads with the full search and shared through LDS): a block's 256 consecutive elements span one or two
+// pyramid levels, so the per-thread search is 0-2 steps instead of log2(n) = 11 dependent loads of `pre`.
+__device__ __forceinline__ int mt_find_in(const long long* __restrict__ pre, const int* lohi, long long t) {
+    int lo = lohi[0], hi = lohi[1] + 1;                        // pre[lo] <= t < pre[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pre[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
 // one thread per output pixel (three channel sums share the window walk and the index arithmetic; the sums are exact
 // integers below 2^24, so their order is free); pre = running totals of output ELEMENTS (pixels x 3)
 __global__ __launch_bounds__(256) void mt_area_resize_ragged_kernel(const MtLevel* __restrict__ lv,
                                                                     const long long* __restrict__ pre, int n,
                                                                     float* __restrict__ dst) {
+    __shared__ int lohi[2];
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < 2) {
+        const long long e = ((long long)blockIdx.x * 256 + (threadIdx.x ? 255 : 0)) * 3;
+        lohi[threadIdx.x] = mt_find(pre, n, e < pre[n] ? e : pre[n] - 1);
+    }
+    __syncthreads();
     if (t * 3 >= pre[n]) return;
-    const int i = mt_find(pre, n, t * 3);
+    const int i = mt_find_in(pre, lohi, t * 3);
     const MtLevel L = lv[i];
     const long long r = t - pre[i] / 3;
     const int ox = (int)(r % L.ow), oy = (int)(r / L.ow);
@@ -244,6 +263,13 @@ __global__ __launch_bounds__(256) void mt_convpx_kernel(const float* __restrict_
     constexpr int CC = CI % 2 == 0 ? 2 : 1;                  // channels per activation load
     constexpr int NW = CI * K * K * CO;
     __shared__ __attribute__((aligned(16))) float sw[NW + (HEADS ? CO * 6 + 8 : 0)];
+    __shared__ int lohi[P][2];
+    if (items && threadIdx.x < 2 * P) {                        // the items of each pixel slot's first / last element of this block
+        const int p = threadIdx.x >> 1, e = threadIdx.x & 1;
+        const long long pix = (long long)blockIdx.x * 256 + (e ? 255 : 0) + (long long)p * gridDim.x * 256;
+        const long long last = pre[n] / CO - 1;
+        lohi[p][e] = mt_find(pre, n, (pix < last ? pix : last) * CO);
+    }
     for (int i = threadIdx.x; i < NW; i += 256) sw[i] = w[i];
     if (HEADS) {
         for (int i = threadIdx.x; i < CO * 2; i += 256) sw[NW + i] = w41[i];
@@ -265,7 +291,7 @@ __global__ __launch_bounds__(256) void mt_convpx_kernel(const float* __restrict_
         ok[p] = pix < npix;
         const long long q = ok[p] ? pix : 0;
         if (items) {
-            const int i = mt_find(pre, n, q * CO);
+            const int i = ok[p] ? mt_find_in(pre, lohi[p], q * CO) : 0;
             const MtItem it = items[i];
             const long long r = q - pre[i] / CO;
             const int ow = it.iw - K + 1;
@@ -389,10 +415,16 @@ __global__ __launch_bounds__(256) void mt_pnet_conv1_pool_kernel(const float* __
                                                                  float* __restrict__ y, const MtItem* __restrict__ items,
                                                                  const long long* __restrict__ pre, int n) {
     constexpr int CO = 10;
+    __shared__ int lohi[2];
     const long long npix = pre[n] / CO;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long q = t < npix ? t : npix - 1;             // surplus threads redo the last pixel (uniform control flow)
-    const int i = mt_find(pre, n, q * CO);
+    if (threadIdx.x < 2) {
+        const long long e = (long long)blockIdx.x * 256 + (threadIdx.x ? 255 : 0);
+        lohi[threadIdx.x] = mt_find(pre, n, (e < npix ? e : npix - 1) * CO);
+    }
+    __syncthreads();
+    const int i = mt_find_in(pre, lohi, q * CO);
     const MtItem it = items[i];
     const long long r = q - pre[i] / CO;
     const int c1h = it.ih - 2, c1w = it.iw - 2;
