@@ -25,7 +25,7 @@ yd = h.alloc(1024)
 h.warmup(256, 0)
 blocks = {(112, 2): "b1.dw", (56, 1): "b2.dw", (56, 2): "b3.dw", (28, 1): "b4.dw", (28, 2): "b5.dw"}
 # -1 = first generation (fp32, stride 2 only), 0-1 = DFD_MB2_TABLE, 6.. = DFD_MB3_TABLE (round 3: NT / INS)
-nvar = {(112, 2): [-1] if not bf16 else [0, 1], (56, 1): [6], (56, 2): [-1], (28, 1): [13, 15, 16, 17],
+nvar = {(112, 2): [-1] if not bf16 else [0, 1], (56, 1): [6, 18], (56, 2): [-1], (28, 1): [13, 18],
         (28, 2): [-3]}
 if os.environ.get("MB_VARS"):
     nvar = {k: [int(v) for v in os.environ["MB_VARS"].split(",")] for k in nvar}

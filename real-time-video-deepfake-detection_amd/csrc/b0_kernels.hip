@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256, ((S == 1 && (((TH - 1) * S + K) * ((TW - 1) * 
 //     old value had to be copied aside, the copy landed in the loop latch behind `s_waitcnt vmcnt(0)` (ISA), and every
 //     4-tile iteration drained the whole ring - an s_memtime trace put 64 % of block 4's time in that loop.
 template <int K, int S, int CB, int TH, int TW, int RP, int NK, typename XT, int ABL = 0, int NT = 256, bool INS = false,
-          int CI = 0, int MINB = (NT == 256 ? 2 : 4)>
+          int CI = 0, int MINB = (NT == 256 ? 2 : 4), bool SKEW = false>
 __global__ __launch_bounds__(NT, MINB) void mbconv2_kernel(const XT* __restrict__ X,
                                                       const unsigned short* __restrict__ We3, int plane, int Kp,
                                                       const float* __restrict__ Wef,
@@ -914,6 +914,25 @@ __global__ __launch_bounds__(NT, MINB) void mbconv2_kernel(const XT* __restrict_
     }
     MB_TP(1);
 
+    // SKEW (off): the MFMAs of tile t are issued, then the epilogue of tile t - 1 (swish + LDS store) while they sit in the
+    // matrix pipe.  Measured again in round 3, after the wait-count fixes: block 2 186.6 vs 185.4 us, block 4 119.3 vs
+    // 117.6, bf16 the same - within noise in both directions; four waves per SIMD already fill each other's gaps.
+    auto epilogue = [&](int mt, const v4f (&acc)[NTB]) {
+        int pr, pcol;
+        tile_rc(mt * 16 + j, pr, pcol);
+        const int p = pr * IW + pcol;                               // unit of the LDS tile
+        const int iy = iy0 + pr, ix = ix0 + pcol;
+        const bool inside = INS || ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H);
+        if (mt < nmt && mt * 16 + j < (INS ? npin : NPX)) {
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt)
+                tile[tile_unit<CG, SWZ>(p, nt * 4 + q)] = inside ? (ABL == 2 ? acc[nt] : swish4(acc[nt])) : (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    v4f prev[NTB];
+#pragma unroll
+    for (int nt = 0; nt < NTB; ++nt) prev[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    int prev_mt = nmt;                                              // no tile yet: the first epilogue stores nothing
 #pragma unroll 1
     for (int it0 = 0; it0 < NIT; it0 += RD) {
 #pragma unroll
@@ -924,6 +943,7 @@ __global__ __launch_bounds__(NT, MINB) void mbconv2_kernel(const XT* __restrict_
         v4f acc[NTB];                                            // starts at the folded-BN bias: no add in the epilogue
 #pragma unroll
         for (int nt = 0; nt < NTB; ++nt) acc[nt] = bex[nt];
+        v4f acc1 = (v4f){0.f, 0.f, 0.f, 0.f};
         // the NTB accumulators interleaved (independent chains)
         if constexpr (ABL == 1) {
 #pragma unroll
@@ -932,13 +952,11 @@ __global__ __launch_bounds__(NT, MINB) void mbconv2_kernel(const XT* __restrict_
             if constexpr (NTB == 1) {
                 // one 16-channel tile: the K steps alternate between two accumulators (two independent MFMA chains instead
                 // of one dependent chain of NM), folded once at the end
-                v4f acc1 = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < NM; ++i) {
                     if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[0][i / 4][i % 4], xa.raw[i / 4][i % 4], acc1, 0, 0, 0);
                     else acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wfr[0][i / 4][i % 4], xa.raw[i / 4][i % 4], acc[0], 0, 0, 0);
                 }
-                acc[0] += acc1;
             } else {
 #pragma unroll
                 for (int i = 0; i < NM; ++i)
@@ -960,18 +978,19 @@ __global__ __launch_bounds__(NT, MINB) void mbconv2_kernel(const XT* __restrict_
             const int mn = mt + NW * RD;
             load_tile(mn < nmt ? mn : nmt - 1, ring[d]);
         }
-        int pr, pcol;
-        tile_rc(mt * 16 + j, pr, pcol);
-        const int p = pr * IW + pcol;                               // unit of the LDS tile
-        const int iy = iy0 + pr, ix = ix0 + pcol;
-        const bool inside = INS || ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)H);
-        if (mt < nmt && mt * 16 + j < (INS ? npin : NPX)) {
+        if constexpr (SKEW) {
+            epilogue(prev_mt, prev);                                // the previous tile, while this tile's MFMAs run
+            if constexpr (ESZ == 4 && NTB == 1) acc[0] += acc1;
 #pragma unroll
-            for (int nt = 0; nt < NTB; ++nt)
-                tile[tile_unit<CG, SWZ>(p, nt * 4 + q)] = inside ? (ABL == 2 ? acc[nt] : swish4(acc[nt])) : (v4f){0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NTB; ++nt) prev[nt] = acc[nt];
+            prev_mt = mt;
+        } else {
+            if constexpr (ESZ == 4 && NTB == 1) acc[0] += acc1;
+            epilogue(mt, acc);
         }
       }
     }
+    if constexpr (SKEW) epilogue(prev_mt, prev);
     if (tid < K * K * CG) wl[tid] = wl_v;
     MB_TP(4);
     __syncthreads();
@@ -1361,7 +1380,7 @@ static int mb_variant(int H, int stride) {
 }
 
 template <int K, int S, int CB, int TH, int TW, int RP, int NK, typename XT, int NT = 256, bool INS = false, int CI = 0,
-          int MINB = (NT == 256 ? 2 : 4)>
+          int MINB = (NT == 256 ? 2 : 4), bool SKEW = false>
 static void mb2_launch(const XT* X, int Cin, const unsigned short* We3, int plane, int Kp, const float* Wef, const float* be,
                        const float* W, const float* b, XT* Y, float* P, int n, int H, int C, int pad_lo, int* tiles, hipStream_t s,
                        const SeTail& se) {
@@ -1369,7 +1388,7 @@ static void mb2_launch(const XT* X, int Cin, const unsigned short* We3, int plan
     const int tx = (Ho + TW - 1) / TW, ty = (Ho + TH - 1) / TH;
     const int tiles_sp = tx * ty;
     *tiles = tiles_sp;
-    hipLaunchKernelGGL((mbconv2_kernel<K, S, CB, TH, TW, RP, NK, XT, 0, NT, INS, CI, MINB>), dim3(tiles_sp * (C / CB) * n), dim3(NT), 0, s, X,
+    hipLaunchKernelGGL((mbconv2_kernel<K, S, CB, TH, TW, RP, NK, XT, 0, NT, INS, CI, MINB, SKEW>), dim3(tiles_sp * (C / CB) * n), dim3(NT), 0, s, X,
                        We3, plane, Kp, Wef, be, W, b, Y, P, H, Ho, C, Cin, pad_lo, tx, tiles_sp, se);
 }
 
@@ -1418,6 +1437,14 @@ bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int 
     // four blocks per CU (128 VGPRs, ring of 3): more waves in different phases on a SIMD
     if (var == 13 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {
         mb2_launch<5, 1, 16, 14, 28, 7, 2, XT, 256, false, 40, 4>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s, se);
+        return true;
+    }
+    if (var == 18 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {             // variant 13 with the one-tile skew
+        mb2_launch<5, 1, 16, 14, 28, 7, 2, XT, 256, false, 40, 4, true>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s, se);
+        return true;
+    }
+    if (var == 18 && k == 3 && stride == 1 && H == 56 && C == 144 && Cin == 24) {             // variant 6 with the one-tile skew
+        mb2_launch<3, 1, 16, 14, 28, 7, 1, XT, 256, true, 24, 2, true>(Xin, Cin, We3, plane, Kp, Wef, be, Wd, bd, Y, P, n, H, C, pad_lo, tiles, s, se);
         return true;
     }
     if (var == 15 && k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40) {
