@@ -31,6 +31,7 @@ struct MtcnnState {
     MtDense o5, o61, o62, o63;
     MtConv r1p;                           // R-Net conv1 with 32 output channels (4 zero filters)
     const float* p1w_pad = nullptr;       // P-Net conv1 weights in a 288-float buffer (scalar loads read 16 at a time)
+    const float *p2m = nullptr, *p3m = nullptr;   // P-Net conv2 / conv3 in the MFMA kernel's K layout ([16][96], [32][160])
     MtGemmConv r2g, r3g, o2g, o3g, o4g;
     DevBuf in, a0, a1, prob, reg, win, coef, bnd, tmp, face, d_lv, d_items, d_pre, bs, cand;
 };
@@ -381,7 +382,7 @@ struct Cascade {
             auto pre_at = [&](int k) { return dp + (size_t)k * (nl + 1); };
             if ((rc = ensure(h, &S->in, pre_in.back() * 4))) return rc;
             if ((rc = ensure(h, &S->a0, std::max(pre_c2.back(), (long long)4) * 4))) return rc;
-            if ((rc = ensure(h, &S->a1, std::max(pre_p.back(), (long long)4) * 4))) return rc;
+            if ((rc = ensure(h, &S->a1, std::max(pre_p.back(), (long long)4) * 4 + 64))) return rc;   // + the MFMA kernel's 2-float row overrun
             if ((rc = ensure(h, &S->prob, cells * 4))) return rc;
             if ((rc = ensure(h, &S->reg, cells * 16))) return rc;
             float *in = (float*)S->in.p, *a0 = (float*)S->a0.p, *a1 = (float*)S->a1.p;
@@ -398,8 +399,20 @@ struct Cascade {
             // 32-channel map is never stored either)
             launch_mt_pnet_conv1_pool(in, S->p1w_pad, S->p1.b, S->p1.a, a1, item_at(0), pre_at(1), nl, pre_p.back(), s);
             bool ok = true;
-            ok = ok && launch_mt_convpx_ragged(a1, S->p2.w, S->p2.b, S->p2.a, a0, item_at(1), pre_at(2), nl, pre_c2.back(), 10, 16, 3, nullptr, s);
-            ok = ok && launch_mt_convpx_ragged(a0, S->p3.w, S->p3.b, S->p3.a, nullptr, item_at(2), pre_at(3), nl, pre_c3.back(), 16, 32, 3, &heads, s);
+            // conv2 / conv3 on the bf16 MFMA with exact three-term operands (DFD_MT_PNET_MFMA=0: the register-blocked VALU kernels)
+            static const bool pnet_mfma = !(getenv("DFD_MT_PNET_MFMA") && atoi(getenv("DFD_MT_PNET_MFMA")) == 0);
+            if (pnet_mfma) {
+                const unsigned short* w2 = split_weights(h, S->p2m, 16, 96);
+                const unsigned short* w3 = split_weights(h, S->p3m, 32, 160);
+                if (!w2 || !w3) return DFD_ERR_HIP;
+                ok = ok && launch_mt_pnet_mfma(a1, w2, (int)split_weights_count(16, 96), 128, S->p2.b, S->p2.a, a0, item_at(1), pre_at(2), nl,
+                                               pre_c2.back(), 10, 16, nullptr, s);
+                ok = ok && launch_mt_pnet_mfma(a0, w3, (int)split_weights_count(32, 160), 192, S->p3.b, S->p3.a, nullptr, item_at(2), pre_at(3), nl,
+                                               pre_c3.back(), 16, 32, &heads, s);
+            } else {
+                ok = ok && launch_mt_convpx_ragged(a1, S->p2.w, S->p2.b, S->p2.a, a0, item_at(1), pre_at(2), nl, pre_c2.back(), 10, 16, 3, nullptr, s);
+                ok = ok && launch_mt_convpx_ragged(a0, S->p3.w, S->p3.b, S->p3.a, nullptr, item_at(2), pre_at(3), nl, pre_c3.back(), 16, 32, 3, &heads, s);
+            }
             if (!ok) return fail(h, DFD_ERR_STATE, "mtcnn: no P-Net kernel instance for this layer shape");
             DFD_HIP_TRY(h, hipGetLastError());
             // the candidates (cells at or above the threshold), not the maps: count first, then that many records, both
@@ -648,6 +661,8 @@ int mtcnn_init(dfd_handle* h) {
     S->o61 = mt_dense(h, "onet.dense6_1", 2, 256, nullptr, &ok);
     S->o62 = mt_dense(h, "onet.dense6_2", 4, 256, nullptr, &ok);
     S->o63 = mt_dense(h, "onet.dense6_3", 10, 256, nullptr, &ok);
+    S->p2m = mt_tensor(h, "mtcnn.pnet.conv2.wm", 16 * 96, &ok);
+    S->p3m = mt_tensor(h, "mtcnn.pnet.conv3.wm", 32 * 160, &ok);
     S->r1p.co = 32; S->r1p.ci = 3; S->r1p.k = 3;
     S->r1p.w = mt_tensor(h, "mtcnn.rnet.conv1.wp", 3 * 3 * 3 * 32, &ok);
     S->r1p.b = mt_tensor(h, "mtcnn.rnet.conv1.bp", 32, &ok);

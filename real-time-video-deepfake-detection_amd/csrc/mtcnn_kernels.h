@@ -37,6 +37,11 @@ struct MtPnetHeads {
 // P-Net conv2 / conv3, register-blocked (a thread owns 4 output pixels, weights in LDS); false = no instance for that
 // shape.  With `heads` (conv3) the 1x1 heads + softmax run in the same launch: prob [cell], reg [cell][4], candidates;
 // y is not written.
+// the same two layers on the bf16 MFMA: w3 = three exact bf16 planes of the weights in the row-contiguous K layout
+// [CO][ky * KR + kx * CI + ci] (KR = 32 / 48; "mtcnn.pnet.conv2.wm" / "conv3.wm" of the blob), rows Kp long
+bool launch_mt_pnet_mfma(const float* x, const unsigned short* w3, int plane, int Kp, const float* b, const float* slope, float* y,
+                         const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co,
+                         const MtPnetHeads* heads, hipStream_t s);
 bool launch_mt_convpx_ragged(const float* x, const float* w, const float* b, const float* slope, float* y,
                              const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co, int k,
                              const MtPnetHeads* heads, hipStream_t s);

@@ -638,6 +638,215 @@ static void convpx_launch(const float* x, const float* w, const float* b, const 
                        hd ? hd->cand_count : nullptr, hd ? hd->cand_cap : 0u, hd ? hd->thr : 0.f);
 }
 
+// ---- P-Net conv2 / conv3 on the matrix pipe (round 3) ---------------------------------------------------------------
+// The two convolutions that carry P-Net's arithmetic (10 -> 16 and 16 -> 32 channels, 3x3 valid, over every pyramid
+// level of every crop: 17 of the cascade's ~20 GFLOP per 256 crops) as ragged implicit GEMMs on
+// v_mfma_f32_16x16x32_bf16 with exact three-term operands, like the classifier's GEMMs.  D[co][pixel] = sum_k W[co][k] *
+// X[k][pixel]; a kernel ROW of a pixel's 3 x 3 x CI window is 3 * CI contiguous floats of the NHWC map, so with k = ky *
+// KR + (kx * CI + ci) (KR = 32 for CI = 10 - two zero-weight slots per row - and 48 for CI = 16) a lane's 8 consecutive
+// k are 8 consecutive floats in memory: the B operand is two 16-byte loads per K-step, no gather.  Block = 4 waves x 4
+// tiles of 16 consecutive output pixels of the ragged index space (a tile may straddle rows and levels: every lane finds
+// its own pixel); the weight planes [3][CO][K] sit in LDS (rows padded by 8 elements: conflict-free 16-byte reads) and
+// a K-step's A fragments serve the wave's four tiles; the next K-step's activations are in flight during the MFMAs.
+// HEADS (conv3): both 1x1 heads, the softmax and the candidate append from the accumulators (the 32-channel map is
+// never stored): a pixel's 32 channels sit on the 4 lanes j, j + 16, j + 32, j + 48 - partial dot products, two
+// shuffles.  (The register-blocked VALU kernels above stay as DFD_MT_PNET_MFMA=0: conv3 792 us, conv2 365 us per 256 crops.)
+template <int CI, int CO, bool HEADS>
+__global__ __launch_bounds__(256) void mt_pnet_mfma_kernel(const float* __restrict__ x, const unsigned short* __restrict__ w3,
+                                                           int plane, int Kp, const float* __restrict__ b,
+                                                           const float* __restrict__ slope, float* __restrict__ y,
+                                                           const MtItem* __restrict__ items, const long long* __restrict__ pre, int n,
+                                                           const float* __restrict__ w41, const float* __restrict__ b41,
+                                                           const float* __restrict__ w42, const float* __restrict__ b42,
+                                                           float* __restrict__ prob, float* __restrict__ reg,
+                                                           MtCand* __restrict__ cand, unsigned* __restrict__ cand_count,
+                                                           unsigned cand_cap, float thr, int tiles_per_wave) {
+    constexpr int KR = CI == 10 ? 32 : 48, KTOT = (3 * KR + 31) / 32 * 32, KS = KTOT / 32, NT = CO / 16;
+    constexpr int KROW = KTOT + 8;                                   // LDS row stride (elements): 16-byte reads of 16 rows hit 16 bank groups
+    __shared__ __attribute__((aligned(16))) unsigned short wl[3 * CO * KROW];
+    __shared__ float hw[HEADS ? CO * 6 + 8 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+    const long long npix = pre[n] / CO;
+    // weight planes -> LDS once per block (16-byte chunks; rows of the global planes are Kp long, zero beyond 3 * KR);
+    // the block then walks 256-pixel chunks of the ragged index space (staged per 256 pixels, the 30 KB of conv3 planes
+    // were 270 MB of L2 -> LDS traffic per launch and a barrier-bound 2-3 us in front of 1.6 us of MFMA work)
+    for (int c = tid; c < 3 * CO * (KTOT / 8); c += 256) {
+        const int row = c / (KTOT / 8), oc = c - row * (KTOT / 8), pl = row / CO, r = row - pl * CO;
+        *reinterpret_cast<uint4*>(&wl[row * KROW + oc * 8]) = *reinterpret_cast<const uint4*>(w3 + (size_t)pl * plane + (size_t)r * Kp + oc * 8);
+    }
+    if (HEADS) {
+        for (int i = tid; i < CO * 2; i += 256) hw[i] = w41[i];
+        for (int i = tid; i < CO * 4; i += 256) hw[CO * 2 + i] = w42[i];
+        if (tid < 2) hw[CO * 6 + tid] = b41[tid];
+        if (tid < 4) hw[CO * 6 + 2 + tid] = b42[tid];
+    }
+    __syncthreads();
+    v4f bv[NT], sv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        bv[nt] = *reinterpret_cast<const v4f*>(b + nt * 16 + 4 * q);
+        sv[nt] = *reinterpret_cast<const v4f*>(slope + nt * 16 + 4 * q);
+    }
+    // A wave owns a CONTIGUOUS run of 16-pixel tiles of the ragged index space (tiles_per_wave each, the launcher's
+    // split): the item (pyramid level) of a pixel only moves forward along the run, so after ONE binary search at the
+    // start the lookup is "advance while the next level begins at or before this pixel" - the per-chunk searches of the
+    // grid-stride version were 8k of its 22k cycles per chunk (s_memtime).
+    const long long ntiles = (npix + 15) / 16;
+    const long long wave_id = (long long)blockIdx.x * 4 + wave;
+    const long long t_begin = wave_id * tiles_per_wave, t_end = t_begin + tiles_per_wave < ntiles ? t_begin + tiles_per_wave : ntiles;
+    if (t_begin >= ntiles) return;                                   // (after the only barrier)
+    // wave-uniform cursor: the item of the current tile's first pixel with its bounds and descriptor IN REGISTERS - the
+    // common lane (same item as the cursor) does no dependent load before its window loads; only a lane past the item's
+    // end walks on through `pre` (levels are thousands of pixels long: rare)
+    int item = mt_find(pre, n, (t_begin * 16 < npix ? t_begin * 16 : npix - 1) * CO);
+    long long cur_start = pre[item], next_start = pre[item + 1];
+    MtItem cur_it = items[item];
+    struct Tile { v4f lo[KS], hi[KS]; long long opix; bool ok; };
+    auto prep = [&](long long tile, Tile& T) {
+        const long long pix = tile * 16 + j;
+        T.ok = pix < npix;
+        const long long pq = T.ok ? pix : npix - 1;
+        MtItem it = cur_it;
+        long long st = cur_start;
+        if (pq * CO >= next_start) {                                 // this lane's pixel lies in a later item
+            int i = item + 1;
+            while (i + 1 < n && pre[i + 1] <= pq * CO) ++i;
+            it = items[i];
+            st = pre[i];
+        }
+        const long long r = pq - st / CO;
+        const int ow = it.iw - 2;
+        const int oy = (int)(r / ow), ox = (int)(r - (long long)oy * ow);
+        const float* xb = x + it.in_off + ((size_t)oy * it.iw + ox) * CI;
+        T.opix = it.out_off / CO + r;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int o = s * 4 + q, ky = o / (KR / 8), r0 = (o - ky * (KR / 8)) * 8;
+            const float* p = xb + (ky < 3 ? (size_t)ky * it.iw * CI + r0 : 0);    // octets past the third row: zero weights
+            T.lo[s] = ldg4u(p);
+            T.hi[s] = ldg4u(p + 4);
+        }
+    };
+    auto advance_item = [&](long long tile) {                       // move the cursor to the item of the tile's first pixel
+        const long long e = (tile * 16 < npix ? tile * 16 : npix - 1) * CO;
+        while (item + 1 < n && next_start <= e) {
+            ++item;
+            cur_start = next_start;
+            next_start = pre[item + 1];
+            cur_it = items[item];
+        }
+    };
+    Tile ring[2];
+    prep(t_begin, ring[0]);
+    for (long long tile = t_begin; tile < t_end; tile += 2) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const long long tcur = tile + d;
+        if (tcur >= t_end) break;                                    // wave-uniform
+        Tile& T = ring[d];
+        if (tcur + 1 < t_end) { advance_item(tcur + 1); prep(tcur + 1, ring[d ^ 1]); }
+        v4f acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf8 wf[NT][3];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    wf[nt][pl] = *reinterpret_cast<const bf8*>(&wl[(pl * CO + nt * 16 + j) * KROW + s * 32 + 8 * q]);
+            bf8 x0, x1, x2;
+            split8(T.lo[s], T.hi[s], x0, x1, x2);
+            const bf8* xs[3] = {&x0, &x1, &x2};
+            const int wsel[6] = {2, 1, 0, 1, 0, 0}, xsel[6] = {0, 1, 2, 0, 1, 0};      // smallest terms first
+#pragma unroll
+            for (int p6 = 0; p6 < 6; ++p6)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][wsel[p6]], *xs[xsel[p6]], acc[nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                       // a K-step's fragments and split terms die here (256 -> VGPRs otherwise)
+        }
+        // epilogue: bias, PReLU; the lane holds channels nt * 16 + 4 q .. + 3 of its pixel
+        float v[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const v4f a = acc[nt] + bv[nt];
+            const float av[4] = {a.x, a.y, a.z, a.w}, sl[4] = {sv[nt].x, sv[nt].y, sv[nt].z, sv[nt].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[nt][e] = av[e] >= 0.f ? av[e] : av[e] * sl[e];
+        }
+        if constexpr (!HEADS) {
+            if (T.ok)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    *reinterpret_cast<v4f*>(y + T.opix * CO + nt * 16 + 4 * q) = (v4f){v[nt][0], v[nt][1], v[nt][2], v[nt][3]};
+        } else {
+            float z[2] = {0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = nt * 16 + 4 * q + e;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) z[k] = fmaf(v[nt][e], hw[c * 2 + k], z[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r4[k] = fmaf(v[nt][e], hw[CO * 2 + c * 4 + k], r4[k]);
+                }
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1) {                // fold the four channel groups of the pixel (a fixed order)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) z[k] += __shfl_xor(z[k], off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r4[k] += __shfl_xor(r4[k], off);
+            }
+            const float z0 = z[0] + hw[CO * 6], z1 = z[1] + hw[CO * 6 + 1];
+            const float m = fmaxf(z0, z1);
+            const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+            const float pf = e1 / (e0 + e1);
+            float4 rv;
+            rv.x = r4[0] + hw[CO * 6 + 2]; rv.y = r4[1] + hw[CO * 6 + 3];
+            rv.z = r4[2] + hw[CO * 6 + 4]; rv.w = r4[3] + hw[CO * 6 + 5];
+            const bool mine = T.ok && q == 0;                        // one lane per pixel writes
+            if (mine) {
+                prob[T.opix] = pf;
+                *reinterpret_cast<float4*>(reg + T.opix * 4) = rv;
+            }
+            const bool pass = cand && mine && pf >= thr;
+            const unsigned long long mask = __ballot(pass);
+            if (mask) {                                              // one atomic per wave (see mt_convpx_kernel)
+                const int leader = __ffsll((long long)mask) - 1;
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(cand_count, (unsigned)__popcll(mask));
+                base = __shfl(base, leader);
+                const unsigned slot = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+                if (pass && slot < cand_cap) cand[slot] = MtCand{(unsigned)T.opix, pf, {rv.x, rv.y, rv.z, rv.w}};
+            }
+        }
+      }
+    }
+}
+
+bool launch_mt_pnet_mfma(const float* x, const unsigned short* w3, int plane, int Kp, const float* b, const float* slope, float* y,
+                         const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co,
+                         const MtPnetHeads* hd, hipStream_t s) {
+    const long long npix = total / co;
+    if (npix <= 0) return true;
+    // 1024 blocks x 4 waves when there is enough work (each wave a contiguous run of tiles), at least 4 tiles per wave
+    const long long ntiles = (npix + 15) / 16;
+    long long tpw = (ntiles + 4095) / 4096;
+    if (tpw < 4) tpw = 4;
+    const unsigned grid = (unsigned)((ntiles + 4 * tpw - 1) / (4 * tpw));
+    if (ci == 10 && co == 16 && !hd)
+        hipLaunchKernelGGL((mt_pnet_mfma_kernel<10, 16, false>), dim3(grid), dim3(256), 0, s, x, w3, plane, Kp, b, slope, y, items_dev, pre_dev,
+                           n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0.f, (int)tpw);
+    else if (ci == 16 && co == 32 && hd)
+        hipLaunchKernelGGL((mt_pnet_mfma_kernel<16, 32, true>), dim3(grid), dim3(256), 0, s, x, w3, plane, Kp, b, slope, y, items_dev, pre_dev,
+                           n, hd->w41, hd->b41, hd->w42, hd->b42, hd->prob, hd->reg, hd->cand, hd->cand_count, hd->cand_cap, hd->thr, (int)tpw);
+    else return false;
+    return true;
+}
+
 bool launch_mt_convpx_ragged(const float* x, const float* w, const float* b, const float* slope, float* y,
                              const MtItem* items_dev, const long long* pre_dev, int n, long long total, int ci, int co, int k,
                              const MtPnetHeads* heads, hipStream_t s) {

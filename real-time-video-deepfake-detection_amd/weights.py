@@ -436,6 +436,16 @@ def pack_mtcnn_tensors(sd: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
         t[f"mtcnn.{net}.{name}.bg"] = pad_to(np.asarray(sd[f"{net}.{name}.bias"], np.float32), co_pad, 0)
         t[f"mtcnn.{net}.{name}.ag"] = pad_to(np.asarray(sd[f"{net}.{prelu}.weight"], np.float32).reshape(-1), co_pad, 0)
 
+    # P-Net conv2 / conv3 for the MFMA kernel (mt_pnet_mfma_kernel): [co][ky * KR + kx * ci_n + ci], a kernel row's
+    # 3 * ci_n values contiguous (as they are in the NHWC map), rows padded to KR = 32 / 48, K to a multiple of 32
+    def pnet_mfma(name, co, ci_n, kr):
+        w = np.asarray(sd[f"pnet.{name}.weight"], np.float32)                                 # [co][ci][ky][kx]
+        rows = w.transpose(0, 2, 3, 1).reshape(co, 3, 3 * ci_n)                               # [co][ky][kx * ci_n + ci]
+        rows = pad_to(rows, kr, 2).reshape(co, 3 * kr)
+        t[f"mtcnn.pnet.{name}.wm"] = np.ascontiguousarray(pad_to(rows, (3 * kr + 31) // 32 * 32, 1))
+
+    pnet_mfma("conv2", 16, 10, 32)
+    pnet_mfma("conv3", 32, 16, 48)
     w1 = t["mtcnn.rnet.conv1.w"]                                                              # [ci][ky][kx][28] -> 32
     t["mtcnn.rnet.conv1.wp"] = np.ascontiguousarray(pad_to(w1, 32, 3))
     t["mtcnn.rnet.conv1.bp"] = pad_to(t["mtcnn.rnet.conv1.b"], 32, 0)
