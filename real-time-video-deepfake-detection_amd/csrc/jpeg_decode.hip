@@ -22,6 +22,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "dfd_common.h"
@@ -194,10 +195,11 @@ int parse_headers(dfd_handle* h, const uint8_t* d, size_t len, Parsed* P) {
 class HostPool {
 public:
     static HostPool& get() { static HostPool p; return p; }
-    int size() const { return (int)workers_.size() + 1; }
+    int size() const { return owner_pid_ == getpid() ? (int)workers_.size() + 1 : 1; }
     void run(int n, const std::function<void(int)>& fn) {
         if (n <= 0) return;
-        if (workers_.empty() || n == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+        // a fork()ed child (pre-fork servers) inherits the pool object but not its threads: everything on the caller there
+        if (workers_.empty() || n == 1 || owner_pid_ != getpid()) { for (int i = 0; i < n; ++i) fn(i); return; }
         std::unique_lock<std::mutex> call(call_mu_);                 // one parallel region at a time
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -215,9 +217,14 @@ private:
         const char* cap = getenv("DFD_HOST_THREADS");
         const int hw = (int)std::thread::hardware_concurrency();
         int nt = std::min(cap ? std::max(atoi(cap), 1) : 16, std::max(hw / 2, 1));
+        owner_pid_ = getpid();
         for (int t = 1; t < nt; ++t) workers_.emplace_back([this] { loop(); });
     }
     ~HostPool() {
+        if (owner_pid_ != getpid()) {                              // forked child: the threads do not exist here
+            for (auto& w : workers_) w.detach();
+            return;
+        }
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++epoch_; }
         cv_.notify_all();
         for (auto& w : workers_) w.join();
@@ -247,6 +254,7 @@ private:
     int n_ = 0, done_ = 0;
     unsigned long epoch_ = 0;
     bool stop_ = false;
+    pid_t owner_pid_ = 0;
 };
 
 // ---- entropy-coded segment -> coefficients ------------------------------------------------------------------

@@ -97,6 +97,24 @@ def test_speculative_chunks_give_the_sequential_result(pkg, monkeypatch, h, w, k
     assert np.array_equal(pkg._lib.jpeg_coefficients(gray)["coef"], want)
 
 
+def test_decoder_pool_survives_fork(pkg):
+    """The entropy decoder's host threads do not exist in a fork()ed child (a pre-fork WSGI server): the child must
+    decode on its own thread instead of waiting for workers that never come."""
+    import os
+
+    data = _jpeg(_img(480, 640, 41), quality=85)
+    want = pkg._lib.jpeg_coefficients(data)["coef"]              # creates the pool in this process
+    pid = os.fork()
+    if pid == 0:
+        try:
+            ok = np.array_equal(pkg._lib.jpeg_coefficients(data)["coef"], want)
+        except BaseException:
+            ok = False
+        os._exit(0 if ok else 3)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+
+
 def test_truncated_scan_is_loud(pkg):
     """A file cut inside its entropy-coded data raises (the old byte-wise reader decoded zeros for the missing MCUs)."""
     data = _jpeg(_img(128, 128, 33), quality=90)
