@@ -190,6 +190,44 @@ __device__ __forceinline__ int mt_find(const long long* __restrict__ pre, int n,
     return lo;
 }
 
+// Exact integer sums of the three channels over the window rows [y0, y1) x pixels [x0, x1) of a packed BGR image.
+// A row's 3 * (x1 - x0) bytes are read as unaligned dwords, 12 bytes (four pixels) per step, instead of one byte per
+// load: the ragged pyramid resize issued 740 M byte loads per 256 crops (every level reads the whole crop) and was bound
+// by load instructions.  `safe_rows`: rows below this index may read up to 3 bytes past their last pixel (they lie inside
+// the image buffer); the rows from it on fall back to byte loads.
+__device__ __forceinline__ void mt_window_sums(const uint8_t* __restrict__ img, size_t stride, int y0, int y1, int x0, int x1,
+                                               int safe_rows, int& sb, int& sg, int& sr) {
+    const int nbytes = 3 * (x1 - x0);
+    for (int y = y0; y < y1; ++y) {
+        const uint8_t* p = img + (size_t)y * stride + (size_t)x0 * 3;
+        if (y < safe_rows) {
+            int k = 0;
+            for (; k + 12 <= nbytes; k += 12) {                     // b g r b | g r b g | r b g r
+                unsigned d0, d1, d2;
+                memcpy(&d0, p + k, 4); memcpy(&d1, p + k + 4, 4); memcpy(&d2, p + k + 8, 4);
+                sb += (d0 & 0xFF) + (d0 >> 24) + ((d1 >> 16) & 0xFF) + ((d2 >> 8) & 0xFF);
+                sg += ((d0 >> 8) & 0xFF) + (d1 & 0xFF) + (d1 >> 24) + ((d2 >> 16) & 0xFF);
+                sr += ((d0 >> 16) & 0xFF) + ((d1 >> 8) & 0xFF) + (d2 & 0xFF) + (d2 >> 24);
+            }
+            // tail: 3, 6 or 9 bytes (one to three pixels) from up to three dwords, bytes past the window masked
+            if (k < nbytes) {
+                const int rem = nbytes - k;                         // 3, 6, 9
+                unsigned d0, d1 = 0, d2 = 0;
+                memcpy(&d0, p + k, 4);
+                if (rem > 4) memcpy(&d1, p + k + 4, 4);
+                if (rem > 8) memcpy(&d2, p + k + 8, 4);
+                sb += (d0 & 0xFF);
+                sg += ((d0 >> 8) & 0xFF);
+                sr += ((d0 >> 16) & 0xFF);
+                if (rem > 3) { sb += (d0 >> 24); sg += (d1 & 0xFF); sr += ((d1 >> 8) & 0xFF); }
+                if (rem > 6) { sb += ((d1 >> 16) & 0xFF); sg += (d1 >> 24); sr += (d2 & 0xFF); }
+            }
+        } else {
+            for (int x = 0; x < nbytes; x += 3) { sb += p[x]; sg += p[x + 1]; sr += p[x + 2]; }
+        }
+    }
+}
+
 // The item that holds element t, searched only between the items of the block's first and last element (lohi[0..1],
 // found by two threads with the full search and shared through LDS): a block's 256 consecutive elements span one or two
 // pyramid levels, so the per-thread search is 0-2 steps instead of log2(n) = 11 dependent loads of `pre`.
@@ -209,24 +247,32 @@ __global__ __launch_bounds__(256) void mt_area_resize_ragged_kernel(const MtLeve
                                                                     const long long* __restrict__ pre, int n,
                                                                     float* __restrict__ dst) {
     __shared__ int lohi[2];
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    // XCD-aware block order (guide T1, bijective form): the eight pyramid levels of a crop each read the WHOLE crop, and
+    // outputs are ordered crop by crop - with the dispatcher's round-robin every XCD read every crop (8 x 8 fetches of
+    // it); ids that share an XCD now walk a contiguous range of the output space, i.e. a few crops, whose bytes stay in
+    // that XCD's L2 across their levels
+    const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, qq = nb >> 3, rr = nb & 7;
+    const unsigned bidx = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
+    const long long t = (long long)bidx * 256 + threadIdx.x;
     if (threadIdx.x < 2) {
-        const long long e = ((long long)blockIdx.x * 256 + (threadIdx.x ? 255 : 0)) * 3;
+        const long long e = ((long long)bidx * 256 + (threadIdx.x ? 255 : 0)) * 3;
         lohi[threadIdx.x] = mt_find(pre, n, e < pre[n] ? e : pre[n] - 1);
     }
     __syncthreads();
     if (t * 3 >= pre[n]) return;
     const int i = mt_find_in(pre, lohi, t * 3);
     const MtLevel L = lv[i];
+    // 32-bit index arithmetic: a level has < 2^31 pixels and (pixel index) x (image edge) < 2^31 for any image this path
+    // accepts (edges < 2^15) - the 64-bit divisions of the first version were several hundred instructions per thread,
+    // more than the window loads
     const long long r = t - pre[i] / 3;
-    const int ox = (int)(r % L.ow), oy = (int)(r / L.ow);
-    const int y0 = (int)(((long long)oy * L.h) / L.oh), y1 = (int)((((long long)oy + 1) * L.h + L.oh - 1) / L.oh);
-    const int x0 = (int)(((long long)ox * L.w) / L.ow), x1 = (int)((((long long)ox + 1) * L.w + L.ow - 1) / L.ow);
+    const unsigned ru = (unsigned)r, uow = (unsigned)L.ow, uoh = (unsigned)L.oh;
+    const unsigned oyu = ru / uow, oxu = ru - oyu * uow;
+    const int ox = (int)oxu, oy = (int)oyu;
+    const int y0 = (int)(oyu * (unsigned)L.h / uoh), y1 = (int)(((oyu + 1u) * (unsigned)L.h + uoh - 1u) / uoh);
+    const int x0 = (int)(oxu * (unsigned)L.w / uow), x1 = (int)(((oxu + 1u) * (unsigned)L.w + uow - 1u) / uow);
     int sb = 0, sg = 0, sr = 0;
-    for (int y = y0; y < y1; ++y) {
-        const uint8_t* p = L.src + (size_t)y * L.stride + (size_t)x0 * 3;
-        for (int x = x0; x < x1; ++x, p += 3) { sb += p[0]; sg += p[1]; sr += p[2]; }
-    }
+    mt_window_sums(L.src, (size_t)L.stride, y0, y1, x0, x1, L.h - 1, sb, sg, sr);      // the last row: byte loads (nothing behind it)
     const float area = (float)((y1 - y0) * (x1 - x0));
     float* d = dst + L.out_off + r * 3;                      // RGB order
     d[0] = ((float)sr / area - 127.5f) * 0.0078125f;
@@ -295,7 +341,8 @@ __global__ __launch_bounds__(256) void mt_convpx_kernel(const float* __restrict_
             const MtItem it = items[i];
             const long long r = q - pre[i] / CO;
             const int ow = it.iw - K + 1;
-            const int oy = (int)(r / ow), ox = (int)(r % ow);
+            const unsigned oyu = (unsigned)r / (unsigned)ow;          // a level has < 2^31 pixels: 32-bit division
+            const int oy = (int)oyu, ox = (int)((unsigned)r - oyu * (unsigned)ow);
             iw[p] = it.iw;
             xp[p] = x + it.in_off + ((size_t)oy * it.iw + ox) * CI;
             opix[p] = it.out_off / CO + r;
@@ -430,7 +477,8 @@ __global__ __launch_bounds__(256) void mt_pnet_conv1_pool_kernel(const float* __
     const int c1h = it.ih - 2, c1w = it.iw - 2;
     int pw = (c1w - 2 + 1) / 2 + 1;                          // MaxPool2d(2, 2, ceil_mode): as mt_pool_out
     if ((pw - 1) * 2 >= c1w) --pw;
-    const int py = (int)(r / pw), px = (int)(r % pw);
+    const unsigned pyu = (unsigned)r / (unsigned)pw;                 // a level has < 2^31 pixels: 32-bit division
+    const int py = (int)pyu, px = (int)((unsigned)r - pyu * (unsigned)pw);
     const bool vy = 2 * py + 1 < c1h, vx = 2 * px + 1 < c1w;
     const float* xi = x + it.in_off;
     float patch[4][4][3];
@@ -716,7 +764,8 @@ __global__ __launch_bounds__(256) void mt_pnet_mfma_kernel(const float* __restri
         }
         const long long r = pq - st / CO;
         const int ow = it.iw - 2;
-        const int oy = (int)(r / ow), ox = (int)(r - (long long)oy * ow);
+        const unsigned oyu = (unsigned)r / (unsigned)ow;             // a level has < 2^31 pixels: 32-bit division
+        const int oy = (int)oyu, ox = (int)((unsigned)r - oyu * (unsigned)ow);
         const float* xb = x + it.in_off + ((size_t)oy * it.iw + ox) * CI;
         T.opix = it.out_off / CO + r;
 #pragma unroll
@@ -863,15 +912,16 @@ __global__ __launch_bounds__(256) void mt_area_resize_multi_kernel(const MtSrcWi
                                                                    float* __restrict__ dst) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;          // one output pixel (three exact integer sums)
     if (t >= (long long)n * oh * ow) return;
-    const int ox = (int)(t % ow), oy = (int)((t / ow) % oh), i = (int)(t / ow / oh);
+    const unsigned tu = (unsigned)t, uow = (unsigned)ow, uoh = (unsigned)oh;   // n * oh * ow < 2^31 (kChunk windows of <= 48 x 48)
+    const unsigned rowi = tu / uow, oxu = tu - rowi * uow, iu = rowi / uoh, oyu = rowi - iu * uoh;
+    const int ox = (int)oxu, oy = (int)oyu, i = (int)iu;
     const MtSrcWindow w = win[i];
-    const int y0 = (int)(((long long)oy * w.h) / oh), y1 = (int)((((long long)oy + 1) * w.h + oh - 1) / oh);
-    const int x0 = (int)(((long long)ox * w.w) / ow), x1 = (int)((((long long)ox + 1) * w.w + ow - 1) / ow);
+    const int y0 = (int)(oyu * (unsigned)w.h / uoh), y1 = (int)(((oyu + 1u) * (unsigned)w.h + uoh - 1u) / uoh);
+    const int x0 = (int)(oxu * (unsigned)w.w / uow), x1 = (int)(((oxu + 1u) * (unsigned)w.w + uow - 1u) / uow);
     int sb = 0, sg = 0, sr = 0;
-    for (int y = y0; y < y1; ++y) {
-        const uint8_t* p = w.src + (size_t)(w.y + y) * w.stride + (size_t)(w.x + x0) * 3;
-        for (int x = x0; x < x1; ++x, p += 3) { sb += p[0]; sg += p[1]; sr += p[2]; }
-    }
+    // (the window lies inside its source image: only the image's LAST row has nothing behind it; the source height is
+    // not known here, so the window's own last row takes the byte loads)
+    mt_window_sums(w.src + (size_t)w.y * w.stride + (size_t)w.x * 3, (size_t)w.stride, y0, y1, x0, x1, w.h - 1, sb, sg, sr);
     const float area = (float)((y1 - y0) * (x1 - x0));
     float* d = dst + t * 3;
     d[0] = ((float)sr / area - 127.5f) * 0.0078125f;
