@@ -356,6 +356,28 @@ def bf16_classify(h, xd, yd, batch, steps, logits_fp32, dw_bytes_bf16):
     return out
 
 
+def late_fusion(h, xd, yd, batch, steps, logits_fp32):
+    """The same fp32 step with option "fuse_late": blocks 6-10 / 12-15 compute their 1x1 expand inside the depthwise
+    launch (whole images per block).  Faster per step, but the launches the roofline object prices
+    then contain the expand's MFMA work: NOT the headline configuration - reported beside it."""
+    h.set_option("fuse_late", 1)
+    try:
+        h.warmup(batch, 0)
+        for _ in range(3):
+            h.classify_device(xd.ptr, batch, yd.ptr)
+        h.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            h.classify_device(xd.ptr, batch, yd.ptr)
+        h.sync()
+        dt = time.perf_counter() - t0
+        y = yd.download((batch, 1))
+    finally:
+        h.set_option("fuse_late", 0)
+    return {"crops_per_s": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+            "max_abs_logit_diff_vs_headline_run": float(np.abs(y - logits_fp32).max())}
+
+
 def stream_frame(base, t):
     """frame t of a synthetic 1080p stream: the stream's base frame with a band that scrolls 4 px per frame and a
     patch whose brightness follows t - cheap to make, deterministic in (base, t), frame-to-frame mean |diff| ~ 1"""
@@ -631,6 +653,7 @@ def main():
         "parity": {"rows": 8, "max_abs_logit_err_vs_oracle": parity, "tol": 1e-3},
     }
     if rank == 0 and world == 1:
+        out["fuse_late"] = late_fusion(h, xd, yd, args.batch, min(args.steps, 20), logits)
         out["bf16"] = bf16_classify(h, xd, yd, args.batch, min(args.steps, 20), logits, b0_arch.depthwise_bytes_per_image(2) * args.batch)
     if not args.no_e2e:
         out["e2e"] = e2e_frames(h, rank, dist, local_rank)

@@ -102,8 +102,10 @@ int depthwise_tiles(int H, int C, int k, int stride);
 template <typename XT>
 bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int plane, int Kp, const float* Wef, const float* be,
                          const float* Wd, const float* bd, XT* Y, float* P, int n, int H, int C, int k, int stride,
-                         int pad_lo, int* tiles, hipStream_t s, const SeTail& se = SeTail());
-int mbconv_tiles(int H, int C, int k, int stride, int Cin);      // largest pool-tile count of the fused variants, -1: none
+                         int pad_lo, int* tiles, hipStream_t s, const SeTail& se = SeTail(), bool late = false);
+// largest pool-tile count of the fused variants, -1: none.  late: also the whole-image launches of blocks 6-15
+// (mbconv_late_kernel, option "fuse_late")
+int mbconv_tiles(int H, int C, int k, int stride, int Cin, bool late = false);
 
 // squeeze-excite gate: mean over tiles*pixels -> FC(c_se)+swish -> FC(C)+sigmoid.
 void launch_se(const float* P, int tiles, float inv_hw, const float* w1, const float* b1,

@@ -472,9 +472,14 @@ __device__ __forceinline__ void stg4_agent(float* p, v4f v) {
     __hip_atomic_store(u + 3, __float_as_uint(v.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int CG, bool SWZ>
+// LDS unit (16 bytes) of channel quad c of tile pixel p.  SWZ 0: plain; 1: XOR swizzle (the expand epilogue stores 16
+// pixels x one quad per instruction: plain, all 16 land in the same four banks); 2: pixel stride CG + 1 units - the same
+// spread (stride 36 dwords), and the depthwise phase's reads keep compile-time offsets (the swizzle costs ~3 VALU
+// instructions of address arithmetic per read: a third of that phase's instructions at 14 x 14, RP = 7)
+template <int CG, int SWZ>
 __device__ __forceinline__ int tile_unit(int p, int c) {
-    if constexpr (SWZ && CG >= 8) return p * CG + (c ^ (p & 7));
+    if constexpr (SWZ == 1 && CG >= 8) return p * CG + (c ^ (p & 7));
+    else if constexpr (SWZ == 2) return p * (CG + 1) + c;
     else return p * CG + c;
 }
 
@@ -487,7 +492,7 @@ struct DwShape {
 // depthwise conv of the LDS tile + folded BN + swish + store + per-tile SE partial sums.
 // Ends with a barrier-protected write of P; callers that reuse tile/wl/red afterwards must
 // __syncthreads() first.
-template <int K, int S, int CB, int TH, int TW, int RP, bool SWZ = false, typename XT = float, int ABL = 0, int NT = 256>
+template <int K, int S, int CB, int TH, int TW, int RP, int SWZ = 0, typename XT = float, int ABL = 0, int NT = 256>
 __device__ __forceinline__ void dw_compute(const v4f* tile, const v4f* wl, v4f* red,
                                            const v4f bv, XT* __restrict__ Y,
                                            float* __restrict__ P, int n, int Ho, int C, int c0, int ty0,
@@ -1308,6 +1313,257 @@ bool launch_depthwise(const XT* X, const float* W, const float* bias, XT* Y, flo
 template bool launch_depthwise<float>(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int*, hipStream_t, const SeTail&);
 template bool launch_depthwise<bf16_t>(const bf16_t*, const float*, const float*, bf16_t*, float*, int, int, int, int, int, int, int*, hipStream_t, const SeTail&);
 
+// ---- MBConv front half of the 14 x 14 and 7 x 7 blocks (6-15) in ONE launch (round 3) ---------------------------------
+// As separate launches these blocks spent 523 us in the expand GEMMs and 411 us in the depthwise kernels per 256 crops:
+// the expanded tensor (C_exp = 480-1152 channels) went to memory and came straight back, and the depthwise kernels,
+// two blocks per CU, sat in the exposed latency of their tile loads.  Here a block owns 196 pixels - one 14 x 14 image
+// or four 7 x 7 images, contiguous NHWC rows - and CB = 32 expanded channels:
+//   phase 1  E[32][196] = swish(We[32][Cin] * X[196][Cin]^T + b) on v_mfma_f32_16x16x32_bf16, operands as in gemm_split
+//            (weights = the handle's three bf16 planes, an fp32 activation split into three exact bf16 terms in
+//            registers: six products, fp32-exact; a bf16 activation is the operand as loaded: three products).
+//            K-steps outermost: a wave keeps the accumulators of its (up to) four pixel tiles live, holds the weight
+//            fragments of ONE K-step (6 registers of 16 bytes) and has the next K-step's fragments and activations in
+//            flight while the current one is split and multiplied.  Channels are MFMA rows, pixels MFMA columns, so a
+//            lane ends with four consecutive channels of one pixel = one 16-byte unit of the LDS tile.
+//   phase 2  the depthwise conv + folded BN + swish + squeeze-excite pool from that tile: 14 x 14 through dw_compute
+//            (zero border written next to the interior), 7 x 7 with an output row per thread (the dw_rows7 scheme, fed
+//            from LDS).  A block holds whole images, so the pool sums it writes are final (one "tile" per image).
+// The activation tile is read once per block (C_exp / 32 blocks share an image through L2: image-major block order on
+// one XCD), the weights once per wave.
+template <int K, int S, int HW, int CIN, typename XT>
+__global__ __launch_bounds__(256, 2) void mbconv_late_kernel(const XT* __restrict__ X,
+                                                             const unsigned short* __restrict__ We3, int plane, int Kp,
+                                                             const float* __restrict__ be, const float* __restrict__ Wt,
+                                                             const float* __restrict__ bias, XT* __restrict__ Y,
+                                                             float* __restrict__ P, int n_img, int C, int pad_lo) {
+    constexpr int CB = 32, CG = 8, NTB = 2, NPX = 196, NMT = 13, MTW = 4;
+    constexpr int NK = (CIN + 31) / 32, ESZ = (int)sizeof(XT), NB = ESZ == 4 ? 2 : 1;
+    constexpr int G = HW == 14 ? 1 : 4;                              // images per block
+    constexpr int TH = HW == 14 ? 14 / S : 7;                        // depthwise output tile = the whole image
+    constexpr int IW = HW == 14 ? (TH - 1) * S + K : 7;              // LDS tile width (7 x 7: no border, rows clip in registers)
+    constexpr int SWZ = 2, UP = CG + 1;                              // padded pixel stride (tile_unit)
+    constexpr int NPIX = HW == 14 ? IW * IW : NPX, NUNIT = NPIX * UP;
+    static_assert(HW == 14 || (HW == 7 && S == 1), "14 x 14 (stride 1 or 2) or 7 x 7 stride 1");
+    static_assert(CIN % 8 == 0 && K * K * CG <= 256, "shape");
+    __shared__ v4f tile[NUNIT];
+    __shared__ v4f wl[K * K * CG];
+    __shared__ v4f red[HW == 14 ? 4 * CG : G * 7 * CG];
+    // the block's 32 weight rows, three bf16 planes, rows padded by 16 bytes (consecutive rows start 4 banks apart): read
+    // from global memory by every wave (rounds of this kernel's first version) they were half of its vector-memory
+    // traffic - 98 of 186 KB per block through a 64 B/clk L1 that the s_memtime trace showed 75 % busy in this phase
+    constexpr int KROW = NK * 32 + 8;
+    __shared__ __attribute__((aligned(16))) unsigned short wlds[3 * CB * KROW];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
+    const BlkId bid = blk_image_major(C / CB);
+    // 13 pixel tiles over 4 waves: one wave carries 4, the others 3.  Which one rotates with the block id - wave w of every
+    // block sits on SIMD w, and with a fixed assignment SIMD 0 carried the long wave of both resident blocks
+    const int wave = ((tid >> 6) + (int)((blockIdx.x >> 3) + (blockIdx.x >> 8))) & 3;   // (first two rounds of an XCD: +0, +1)
+    const int grp = bid.n, c0 = bid.x * CB;
+    const int rows_valid = HW == 14 ? NPX : ((n_img - grp * G < G ? n_img - grp * G : G) * 49);
+    const XT* xb = X + (size_t)grp * NPX * CIN;
+#ifdef MB_TRACE
+    int mtp = 0;
+    const int H = HW;
+#endif
+    MB_TP(0);
+
+    // request order = wait order (see mbconv2_kernel): constants, the weight rows (LDS before the first MFMA), then the
+    // activation ring
+    const int wli = tid < K * K * CG ? tid : 0;
+    const v4f wl_v = ldg4(Wt + (size_t)(wli / CG) * C + c0 + 4 * (wli % CG));
+    const v4f bv = ldg4(bias + c0 + 4 * (tid % CG));
+    v4f bex[NTB];
+#pragma unroll
+    for (int nt = 0; nt < NTB; ++nt) bex[nt] = ldg4(be + c0 + nt * 16 + 4 * q);
+    unsigned xoff[MTW];                                               // element offset of this lane's pixel row, per pixel tile
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int p = (wave + 4 * i) * 16 + j;
+        xoff[i] = (unsigned)(p < rows_valid ? p : 0) * CIN;
+    }
+    struct Stage { v4f b[MTW][NB]; };
+    auto load_stage = [&](int ks, Stage& st) {
+        const int k = ks * 32 + 8 * q, kk = k < CIN ? k : 0;          // channels >= Cin: any address, the planes are zero there
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            if constexpr (ESZ == 4) {
+                const float* px = reinterpret_cast<const float*>(xb) + xoff[i] + kk;
+                st.b[i][0] = ldg4(px);
+                st.b[i][NB - 1] = ldg4(px + 4);
+            } else {
+                st.b[i][0] = *reinterpret_cast<const v4f*>(xb + xoff[i] + kk);   // 8 bf16
+            }
+        }
+    };
+    // activation fragments are requested RD K-steps ahead: with one step ahead every K-step lasted exactly one L2 round
+    // trip (s_memtime: 2.2k cycles per step for 0.8k cycles of MFMAs)
+    constexpr int CPR = NK * 4, NCH = 3 * CB * CPR, NLD = (NCH + 255) / 256;      // weight rows: 16-byte chunks per row / in all
+    v4f wv[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int ch = tid + u * 256 < NCH ? tid + u * 256 : NCH - 1;
+        const int row = ch / CPR, kc = ch - row * CPR, pl = row / CB, r = row - pl * CB;
+        wv[u] = *reinterpret_cast<const v4f*>(We3 + (size_t)pl * plane + (size_t)(c0 + r) * Kp + kc * 8);
+    }
+    constexpr int RD = NK < 3 ? NK : 3;
+    Stage st[RD];
+#pragma unroll
+    for (int d = 0; d < RD; ++d) load_stage(d, st[d]);
+    if constexpr (HW == 14) {
+        // the zero border of the TF-SAME padding: written, not computed (disjoint from the units phase 1 writes)
+        for (int i = tid; i < NPIX * CG; i += 256) {
+            const int pp = i / CG, r = pp / IW - pad_lo, c = pp % IW - pad_lo;
+            if ((unsigned)r >= 14u || (unsigned)c >= 14u) tile[tile_unit<CG, SWZ>(pp, i % CG)] = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int ch = tid + u * 256 < NCH ? tid + u * 256 : NCH - 1;
+        const int row = ch / CPR, kc = ch - row * CPR;
+        *reinterpret_cast<v4f*>(&wlds[row * KROW + kc * 8]) = wv[u];
+    }
+    __syncthreads();                                                  // weight rows in LDS
+    MB_TP(1);
+    v4f acc[MTW][NTB];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt) acc[i][nt] = bex[nt];
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const Stage& cur = st[ks % RD];
+        v4f wa[NTB][3];
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                wa[nt][pl] = *reinterpret_cast<const v4f*>(&wlds[((pl * CB) + nt * 16 + j) * KROW + ks * 32 + 8 * q]);
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            if (wave + 4 * i < NMT) {                                 // wave-uniform
+                if constexpr (ESZ == 4) {
+                    bf8 x0, x1, x2;
+                    split8(cur.b[i][0], cur.b[i][NB - 1], x0, x1, x2);
+                    const bf8* xs[3] = {&x0, &x1, &x2};
+                    const int wsel[6] = {2, 1, 0, 1, 0, 0}, xsel[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+#pragma unroll
+                    for (int p6 = 0; p6 < 6; ++p6)
+#pragma unroll
+                        for (int nt = 0; nt < NTB; ++nt)
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, wa[nt][wsel[p6]]),
+                                                                                *xs[xsel[p6]], acc[i][nt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                        for (int nt = 0; nt < NTB; ++nt)
+                            acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, wa[nt][pl]),
+                                                                                __builtin_bit_cast(bf8, cur.b[i][0]), acc[i][nt], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + RD < NK) load_stage(ks + RD, st[ks % RD]);           // refill the slot whose MFMAs have just issued
+        __builtin_amdgcn_sched_barrier(0);
+        MB_TP(10 + ks);
+    }
+    // swish -> LDS tile
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int p = (wave + 4 * i) * 16 + j;
+        if (p < NPX) {
+            int unit_p;
+            if constexpr (HW == 14) {
+                const int y = p / 14, x = p - y * 14;
+                unit_p = (y + pad_lo) * IW + x + pad_lo;
+            } else {
+                unit_p = p;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt) tile[tile_unit<CG, SWZ>(unit_p, nt * 4 + q)] = swish4(acc[i][nt]);
+        }
+    }
+    if (tid < K * K * CG) wl[tid] = wl_v;
+    MB_TP(4);
+    __syncthreads();
+    MB_TP(5);
+    if constexpr (HW == 14) {
+        constexpr int RP = S == 1 ? 7 : 1;
+        dw_compute<K, S, CB, TH, TH, RP, SWZ, XT, 0, 256>(tile, wl, red, bv, Y, P, grp, TH, C, c0, 0, 0, 0, 1);
+    } else {
+        // an output row (7 pixels x 4 channels) per thread: 4 images x 7 rows x 8 channel quads = 224 threads
+        constexpr int H = 7, PAD = (K - 1) / 2;
+        const int cg = tid & 7, rr = (tid >> 3) % H, sub = (tid >> 3) / H;
+        const bool live = tid < G * H * CG;
+        const int img = grp * G + sub;
+        v4f psum = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            v4f o[H];
+#pragma unroll
+            for (int ox = 0; ox < H; ++ox) o[ox] = bv;
+#pragma unroll 1
+            for (int ky = 0; ky < K; ++ky) {
+                const int iy = rr + ky - PAD;
+                const bool ok = (unsigned)iy < (unsigned)H;
+                const int pb = sub * 49 + (ok ? iy : 0) * H;
+                v4f in[H], w[K];
+#pragma unroll
+                for (int ix = 0; ix < H; ++ix) in[ix] = tile[tile_unit<CG, SWZ>(pb + ix, cg)];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const v4f wv = wl[(ky * K + kx) * CG + cg];
+                    w[kx] = ok ? wv : (v4f){0.f, 0.f, 0.f, 0.f};      // rows outside the image: TF-SAME zero padding
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int ox = 0; ox < H; ++ox) {
+                        const int ix = ox + kx - PAD;                 // compile-time after unrolling
+                        if (ix >= 0 && ix < H) o[ox] += in[ix] * w[kx];
+                    }
+            }
+            XT* yb = Y + ((size_t)img * H * H + (size_t)rr * H) * C + c0 + 4 * cg;
+#pragma unroll
+            for (int ox = 0; ox < H; ++ox) {
+                const v4f v = swish4(o[ox]);
+                if (img < n_img) st4(yb + (size_t)ox * C, v);
+                psum += v;
+            }
+            red[(sub * H + rr) * CG + cg] = psum;
+        }
+        __syncthreads();
+        if (tid < G * CG) {                                            // the 7 row sums of a channel quad folded in row order
+            const int s2 = tid >> 3, c2 = tid & 7;
+            v4f t = red[(s2 * H) * CG + c2];
+#pragma unroll
+            for (int r2 = 1; r2 < H; ++r2) t += red[(s2 * H + r2) * CG + c2];
+            if (grp * G + s2 < n_img) stg4(P + (size_t)(grp * G + s2) * C + c0 + 4 * c2, t);
+        }
+    }
+    MB_TP(6);
+#ifdef MB_TRACE
+    if (H == MB_TRACE_H && S == MB_TRACE_S && bid.x == 5 && bid.n == 3 && threadIdx.x == 0) g_mb_trace[255] = mtp;
+#endif
+}
+
+template <int K, int S, int HW, int CIN, typename XT>
+static void mb_late_launch(const XT* X, const unsigned short* We3, int plane, int Kp, const float* be, const float* W, const float* b,
+                           XT* Y, float* P, int n, int C, int pad_lo, int* tiles, hipStream_t s) {
+    *tiles = 1;
+    const int groups = HW == 14 ? n : (n + 3) / 4;
+    hipLaunchKernelGGL((mbconv_late_kernel<K, S, HW, CIN, XT>), dim3(groups * (C / 32)), dim3(256), 0, s, X, We3, plane, Kp, be, W, b,
+                       Y, P, n, C, pad_lo);
+}
+
+// (k, stride, H, C, Cin) of blocks 6-10 and 12-15 (block 11, 14 -> 7 at stride 2, measured 115 us in this form against
+// 110 us as GEMM + depthwise: left out)
+#define DFD_MB_LATE_TABLE(OP)  \
+    OP(3, 1, 14, 480, 80)      \
+    OP(5, 1, 14, 480, 80)      \
+    OP(5, 1, 14, 672, 112)     \
+    OP(5, 1, 7, 1152, 192)     \
+    OP(3, 1, 7, 1152, 192)
+
 // expand (1x1 + BN + swish) fused into the depthwise kernel; only the five large-spatial MBConv
 // blocks (1..5) are instantiated: there the expanded tensor dominates HBM traffic and C_in <= 48.
 // (k, stride, H, C, Cin) -> <K,S,CB,TH,TW,RP, NK = ceil(Cin/32)>; several variants per block, the first is the
@@ -1395,7 +1651,19 @@ static void mb2_launch(const XT* X, int Cin, const unsigned short* We3, int plan
 template <typename XT>
 bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int plane, int Kp, const float* Wef, const float* be,
                          const float* Wd, const float* bd, XT* Y, float* P, int n, int H, int C, int k, int stride,
-                         int pad_lo, int* tiles, hipStream_t s, const SeTail& se) {
+                         int pad_lo, int* tiles, hipStream_t s, const SeTail& se, bool late) {
+    if (H <= 14) {
+        // option "fuse_late"; the squeeze-excite tail counts blocks per image, a late block holds up to four: not combined
+        if (!late || se.gate) return false;
+#define DFD_MB_LATE_DISPATCH(KK, SS, HH, CC, CI)                                                                     \
+    if (k == KK && stride == SS && H == HH && C == CC && Cin == CI) {                                               \
+        mb_late_launch<KK, SS, HH, CI, XT>(Xin, We3, plane, Kp, be, Wd, bd, Y, P, n, C, pad_lo, tiles, s);          \
+        return true;                                                                                                \
+    }
+        DFD_MB_LATE_TABLE(DFD_MB_LATE_DISPATCH)
+#undef DFD_MB_LATE_DISPATCH
+        return false;
+    }
     int var = mb_variant(H, stride);
     if (var == -2) {
         // defaults by measurement at batch 256 (profiles/mb_variants.py, round 3, us fp32 / bf16):
@@ -1487,11 +1755,11 @@ bool launch_mbconv_front(const XT* Xin, int Cin, const unsigned short* We3, int 
 #endif
     return false;
 }
-template bool launch_mbconv_front<float>(const float*, int, const unsigned short*, int, int, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int*, hipStream_t, const SeTail&);
-template bool launch_mbconv_front<bf16_t>(const bf16_t*, int, const unsigned short*, int, int, const float*, const float*, const float*, const float*, bf16_t*, float*, int, int, int, int, int, int, int*, hipStream_t, const SeTail&);
+template bool launch_mbconv_front<float>(const float*, int, const unsigned short*, int, int, const float*, const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int*, hipStream_t, const SeTail&, bool);
+template bool launch_mbconv_front<bf16_t>(const bf16_t*, int, const unsigned short*, int, int, const float*, const float*, const float*, const float*, bf16_t*, float*, int, int, int, int, int, int, int*, hipStream_t, const SeTail&, bool);
 
 // SE pool partial-sum tiles of a fused launch (the workspace is sized for the largest count over all variants)
-int mbconv_tiles(int H, int C, int k, int stride, int Cin) {
+int mbconv_tiles(int H, int C, int k, int stride, int Cin, bool late) {
     const int Ho = (H + stride - 1) / stride;
     int best = -1;
 #define DFD_MB2_TILES(VV, KK, SS, HH, CC, CI, CB, TH, TW, RP, NK)                    \
@@ -1512,6 +1780,10 @@ int mbconv_tiles(int H, int C, int k, int stride, int Cin) {
     DFD_MB1_TABLE(DFD_MB1_TILES)
 #undef DFD_MB1_TILES
     if (k == 5 && stride == 1 && H == 28 && C == 240 && Cin == 40 && best < 4) best = 4;      // variant 14: 7 x 28 tiles
+#define DFD_MB_LATE_TILES(KK, SS, HH, CC, CI) \
+    if (late && k == KK && stride == SS && H == HH && C == CC && Cin == CI && best < 1) best = 1;
+    DFD_MB_LATE_TABLE(DFD_MB_LATE_TILES)
+#undef DFD_MB_LATE_TILES
     return best;
 }
 

@@ -117,7 +117,7 @@ int b0_build_plan(dfd_handle* h) {
             b.proj_b = need(h, q + ".proj.b", {co}, &ok);
             b.dw_tiles = depthwise_tiles(b.h_in, b.c_exp, b.kernel, b.stride);
             if (b.dw_tiles < 0) return fail(h, DFD_ERR_STATE, "no depthwise kernel for block %d", idx);
-            b.dw_tiles = std::max(b.dw_tiles, mbconv_tiles(b.h_in, b.c_exp, b.kernel, b.stride, b.c_in));
+            b.dw_tiles = std::max(b.dw_tiles, mbconv_tiles(b.h_in, b.c_exp, b.kernel, b.stride, b.c_in, true));
             auto mx = [](size_t& a, size_t v) { if (v > a) a = v; };
             mx(P.io_floats, (size_t)b.h_out * b.h_out * b.c_out);
             if (b.expand != 1) mx(P.exp_floats, (size_t)b.h_in * b.h_in * b.c_exp);
@@ -274,11 +274,11 @@ static int b0_forward_t(dfd_handle* h, const float* x, int n, float* logits_dev,
         int tiles = 0;
         bool fused = false;
         const unsigned short* we3 = nullptr;
-        if (b.expand != 1 && h->fuse_expand && mbconv_tiles(b.h_in, b.c_exp, b.kernel, b.stride, b.c_in) > 0 &&
+        if (b.expand != 1 && h->fuse_expand && mbconv_tiles(b.h_in, b.c_exp, b.kernel, b.stride, b.c_in, h->fuse_late) > 0 &&
             !(we3 = split_weights(h, b.exp_w, b.c_exp, b.c_in))) return DFD_ERR_HIP;
         if (we3 && launch_mbconv_front<XT>(cur, b.c_in, we3, (int)split_weights_count(b.c_exp, b.c_in), (b.c_in + 63) / 64 * 64,
                                            b.exp_w, b.exp_b, b.dw_w, b.dw_b, dwbuf, h->pool, n, b.h_in, b.c_exp,
-                                           b.kernel, b.stride, b.pad_lo, &tiles, s, se_of(b))) {
+                                           b.kernel, b.stride, b.pad_lo, &tiles, s, se_of(b), h->fuse_late)) {
             fused = true;
             mk.mark(layer_name(bi, "dw"));            // expand + depthwise in one launch
             if (tap && tap->name && q + ".exp" == tap->name)

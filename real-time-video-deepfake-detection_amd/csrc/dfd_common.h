@@ -116,6 +116,7 @@ struct dfd_handle {
     bool use_mtcnn = true;                    // classify paths align each crop with the cascade when the blob has one
     bool fuse_stem = true;               // stem conv computed inside block 0's depthwise kernel
     bool fuse_expand = true;             // MBConv blocks 1-5: expand conv computed inside the depthwise kernel
+    bool fuse_late = false;              // blocks 6-15: expand + depthwise of whole images in one launch (mbconv_late_kernel); see DESIGN section 5
     bool fuse_se = false;                // squeeze-excite gate computed by the last block of each image inside the depthwise launch
                                          // (measured slower than the separate launch: DESIGN.md section 5, round 3; kept as an option)
     unsigned* se_counter = nullptr;      // [max_batch] arrival counters of that hand-off (zero between launches)

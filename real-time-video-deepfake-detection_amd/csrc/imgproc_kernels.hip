@@ -92,30 +92,6 @@ void u8_to_float(const uint8_t* src, float* dst, int n, float scale, hipStream_t
 }
 
 // ------------------------------------------------------------------------------ Lab
-__device__ __forceinline__ void bgr2lab(const ColorTables& T, int b, int g, int r, int& L, int& A, int& B) {
-    const long long R_ = T.gamma[r], G_ = T.gamma[g], B_ = T.gamma[b];
-    const int fX = T.cbrt[descale(R_ * T.fwd[0] + G_ * T.fwd[1] + B_ * T.fwd[2], 12)];
-    const int fY = T.cbrt[descale(R_ * T.fwd[3] + G_ * T.fwd[4] + B_ * T.fwd[5], 12)];
-    const int fZ = T.cbrt[descale(R_ * T.fwd[6] + G_ * T.fwd[7] + B_ * T.fwd[8], 12)];
-    const int Lscale = (116 * 255 + 50) / 100;
-    const int Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
-    L = clampi(descale((long long)Lscale * fY + Lshift, 15), 0, 255);
-    A = clampi(descale(500ll * (fX - fY) + 128ll * (1 << 15), 15), 0, 255);
-    B = clampi(descale(200ll * (fY - fZ) + 128ll * (1 << 15), 15), 0, 255);
-}
-
-__device__ __forceinline__ void lab2bgr(const ColorTables& T, int L, int A, int B, int& b, int& g, int& r) {
-    // OpenCV Lab2RGBinteger::process: LabToYF_b, adiv / bdiv, abToXZ_b (indexed from minABvalue), 12-bit matrix descaled by
-    // lab_shift + base_shift - inv_gamma_shift = 14 to a 12-bit linear value, sRGBInvGammaTab_b
-    const int AB_MIN = -8145, AB_TAB = 36864, TAB = 1 << 12;
-    const long long fy = T.L_fy[L], y = T.L_y[L];
-    const long long x = T.ab_xz[clampi((int)(fy + T.a_div[A]) - AB_MIN, 0, AB_TAB - 1)];
-    const long long z = T.ab_xz[clampi((int)(fy - T.b_div[B]) - AB_MIN, 0, AB_TAB - 1)];
-    r = T.inv_gamma[clampi(descale(T.inv[0] * x + T.inv[1] * y + T.inv[2] * z, 14), 0, TAB - 1)];
-    g = T.inv_gamma[clampi(descale(T.inv[3] * x + T.inv[4] * y + T.inv[5] * z, 14), 0, TAB - 1)];
-    b = T.inv_gamma[clampi(descale(T.inv[6] * x + T.inv[7] * y + T.inv[8] * z, 14), 0, TAB - 1)];
-}
-
 // ------------------------------------------------------------------------------ CLAHE
 // One block per (tile, crop).  The tile grid is 8x8 over the crop extended by reflect-101 to
 // a multiple of 8 (OpenCV pads BOTH dimensions by a full 8-rem when either is ragged).
@@ -124,12 +100,38 @@ __device__ __forceinline__ void clahe_geometry(const CropDesc& cd, int& ew, int&
     else { ew = cd.w + (8 - cd.w % 8); eh = cd.h + (8 - cd.h % 8); }
 }
 
+// Round 3: the first version spent its time in the texture-address unit, not in HBM - per pixel 3 byte loads, 6 table
+// gathers from global memory and 3 byte stores, each a full 64-address instruction (206 us per 256 crops of ~150k px =
+// 0.56 TB/s).  Now: gamma + cbrt tables in LDS (6.5 KB as u16), four pixels per thread = one 12-byte load and one
+// 12-byte store (the conversions in 32-bit integers: every intermediate stays below 2^31, see the table ranges in
+// luts.py), one sub-histogram per wave.  Pixels of the reflected border (the last tile column / row of a ragged crop)
+// take the one-pixel path.
+struct LabLds { unsigned short gamma[256]; unsigned short cbrt[3072]; };
+
+__device__ __forceinline__ void lab_tables_to_lds(const ColorTables& T, LabLds& S, int tid) {
+    S.gamma[tid] = (unsigned short)T.gamma[tid];
+    for (int i = tid; i < 3072; i += 256) S.cbrt[i] = (unsigned short)T.cbrt[i];
+}
+
+__device__ __forceinline__ void bgr2lab_lds(const ColorTables& T, const LabLds& S, int b, int g, int r, int& L, int& A, int& B) {
+    const int R_ = S.gamma[r], G_ = S.gamma[g], B_ = S.gamma[b];
+    const int fX = S.cbrt[(R_ * T.fwd[0] + G_ * T.fwd[1] + B_ * T.fwd[2] + (1 << 11)) >> 12];
+    const int fY = S.cbrt[(R_ * T.fwd[3] + G_ * T.fwd[4] + B_ * T.fwd[5] + (1 << 11)) >> 12];
+    const int fZ = S.cbrt[(R_ * T.fwd[6] + G_ * T.fwd[7] + B_ * T.fwd[8] + (1 << 11)) >> 12];
+    const int Lscale = (116 * 255 + 50) / 100;
+    const int Lshift = -((16 * 255 * (1 << 15) + 50) / 100);
+    L = clampi((Lscale * fY + Lshift + (1 << 14)) >> 15, 0, 255);
+    A = clampi((500 * (fX - fY) + 128 * (1 << 15) + (1 << 14)) >> 15, 0, 255);
+    B = clampi((200 * (fY - fZ) + 128 * (1 << 15) + (1 << 14)) >> 15, 0, 255);
+}
+
 __global__ __launch_bounds__(256) void clahe_hist_kernel(const uint8_t* __restrict__ frame, size_t fstride,
                                                          const CropDesc* __restrict__ crops,
                                                          uint8_t* __restrict__ lab_out,
                                                          uint8_t* __restrict__ luts, ColorTables T,
                                                          float clip_limit) {
-    __shared__ int hist[256];
+    __shared__ LabLds S;
+    __shared__ int hist[4][256];
     __shared__ int scan[256];
     __shared__ int clipped_total;
     const int tid = threadIdx.x;
@@ -138,27 +140,49 @@ __global__ __launch_bounds__(256) void clahe_hist_kernel(const uint8_t* __restri
     clahe_geometry(cd, ew, eh);
     const int tw = ew / 8, th = eh / 8;
     const int tx = blockIdx.x % 8, ty = blockIdx.x / 8;
-    hist[tid] = 0;
+    lab_tables_to_lds(T, S, tid);
+    for (int w = 0; w < 4; ++w) hist[w][tid] = 0;
     if (tid == 0) clipped_total = 0;
     __syncthreads();
     uint8_t* lab = lab_out + cd.offset;
-    for (int i = tid; i < tw * th; i += 256) {
-        const int ex = tx * tw + i % tw, ey = ty * th + i / tw;
-        const int sx = reflect101(ex, cd.w), sy = reflect101(ey, cd.h);
-        const uint8_t* p = frame + cd.src_off + (size_t)(cd.y + sy) * fstride + (size_t)(cd.x + sx) * 3;
-        int L, A, B;
-        bgr2lab(T, p[0], p[1], p[2], L, A, B);
-        atomicAdd(&hist[L], 1);
-        if (ex < cd.w && ey < cd.h) {
-            uint8_t* o = lab + ((size_t)ey * cd.w + ex) * 3;
-            o[0] = (uint8_t)L; o[1] = (uint8_t)A; o[2] = (uint8_t)B;
+    int* myhist = hist[tid >> 6];
+    const uint8_t* src = frame + cd.src_off + (size_t)cd.y * fstride + (size_t)cd.x * 3;
+    const unsigned gpr = (unsigned)(tw + 3) / 4, ngroups = gpr * (unsigned)th;
+    for (unsigned gi = tid; gi < ngroups; gi += 256) {
+        const unsigned row = gi / gpr, gx = gi - row * gpr;
+        const int ex0 = tx * tw + (int)gx * 4, ey = ty * th + (int)row;
+        const int cnt = tw - (int)gx * 4 < 4 ? tw - (int)gx * 4 : 4;
+        if (cnt == 4 && ex0 + 3 < cd.w && ey < cd.h) {
+            unsigned char px[12], res[12];
+            __builtin_memcpy(px, src + (size_t)ey * fstride + (size_t)ex0 * 3, 12);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int L, A, B;
+                bgr2lab_lds(T, S, px[3 * k], px[3 * k + 1], px[3 * k + 2], L, A, B);
+                atomicAdd(&myhist[L], 1);
+                res[3 * k] = (unsigned char)L; res[3 * k + 1] = (unsigned char)A; res[3 * k + 2] = (unsigned char)B;
+            }
+            __builtin_memcpy(lab + ((size_t)ey * cd.w + ex0) * 3, res, 12);
+        } else {
+            for (int k = 0; k < cnt; ++k) {
+                const int ex = ex0 + k;
+                const int sx = reflect101(ex, cd.w), sy = reflect101(ey, cd.h);
+                const uint8_t* p = src + (size_t)sy * fstride + (size_t)sx * 3;
+                int L, A, B;
+                bgr2lab_lds(T, S, p[0], p[1], p[2], L, A, B);
+                atomicAdd(&myhist[L], 1);
+                if (ex < cd.w && ey < cd.h) {
+                    uint8_t* o = lab + ((size_t)ey * cd.w + ex) * 3;
+                    o[0] = (uint8_t)L; o[1] = (uint8_t)A; o[2] = (uint8_t)B;
+                }
+            }
         }
     }
     __syncthreads();
     const int area = tw * th;
     int clip = (int)((double)clip_limit * area / 256);
     if (clip < 1) clip = 1;
-    int hv = hist[tid];
+    int hv = hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid];
     if (hv > clip) { atomicAdd(&clipped_total, hv - clip); hv = clip; }
     __syncthreads();
     const int clipped = clipped_total;
@@ -193,14 +217,21 @@ __device__ __forceinline__ int ab_to_xz(int v) {
     return v <= 3390 ? lin : cube;
 }
 
-__device__ __forceinline__ void lab2bgr_fast(const ColorTables& T, int L, int A, int B, int& b, int& g, int& r) {
+// Round 3: a block owns a contiguous run of a crop's pixels and keeps what it gathers from in LDS - the crop's 64 tile
+// LUTs (16 KB), sRGBInvGammaTab_b as bytes (4 KB), LabToYF_b (2 KB): the 9 global gathers per pixel of the first version
+// (222 us per 256 crops, address-unit bound) become LDS reads; the matrix in 32-bit integers (|terms| < 1.2e9, luts.py).
+struct ApplyLds { unsigned char lut[64 * 256]; unsigned char inv_gamma[4096]; int L_fy[256]; int L_y[256]; };
+
+__device__ __forceinline__ void lab2bgr_lds(const ColorTables& T, const ApplyLds& S, int L, int A, int B, int& b, int& g, int& r) {
     const int TAB = 1 << 12;
-    const int fy = T.L_fy[L], y = T.L_y[L];
+    const int fy = S.L_fy[L], y = S.L_y[L];
     const int adiv = ((5 * A * 53687 + 128) >> 13) - 4194, bdiv = ((B * 41943 + 16) >> 9) - 10485 + 1;
-    const long long x = ab_to_xz(fy + adiv), z = ab_to_xz(fy - bdiv);
-    r = T.inv_gamma[clampi(descale(T.inv[0] * x + T.inv[1] * y + T.inv[2] * z, 14), 0, TAB - 1)];
-    g = T.inv_gamma[clampi(descale(T.inv[3] * x + T.inv[4] * y + T.inv[5] * z, 14), 0, TAB - 1)];
-    b = T.inv_gamma[clampi(descale(T.inv[6] * x + T.inv[7] * y + T.inv[8] * z, 14), 0, TAB - 1)];
+    const int x = ab_to_xz(fy + adiv), z = ab_to_xz(fy - bdiv);
+    const int i0 = (int)T.inv[0], i1 = (int)T.inv[1], i2 = (int)T.inv[2], i3 = (int)T.inv[3], i4 = (int)T.inv[4],
+              i5 = (int)T.inv[5], i6 = (int)T.inv[6], i7 = (int)T.inv[7], i8 = (int)T.inv[8];
+    r = S.inv_gamma[clampi((i0 * x + i1 * y + i2 * z + (1 << 13)) >> 14, 0, TAB - 1)];
+    g = S.inv_gamma[clampi((i3 * x + i4 * y + i5 * z + (1 << 13)) >> 14, 0, TAB - 1)];
+    b = S.inv_gamma[clampi((i6 * x + i7 * y + i8 * z + (1 << 13)) >> 14, 0, TAB - 1)];
 }
 
 // four pixels (12 bytes of the packed crop: three aligned dwords in, three out) per thread and iteration
@@ -208,25 +239,36 @@ __global__ __launch_bounds__(256) void clahe_apply_kernel(const CropDesc* __rest
                                                           const uint8_t* __restrict__ lab_in,
                                                           const uint8_t* __restrict__ luts,
                                                           uint8_t* __restrict__ bgr_out, ColorTables T) {
+    __shared__ ApplyLds S;
     const CropDesc cd = crops[blockIdx.y];
     int ew, eh;
     clahe_geometry(cd, ew, eh);
+    const int npix = cd.w * cd.h, ngroups = (npix + 3) / 4;
+    const int per_block = (ngroups + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int g_begin = (int)blockIdx.x * per_block, g_end = g_begin + per_block < ngroups ? g_begin + per_block : ngroups;
+    if (g_begin >= g_end) return;                                           // uniform per block
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(luts + (size_t)blockIdx.y * 64 * 256);
+        uint4* dst = reinterpret_cast<uint4*>(S.lut);
+        for (int i = threadIdx.x; i < 64 * 256 / 16; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < 4096; i += 256) S.inv_gamma[i] = (unsigned char)T.inv_gamma[i];
+        S.L_fy[threadIdx.x] = T.L_fy[threadIdx.x];
+        S.L_y[threadIdx.x] = T.L_y[threadIdx.x];
+    }
+    __syncthreads();
     const float inv_tw = 1.0f / (float)(ew / 8), inv_th = 1.0f / (float)(eh / 8);
-    const uint8_t* lut = luts + (size_t)blockIdx.y * 64 * 256;
     const uint8_t* lab = lab_in + cd.offset;
     uint8_t* out = bgr_out + cd.offset;
-    const int npix = cd.w * cd.h, ngroups = (npix + 3) / 4;
-    for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ngroups; gi += gridDim.x * 256) {
+    for (int gi = g_begin + (int)threadIdx.x; gi < g_end; gi += 256) {
         const int i0 = gi * 4;
         const int cnt = npix - i0 < 4 ? npix - i0 : 4;                     // the crop's last group may be short
         unsigned char px[12], res8[12];
         if (cnt == 4) *reinterpret_cast<uint3*>(px) = *reinterpret_cast<const uint3*>(lab + (size_t)i0 * 3);
         else
             for (int k = 0; k < 12; ++k) px[k] = k < cnt * 3 ? lab[(size_t)i0 * 3 + k] : 0;
+        int y = (int)((unsigned)i0 / (unsigned)cd.w), x = i0 - y * cd.w;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int i = i0 + k < npix ? i0 + k : npix - 1;
-            const int x = i % cd.w, y = i / cd.w;
             const float txf = (float)x * inv_tw - 0.5f, tyf = (float)y * inv_th - 0.5f;
             int tx1 = (int)floorf(txf), ty1 = (int)floorf(tyf);
             const float xa = txf - (float)tx1, ya = tyf - (float)ty1;
@@ -235,13 +277,17 @@ __global__ __launch_bounds__(256) void clahe_apply_kernel(const CropDesc* __rest
             tx1 = tx1 > 0 ? tx1 : 0;
             ty1 = ty1 > 0 ? ty1 : 0;
             const int L = px[3 * k];
-            const float l11 = lut[(ty1 * 8 + tx1) * 256 + L], l12 = lut[(ty1 * 8 + tx2) * 256 + L];
-            const float l21 = lut[(ty2 * 8 + tx1) * 256 + L], l22 = lut[(ty2 * 8 + tx2) * 256 + L];
+            const float l11 = S.lut[(ty1 * 8 + tx1) * 256 + L], l12 = S.lut[(ty1 * 8 + tx2) * 256 + L];
+            const float l21 = S.lut[(ty2 * 8 + tx1) * 256 + L], l22 = S.lut[(ty2 * 8 + tx2) * 256 + L];
             const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
             const int Ln = clampi((int)rintf(res), 0, 255);
             int b, g, r;
-            lab2bgr_fast(T, Ln, px[3 * k + 1], px[3 * k + 2], b, g, r);
+            lab2bgr_lds(T, S, Ln, px[3 * k + 1], px[3 * k + 2], b, g, r);
             res8[3 * k] = (unsigned char)b; res8[3 * k + 1] = (unsigned char)g; res8[3 * k + 2] = (unsigned char)r;
+            if (++x == cd.w) {                                             // a pixel past the crop's end (short last group)
+                x = 0;                                                      // is clamped below
+                if (y + 1 < cd.h) ++y; else x = cd.w - 1;
+            }
         }
         if (cnt == 4) *reinterpret_cast<uint3*>(out + (size_t)i0 * 3) = *reinterpret_cast<const uint3*>(res8);
         else
@@ -291,8 +337,11 @@ __global__ __launch_bounds__(256) void crop_norm_kernel(const uint8_t* __restric
 void launch_clahe(const uint8_t* frame, size_t fstride, const CropDesc* crops_dev, int n, uint8_t* lab,
                   uint8_t* luts, uint8_t* bgr_out, const ColorTables& T, int max_pixels, hipStream_t s) {
     hipLaunchKernelGGL(clahe_hist_kernel, dim3(64, n), dim3(256), 0, s, frame, fstride, crops_dev, lab, luts, T, 2.0f);
-    int gx = (max_pixels / 4 + 255) / 256;
-    if (gx > 1024) gx = 1024;
+    // blocks per crop: each stages 22 KB of tables, so a block gets >= 1024 pixel groups (one crop alone still fills
+    // the chip's eighth: the request path) and a large batch 8 blocks per crop
+    int gx = (max_pixels / 4 + 1023) / 1024;
+    const int cap = n >= 256 ? 8 : n >= 64 ? 16 : 64;
+    if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(clahe_apply_kernel, dim3(gx, n), dim3(256), 0, s, crops_dev, lab, luts, bgr_out, T);
 }

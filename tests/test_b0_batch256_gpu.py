@@ -92,3 +92,17 @@ def test_analyze_batch_1080p_x64_matches_per_frame_path(big):
         _, prob, _ = big.forensics(frames[f], True, stream_id=900 + f)
         assert prob == fp[f], (f, prob, fp[f])
     assert sum(len(b) for b in db) > 0, "the detector never fired: the detected-box half of this test is empty"
+
+
+def test_batch256_late_block_launches_agree_with_the_default_path(big, crops):
+    """Option "fuse_late" at the benchmark's size: blocks 6-10 / 12-15 as whole-image launches.  The expand products are
+    the same six exact bf16 cross terms as in the GEMM, summed in a different order: logits agree to fp32 round-off."""
+    x = crops.numpy()
+    base = big.classify(x)
+    big.set_option("fuse_late", 1)
+    try:
+        late = big.classify(x)
+    finally:
+        big.set_option("fuse_late", 0)
+    assert np.all(np.isfinite(late))
+    assert float(np.abs(late - base).max()) <= 1e-4

@@ -66,6 +66,26 @@ def test_bf16_taps_and_logits_close_to_fp32_oracle(pkg, bf16, seeded_sd, fuse):
     assert err > 1e-6, "suspiciously exact: is the bf16 path running?"
 
 
+def test_bf16_late_block_launches_stay_within_the_bf16_bars(pkg, bf16, seeded_sd):
+    """Option "fuse_late" with bf16 activations (three products per K-step against the exact weight planes): the taps of
+    the blocks it changes stay within the same relative bar as the default path."""
+    x = _crops(3, 21)
+    taps = {}
+    b0_ref.forward(pkg.weights.to_torch(seeded_sd), torch.from_numpy(x), taps)
+    xd = bf16.alloc(x.nbytes).upload(x)
+    bf16.set_option("fuse_late", 1)
+    try:
+        for i in (6, 8, 9, 12, 15):
+            for kind in ("dw", "out"):
+                w = _nhwc(taps[f"b{i}.{kind}"]).reshape(-1)
+                got = bf16.tap(xd.ptr, 3, f"b{i}.{kind}", w.size)
+                rel = float(np.abs(got - w).max() / max(1e-6, np.abs(w).max()))
+                assert rel <= 2e-2, f"b{i}.{kind}: {rel:.3e} of max|ref|"
+    finally:
+        bf16.set_option("fuse_late", 0)
+        xd.free()
+
+
 def test_bf16_logit_error_statistics(pkg, bf16, seeded_sd):
     """The logit bar of the bf16 config, stated as what it is: a distribution.  Rounding every stored activation to
     bf16 (8 significand bits, 81 conv layers) makes the logit error a random variable - measured over 64 crops x 4

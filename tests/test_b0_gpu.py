@@ -66,6 +66,35 @@ def test_taps_match_oracle(b0_handle, ref, fuse):
     print("worst tap errors:", sorted(worst.items(), key=lambda kv: -kv[1])[:5])
 
 
+def test_late_blocks_in_one_launch_match_oracle(b0_handle, ref):
+    """Option "fuse_late": blocks 6-10 and 12-15 run expand + depthwise of whole images in one launch
+    (mbconv_late_kernel); every tap downstream of them and the logits stay within the fp32 bar, and the expanded
+    tensor of such a block is reported as not materialised."""
+    x, want, taps = ref
+    n = x.shape[0]
+    xd = b0_handle.alloc(x.nbytes).upload(x)
+    b0_handle.set_option("fuse_late", 1)
+    try:
+        for i in range(6, 16):
+            for kind in ("dw", "gate", "out"):
+                name = f"b{i}.{kind}"
+                w = _nhwc(taps[name])
+                if kind == "gate":
+                    w = w.reshape(n, -1)
+                got = b0_handle.tap(xd.ptr, n, name, w.size).reshape(w.shape)
+                err = float(np.abs(got - w).max())
+                assert err <= LOGIT_TOL, f"{name}: max|d|={err:.3e}"
+        with pytest.raises(Exception):
+            b0_handle.tap(xd.ptr, n, "b9.exp", 10)
+        got = b0_handle.classify(x)
+        assert np.abs(got - want).max() <= LOGIT_TOL
+        for m in (1, 2):                                    # 7 x 7 blocks hold four images: ragged last group
+            assert np.abs(b0_handle.classify(x[:m]) - want[:m]).max() <= LOGIT_TOL
+    finally:
+        b0_handle.set_option("fuse_late", 0)
+        xd.free()
+
+
 def test_fused_and_unfused_logits_agree(b0_handle, ref):
     x, want, _ = ref
     b0_handle.set_option("fuse_expand", 0)
