@@ -287,17 +287,39 @@ int ssd_forward(dfd_handle* h, const uint8_t* in300, int n, const char* tap_name
         tapped = true;
         return DFD_OK;
     };
-    for (const SsdLayer& L : S->layers) {
+    bool skip_pool = false;                  // pool1 was computed inside conv1's launch
+    for (size_t li = 0; li < S->layers.size(); ++li) {
+        const SsdLayer& L = S->layers[li];
         const SsdTensor& src = S->t[L.src];
         const SsdTensor& dst = S->t[L.name];
         const std::string q = std::string("ssd.") + L.name;
+        if (skip_pool && L.kind == SK_POOL) {
+            skip_pool = false;
+            if ((rc = tap(L.name))) return rc;
+            continue;
+        }
         switch (L.kind) {
             case SK_CONV1: {
                 // the matrix-pipe kernel (DFD_SSD_CONV1_MFMA=0: the thread-per-pixel kernel, for A/B runs)
                 static const bool mfma = !(getenv("DFD_SSD_CONV1_MFMA") && atoi(getenv("DFD_SSD_CONV1_MFMA")) == 0);
+                static const bool pool_fused = !(getenv("DFD_SSD_CONV1_POOL") && atoi(getenv("DFD_SSD_CONV1_POOL")) == 0);
                 const float* wc = W_(q + ".w", 147 * 32);
                 const unsigned short* w3 = mfma ? split_weights(h, wc, 32, 147, true) : nullptr;
                 if (mfma && !w3) return DFD_ERR_HIP;
+                // conv1 -> pool1 with nothing else reading conv1 (and no tap on it): one launch, the 150 x 150 map stays on chip
+                bool fuse = mfma && pool_fused && li + 1 < S->layers.size() && S->layers[li + 1].kind == SK_POOL &&
+                            S->layers[li + 1].src == L.name && dst.size == 150 && dst.c == 32 &&
+                            S->t[S->layers[li + 1].name].size == 75 && !(tap_name && L.name == tap_name);
+                for (size_t o = li + 2; fuse && o < S->layers.size(); ++o)
+                    if (S->layers[o].src == L.name || S->layers[o].res == L.name) fuse = false;
+                for (int i6 = 0; fuse && i6 < 6; ++i6)
+                    if (L.name == S->sources[i6].tensor) fuse = false;
+                if (fuse) {
+                    launch_ssd_conv1_pool(in300, w3, (int)split_weights_count(32, 147), 192, W_(q + ".b", 32), ptr(S->layers[li + 1].name), n,
+                                          S->in_scale, S->in_shift, L.relu, s);
+                    skip_pool = true;
+                    break;
+                }
                 if (mfma)
                     launch_ssd_conv1_mfma(in300, w3, (int)split_weights_count(32, 147), 192, W_(q + ".b", 32), ptr(L.name), n,
                                           S->in_scale, S->in_shift, L.relu, s);

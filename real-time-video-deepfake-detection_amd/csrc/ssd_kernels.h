@@ -22,6 +22,10 @@ void launch_ssd_conv1(const uint8_t* img, const float* w, const float* b, float*
 // the same convolution on the bf16 MFMA against the three exact weight planes [32][Kp] of split_weights(w, 32, 147, transposed)
 void launch_ssd_conv1_mfma(const uint8_t* img, const unsigned short* w3, int plane, int Kp, const float* b, float* y, int n,
                            const float in_scale[3], const float in_shift[3], bool relu, hipStream_t s);
+// conv1 (as above) + ReLU + the 3x3 stride-2 ceil-mode max pool behind it in one launch: y_pool [n][75][75][32]; the
+// 150 x 150 conv map is not materialised
+bool launch_ssd_conv1_pool(const uint8_t* img, const unsigned short* w3, int plane, int Kp, const float* b, float* y_pool, int n,
+                           const float in_scale[3], const float in_shift[3], bool relu, hipStream_t s);
 // y = [relu](x * scale[c] + shift[c]) (scale/shift may be null: 1 / 0) (+ add, before the relu); NHWC fp32, C % 4 == 0:
 // a BatchNorm+Scale(+ReLU) that cannot be folded into a convolution (pre-activation ResNet), or an Eltwise SUM
 void launch_channel_affine(const float* x, const float* scale, const float* shift, const float* add, float* y,

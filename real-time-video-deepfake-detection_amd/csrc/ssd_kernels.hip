@@ -231,6 +231,170 @@ void launch_ssd_conv1_mfma(const uint8_t* img, const unsigned short* w3, int pla
                            in_scale[2], in_shift[0], in_shift[1], in_shift[2], relu ? 1 : 0);
 }
 
+// ---- conv1 + ReLU + pool1 in one launch (round 3) ---------------------------------------------------------------
+// The 150 x 150 x 32 conv1 map was written (184 MB per 64 frames) only for the 3x3 stride-2 max pool to read it back:
+// 88 + 48 us.  Here a block owns an 8 x 8 tile of POOLED pixels = 17 x 17 conv pixels (13 % of them shared with the
+// neighbours and recomputed): the conv runs as in ssd_conv1_mfma_kernel (19 sixteen-pixel MFMA column tiles over the
+// block's fp32 input patch), its ReLU'd outputs go to an LDS tile that takes over the patch's storage, and a thread then
+// folds the nine taps of a pooled pixel's channel quad.  Caffe's ceil-mode pooling: the last window hangs over the map's
+// edge and a clamped tap re-reads an element of the window (maxpool3s2_kernel), so conv pixels outside the map are never
+// read.
+template <bool EXACT>
+__global__ __launch_bounds__(256, 3) void ssd_conv1_pool_kernel(const uint8_t* __restrict__ img, const unsigned short* __restrict__ w3,
+                                                             int plane, int Kp, const float* __restrict__ bias,
+                                                             float* __restrict__ y, float sb, float sg, float sr, float hb,
+                                                             float hg, float hr, int relu) {
+    constexpr int PT = 8, CT = 2 * PT + 1, NPX = CT * CT, NMT = (NPX + 15) / 16, NMTW = (NMT + 3) / 4;   // 17 x 17 conv pixels, 19 tiles
+    constexpr int PH = 2 * CT + 5, PW = (2 * CT + 5) * 3, PWP = PW + 1;                                    // 39 rows x 117 (+1) floats
+    constexpr int CS = 36;                                                 // floats per pixel of the conv tile (32 + 4: bank spread)
+    constexpr int LDSF = NPX * CS > PH * PWP ? NPX * CS : PH * PWP;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    float* patch = lds;
+    float* ctile = lds;                                                    // after the last gather
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+    const int n = blockIdx.z, py0 = blockIdx.y * PT, px0 = blockIdx.x * PT;       // pooled origin
+    const int ty0 = 2 * py0, tx0 = 2 * px0;                                       // conv origin
+    const uint8_t* src = img + (size_t)n * 300 * 300 * 3;
+    const int r0 = 2 * ty0 - 3, c0 = (2 * tx0 - 3) * 3;
+    const float sc[3] = {sb, sg, sr}, sh[3] = {hb, hg, hr};
+    // patch: aligned dword loads (c0 - 3 = 96 * blockIdx.x - 12), 30 dwords cover the 117 bytes of a row
+    constexpr int DW = 30, NEL = PH * DW, NLD = (NEL + 255) / 256;
+    unsigned pv[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + k * 256 < NEL ? tid + k * 256 : NEL - 1;
+        const int r = i / DW, d = i - r * DW;
+        const int iy = r0 + r, ib = c0 - 3 + 4 * d;
+        const bool inside = (unsigned)iy < 300u && ib >= 0 && ib < 900;
+        pv[k] = *reinterpret_cast<const unsigned*>(src + (size_t)(inside ? iy : 0) * 900 + (inside ? ib : 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + k * 256 < NEL ? tid + k * 256 : NEL - 1;
+        const int r = i / DW, d = i - r * DW;
+        const int iy = r0 + r, ib0 = c0 - 3 + 4 * d;
+        const bool row_in = (unsigned)iy < 300u;
+        int ci = (ib0 + 900) % 3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ib = ib0 + e, pc = 4 * d + e - 3;
+            const bool inside = row_in && ib >= 0 && ib < 900;
+            const float v = (float)((pv[k] >> (8 * e)) & 0xFFu) * sc[ci] + sh[ci];
+            if (pc >= 0 && pc < PW) patch[r * PWP + pc] = inside ? v : 0.f;
+            ci = ci == 2 ? 0 : ci + 1;
+        }
+    }
+    int koff[5][8];
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = s5 * 32 + 8 * q + e, kc = k < 147 ? k : 0;
+            const int ky = kc / 21;
+            koff[s5][e] = ky * PWP + (kc - ky * 21);
+        }
+    const v4f b0 = *reinterpret_cast<const v4f*>(bias + 4 * q), b1 = *reinterpret_cast<const v4f*>(bias + 16 + 4 * q);
+    // this lane's pixel of each of the wave's tiles: patch offset of its top-left input sample
+    int poff[NMTW];
+#pragma unroll
+    for (int t = 0; t < NMTW; ++t) {
+        const int p = (wave + 4 * t) * 16 + j, pc = p < NPX ? p : NPX - 1;
+        const int cy = pc / CT, cx = pc - cy * CT;
+        poff[t] = (2 * cy) * PWP + (2 * cx) * 3;
+    }
+    __syncthreads();
+    v4f acc[NMTW][2];
+#pragma unroll
+    for (int t = 0; t < NMTW; ++t) { acc[t][0] = b0; acc[t][1] = b1; }
+    const unsigned short* wrow = w3 + (size_t)j * Kp + 8 * q;
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+        bf8 wf[2][3];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                wf[nt][pl] = *reinterpret_cast<const bf8*>(wrow + (size_t)pl * plane + (size_t)nt * 16 * Kp + s5 * 32);
+#pragma unroll
+        for (int t = 0; t < NMTW; ++t) {
+            if (wave + 4 * t >= NMT) continue;                             // wave-uniform (tile 19 does not exist)
+            const float* pp = &patch[poff[t]];
+            v4f lo, hi;
+            lo.x = pp[koff[s5][0]]; lo.y = pp[koff[s5][1]]; lo.z = pp[koff[s5][2]]; lo.w = pp[koff[s5][3]];
+            hi.x = pp[koff[s5][4]]; hi.y = pp[koff[s5][5]]; hi.z = pp[koff[s5][6]]; hi.w = pp[koff[s5][7]];
+            if constexpr (EXACT) {
+                bf8 x0;
+                x0[0] = (__bf16)lo.x; x0[1] = (__bf16)lo.y; x0[2] = (__bf16)lo.z; x0[3] = (__bf16)lo.w;
+                x0[4] = (__bf16)hi.x; x0[5] = (__bf16)hi.y; x0[6] = (__bf16)hi.z; x0[7] = (__bf16)hi.w;
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][pl], x0, acc[t][nt], 0, 0, 0);
+            } else {
+                bf8 x0, x1, x2;
+                split8(lo, hi, x0, x1, x2);
+                const bf8* xs[3] = {&x0, &x1, &x2};
+                const int wsel[6] = {2, 1, 0, 1, 0, 0}, xsel[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int p6 = 0; p6 < 6; ++p6)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][wsel[p6]], *xs[xsel[p6]], acc[t][nt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                                       // every gather of the patch is done: the tile takes its place
+#pragma unroll
+    for (int t = 0; t < NMTW; ++t) {
+        const int p = (wave + 4 * t) * 16 + j;
+        if (p < NPX) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                v4f v = acc[t][nt];
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<v4f*>(&ctile[p * CS + nt * 16 + 4 * q]) = v;
+            }
+        }
+    }
+    __syncthreads();
+    // pool: 64 pooled pixels x 8 channel quads = 512 items
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int item = tid + it * 256, cg = item & 7, pp = item >> 3, ppy = pp >> 3, ppx = pp & 7;
+        const int oy = py0 + ppy, ox = px0 + ppx;
+        v4f m = (v4f){-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int gy = 2 * oy + ky < 150 ? 2 * oy + ky : 149;          // conv row in the map, clamped (ceil mode)
+            const int cy = gy - ty0 < CT ? gy - ty0 : CT - 1;              // pooled pixels past the map: any tile row (not stored)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int gx = 2 * ox + kx < 150 ? 2 * ox + kx : 149;
+                const int cx = gx - tx0 < CT ? gx - tx0 : CT - 1;
+                const v4f v = *reinterpret_cast<const v4f*>(&ctile[((cy < 0 ? 0 : cy) * CT + (cx < 0 ? 0 : cx)) * CS + 4 * cg]);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        if (oy < 75 && ox < 75) *reinterpret_cast<v4f*>(y + (((size_t)n * 75 + oy) * 75 + ox) * 32 + 4 * cg) = m;
+    }
+}
+
+bool launch_ssd_conv1_pool(const uint8_t* img, const unsigned short* w3, int plane, int Kp, const float* b, float* y_pool, int n,
+                           const float in_scale[3], const float in_shift[3], bool relu, hipStream_t s) {
+    bool exact = true;
+    for (int c = 0; c < 3; ++c)
+        exact = exact && in_scale[c] == 1.f && in_shift[c] == (float)(int)in_shift[c] && in_shift[c] >= -255.f && in_shift[c] <= 0.f;
+    const dim3 grid((75 + 7) / 8, (75 + 7) / 8, n);
+    if (exact)
+        hipLaunchKernelGGL(ssd_conv1_pool_kernel<true>, grid, dim3(256), 0, s, img, w3, plane, Kp, b, y_pool, in_scale[0], in_scale[1],
+                           in_scale[2], in_shift[0], in_shift[1], in_shift[2], relu ? 1 : 0);
+    else
+        hipLaunchKernelGGL(ssd_conv1_pool_kernel<false>, grid, dim3(256), 0, s, img, w3, plane, Kp, b, y_pool, in_scale[0], in_scale[1],
+                           in_scale[2], in_shift[0], in_shift[1], in_shift[2], relu ? 1 : 0);
+    return true;
+}
+
 // ------------------------------------------------------------------- per-channel affine / add
 __global__ __launch_bounds__(256) void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* __restrict__ add,
