@@ -59,6 +59,9 @@ int dfd_max_batch(const dfd_handle* h);
 /* Tuning switches (results stay within the parity tolerances either way):
  *   "fuse_expand" (default 1, env DFD_FUSE_EXPAND): MBConv blocks 1-5 compute the 1x1 expand conv
  *   inside the depthwise kernel instead of writing the expanded tensor to HBM.
+ *   "fuse_late" (default 0, env DFD_FUSE_LATE; needs "fuse_expand"): blocks 6-10 and 12-15 (14 x 14 / 7 x 7 maps) do the
+ *   same with whole images per thread block (slightly faster per step, not the configuration the
+ *   depthwise roofline is quoted on).
  *   "fuse_stem" (default 1, env DFD_FUSE_STEM): the stem conv is computed inside block 0's depthwise
  *   kernel (the 112x112x32 stem activation stays in LDS).
  *   "split_gemm" (default 1, env DFD_SPLIT_GEMM): 1x1 convs (N >= 16) and the detector's k x k convs run on
