@@ -34,6 +34,9 @@ struct MtcnnState {
     const float *p2m = nullptr, *p3m = nullptr;   // P-Net conv2 / conv3 in the MFMA kernel's K layout ([16][96], [32][160])
     MtGemmConv r2g, r3g, o2g, o3g, o4g;
     DevBuf in, a0, a1, prob, reg, win, coef, bnd, tmp, face, d_lv, d_items, d_pre, bs, cand;
+    // box bookkeeping on the device (mtcnn_boxes.hip): crop / level tables, counts + prefix arrays + meta words, segmented and
+    // compact row / window arenas, per-crop result rows, rows of crop 0 for the parity taps
+    DevBuf d_cg, d_lg, cnt, rows_a, wins_a, rows_b, wins_b, res, taprows;
 };
 
 void mtcnn_destroy(dfd_handle* h) {
@@ -327,17 +330,22 @@ struct Cascade {
 
     struct Level { int crop; double scale; int sh, sw, oh, ow; long long cell_off; };
 
-    // ---- stage 1: P-Net over all pyramid levels of all crops -> per-crop candidate boxes (after regression + rerec)
-    int stage1(std::vector<std::vector<Box>>* out) {
+    bool stage1_done = false;              // the P-Net launches of this step are already queued (device path fell back)
+    std::vector<Level> levels;             // pyramid levels of all crops (stage1_gpu)
+    long long cells = 0;                   // P-Net output cells of all levels
+    std::vector<float> tap_prob, tap_reg;  // whole P-Net maps (parity taps only)
+
+    // ---- stage 1, device half: P-Net over all pyramid levels of all crops -> prob / reg maps + candidate list in HBM
+    int stage1_gpu() {
         hipStream_t s = h->stream;
         int rc;
-        std::vector<Level> levels;
         std::vector<MtLevel> lv;
         // per launch: items + running totals of output elements (arena offsets are the same running totals):
         //   pyramid (resize) -> pooled conv1 map (conv1 + PReLU + pool) -> conv2 map -> conv3 cells (heads only)
         std::vector<MtItem> it_f, it_c2, it_c3;
         std::vector<long long> pre_in{0}, pre_p{0}, pre_c2{0}, pre_c3{0};
-        long long cells = 0;
+        levels.clear();
+        cells = 0;
         for (int c = 0; c < n; ++c) {
             const int hh = imgs[c].h, ww = imgs[c].w;
             const double m = 12.0 / 20.0;                         // scale pyramid in double, as the package's Python floats
@@ -361,10 +369,7 @@ struct Cascade {
             }
         }
         mark("s1 host: pyramid tables");
-        out->assign(n, {});
         const int nl = (int)levels.size();
-        std::vector<float> prob, reg;
-        std::vector<MtCand> cands;
         if (nl) {
             // descriptors through the mailbox (copied before the call returns)
             if ((rc = upload(&S->d_lv, lv))) return rc;
@@ -415,6 +420,39 @@ struct Cascade {
             }
             if (!ok) return fail(h, DFD_ERR_STATE, "mtcnn: no P-Net kernel instance for this layer shape");
             DFD_HIP_TRY(h, hipGetLastError());
+            if (tap_name) {                                   // parity taps read whole maps
+                tap_prob.resize(cells);
+                DFD_HIP_TRY(h, hipMemcpyAsync(tap_prob.data(), S->prob.p, cells * 4, hipMemcpyDeviceToHost, s));
+                if ((rc = download(S->reg.p, (size_t)cells * 4, &tap_reg))) return rc;
+            }
+        }
+        int level_in_crop = 0, prev_crop = -1;
+        for (const Level& L : levels) {                      // parity taps (crop 0 only)
+            level_in_crop = L.crop == prev_crop ? level_in_crop + 1 : 0;
+            prev_crop = L.crop;
+            if (L.crop != 0 || !tap_name) continue;
+            const float* P = tap_prob.data() + L.cell_off;
+            const float* R = tap_reg.data() + L.cell_off * 4;
+            if (want("pnet.prob." + std::to_string(level_in_crop))) {
+                tap->assign(P, P + (size_t)std::max(L.oh, 0) * std::max(L.ow, 0));
+                tap_dims[0] = L.oh; tap_dims[1] = L.ow; tap_dims[2] = 1;
+            }
+            if (want("pnet.reg." + std::to_string(level_in_crop))) {
+                tap->assign(R, R + (size_t)std::max(L.oh, 0) * std::max(L.ow, 0) * 4);
+                tap_dims[0] = L.oh; tap_dims[1] = L.ow; tap_dims[2] = 4;
+            }
+        }
+        mark("s1 gpu: P-Net launches");
+        return DFD_OK;
+    }
+
+    // ---- stage 1, host half (host path): candidates -> per-crop boxes after NMS, regression and rerec
+    int stage1_host(std::vector<std::vector<Box>>* out) {
+        out->assign(n, {});
+        std::vector<MtCand> cands;
+        if (!levels.empty()) {
+            const unsigned* d_count = (const unsigned*)S->cand.p;
+            const MtCand* d_cand = (const MtCand*)((const char*)S->cand.p + 16);
             // the candidates (cells at or above the threshold), not the maps: count first, then that many records, both
             // through the mailbox; the atomic append order is restored to (level, y, x) by sorting on the cell
             const unsigned* pc = (const unsigned*)mailbox_d2h(h, d_count, 4);
@@ -428,31 +466,10 @@ struct Cascade {
                 cands.assign(pr, pr + nc);
             }
             std::sort(cands.begin(), cands.end(), [](const MtCand& a, const MtCand& b) { return a.cell < b.cell; });
-            if (tap_name) {                                   // parity taps read whole maps
-                prob.resize(cells);
-                DFD_HIP_TRY(h, hipMemcpyAsync(prob.data(), S->prob.p, cells * 4, hipMemcpyDeviceToHost, s));
-                if ((rc = download(S->reg.p, (size_t)cells * 4, &reg))) return rc;
-            }
         }
-        mark("s1 gpu: P-Net + download");
+        mark("s1 host: candidate download");
         // host: generateBoundingBox per level, per-scale NMS, cross-scale NMS, regression, rerec - per crop
         std::vector<std::vector<Box>> all(n);
-        int level_in_crop = 0, prev_crop = -1;
-        for (const Level& L : levels) {                      // parity taps (crop 0 only)
-            level_in_crop = L.crop == prev_crop ? level_in_crop + 1 : 0;
-            prev_crop = L.crop;
-            if (L.crop != 0 || !tap_name) continue;
-            const float* P = prob.data() + L.cell_off;
-            const float* R = reg.data() + L.cell_off * 4;
-            if (want("pnet.prob." + std::to_string(level_in_crop))) {
-                tap->assign(P, P + (size_t)std::max(L.oh, 0) * std::max(L.ow, 0));
-                tap_dims[0] = L.oh; tap_dims[1] = L.ow; tap_dims[2] = 1;
-            }
-            if (want("pnet.reg." + std::to_string(level_in_crop))) {
-                tap->assign(R, R + (size_t)std::max(L.oh, 0) * std::max(L.ow, 0) * 4);
-                tap_dims[0] = L.oh; tap_dims[1] = L.ow; tap_dims[2] = 4;
-            }
-        }
         std::vector<std::vector<Box>> kept(levels.size());
         // first candidate of each level in the cell-sorted list (levels own consecutive cell ranges)
         std::vector<size_t> lfirst(levels.size() + 1, cands.size());
@@ -502,26 +519,25 @@ struct Cascade {
         return DFD_OK;
     }
 
-    // R-Net (24) / O-Net (48) over `wins` (at most kChunk per launch set): face probability [n], regression [n][4]
-    int refine(bool onet, const std::vector<MtSrcWindow>& wins, std::vector<float>* prob, std::vector<float>* reg) {
+    // R-Net (24) / O-Net (48) over `total` windows on the device (at most kChunk per launch set): face probability
+    // S->prob [total], regression S->reg [total][4]; nothing is read back
+    int refine_gpu(bool onet, const MtSrcWindow* wd_all, int total) {
         hipStream_t s = h->stream;
-        const int total = (int)wins.size(), sz = onet ? 48 : 24;
+        const int sz = onet ? 48 : 24;
         constexpr int kChunk = 4096;
-        prob->clear();
-        reg->clear();
         int rc;
-        if ((rc = upload(&S->win, wins))) return rc;
+        const int mmax = std::min(kChunk, total);
+        const size_t big = (size_t)mmax * (sz - 2) * (sz - 2) * 32 * 4;
+        if ((rc = ensure(h, &S->in, (size_t)mmax * sz * sz * 3 * 4))) return rc;
+        if ((rc = ensure(h, &S->a0, big))) return rc;
+        if ((rc = ensure(h, &S->a1, big))) return rc;
+        if ((rc = ensure(h, &S->prob, (size_t)total * 4))) return rc;
+        if ((rc = ensure(h, &S->reg, (size_t)total * 4 * 4))) return rc;
         for (int start = 0; start < total; start += kChunk) {
             const int m = std::min(kChunk, total - start);
-            const MtSrcWindow* wd = (const MtSrcWindow*)S->win.p + start;
-            const size_t big = (size_t)m * (sz - 2) * (sz - 2) * 32 * 4;
-            if ((rc = ensure(h, &S->in, (size_t)m * sz * sz * 3 * 4))) return rc;
-            if ((rc = ensure(h, &S->a0, big))) return rc;
-            if ((rc = ensure(h, &S->a1, big))) return rc;
-            if ((rc = ensure(h, &S->prob, (size_t)m * 4))) return rc;
-            if ((rc = ensure(h, &S->reg, (size_t)m * 4 * 4))) return rc;
-            wd = (const MtSrcWindow*)S->win.p + start;      // (ensure never moves S->win)
+            const MtSrcWindow* wd = wd_all + start;                  // (the ensure calls above never move the window list)
             float *in = (float*)S->in.p, *a0 = (float*)S->a0.p, *a1 = (float*)S->a1.p;
+            float *pr = (float*)S->prob.p + start, *rg = (float*)S->reg.p + (size_t)start * 4;
             launch_mt_area_resize_multi(wd, m, sz, sz, in, s);
             if (!onet) {
                 // conv1 (22, 32 ch = 28 + 4 zero) + PReLU + pool (11) in one launch
@@ -531,8 +547,8 @@ struct Cascade {
                 if ((rc = gemm_conv_prelu(h, S->r3g, a1, a0, m, 4, 4))) return rc;                  // 3 -> [m][3][3][64]
                 if ((rc = gemm_dense_prelu(h, S->r4, a0, a1, m))) return rc;                        // 576 -> 128
                 launch_mt_dense(a1, S->r51.w, S->r51.b, nullptr, a0, m, 128, 2, s);
-                launch_mt_softmax_face(a0, (float*)S->prob.p, m, s);
-                launch_mt_dense(a1, S->r52.w, S->r52.b, nullptr, (float*)S->reg.p, m, 128, 4, s);
+                launch_mt_softmax_face(a0, pr, m, s);
+                launch_mt_dense(a1, S->r52.w, S->r52.b, nullptr, rg, m, 128, 4, s);
             } else {
                 // conv1 (46) + PReLU + pool (23) in one launch
                 if (!launch_mt_conv1_pool(in, S->o1.w, S->o1.b, S->o1.a, a1, m, 48, 48, 32, s)) return fail(h, DFD_ERR_STATE, "mtcnn: conv1+pool shape");
@@ -543,19 +559,30 @@ struct Cascade {
                 if ((rc = gemm_conv_prelu(h, S->o4g, a1, a0, m, 4, 4))) return rc;                  // 3 -> [m][3][3][128]
                 if ((rc = gemm_dense_prelu(h, S->o5, a0, a1, m))) return rc;                        // 1152 -> 256
                 launch_mt_dense(a1, S->o61.w, S->o61.b, nullptr, a0, m, 256, 2, s);
-                launch_mt_softmax_face(a0, (float*)S->prob.p, m, s);
-                launch_mt_dense(a1, S->o62.w, S->o62.b, nullptr, (float*)S->reg.p, m, 256, 4, s);
+                launch_mt_softmax_face(a0, pr, m, s);
+                launch_mt_dense(a1, S->o62.w, S->o62.b, nullptr, rg, m, 256, 4, s);
                 // dense6_3 (landmarks) does not influence the selected crop: not evaluated
             }
             DFD_HIP_TRY(h, hipGetLastError());
-            const float* pp = (const float*)mailbox_d2h(h, S->prob.p, (size_t)m * 4);
-            const float* rr = (const float*)mailbox_d2h(h, S->reg.p, (size_t)m * 16);
-            if (!pp || !rr) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
-            DFD_HIP_TRY(h, hipGetLastError());
-            DFD_HIP_TRY(h, stream_sync(h));
-            prob->insert(prob->end(), pp, pp + m);
-            reg->insert(reg->end(), rr, rr + (size_t)m * 4);
         }
+        return DFD_OK;
+    }
+
+    // host path: upload the windows, run the network, read probability [n] and regression [n][4] back
+    int refine(bool onet, const std::vector<MtSrcWindow>& wins, std::vector<float>* prob, std::vector<float>* reg) {
+        const int total = (int)wins.size();
+        prob->clear();
+        reg->clear();
+        int rc;
+        if ((rc = upload(&S->win, wins))) return rc;
+        if ((rc = refine_gpu(onet, (const MtSrcWindow*)S->win.p, total))) return rc;
+        const float* pp = (const float*)mailbox_d2h(h, S->prob.p, (size_t)total * 4);
+        const float* rr = (const float*)mailbox_d2h(h, S->reg.p, (size_t)total * 16);
+        if (!pp || !rr) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
+        DFD_HIP_TRY(h, hipGetLastError());
+        DFD_HIP_TRY(h, stream_sync(h));
+        prob->assign(pp, pp + total);
+        reg->assign(rr, rr + (size_t)total * 4);
         return DFD_OK;
     }
 
@@ -566,7 +593,8 @@ struct Cascade {
         const auto t0 = std::chrono::steady_clock::now();
         auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
         std::vector<std::vector<Box>> boxes;
-        if ((rc = stage1(&boxes))) return rc;
+        if (!stage1_done && (rc = stage1_gpu())) return rc;
+        if ((rc = stage1_host(&boxes))) return rc;
         if (verbose) {
             size_t tot = 0;
             for (auto& b : boxes) tot += b.size();
@@ -631,6 +659,171 @@ struct Cascade {
             }
         }
         *out = boxes;
+        return DFD_OK;
+    }
+
+    // Pillow's kernel size for a 160-wide axis read from in_size pixels (pil_coeffs)
+    static int pil_ksize(int in_size) {
+        const double scale = (double)in_size / 160;
+        return (int)std::ceil(scale < 1.0 ? 1.0 : scale) * 2 + 1;
+    }
+
+    // The whole step with the box bookkeeping on the device (mtcnn_boxes.hip): per stage one block per crop does what the
+    // host path does between the networks; the host reads back the window count of all crops after stages 1 and 2
+    // (launch sizes of the next network) and one result row per crop at the end - three stream waits, no box on the
+    // host.  *done = false: a crop exceeded the blocks' capacity (overflow flag) - nothing was written to the outputs
+    // and the caller runs the host path on the P-Net results that are already in HBM.
+    int run_device(uint8_t* faces_out, float* boxes_out, char* found, bool* done) {
+        hipStream_t s = h->stream;
+        int rc;
+        *done = false;
+        static const bool verbose = getenv("DFD_MT_VERBOSE") != nullptr;
+        if ((rc = stage1_gpu())) return rc;
+        stage1_done = true;
+        // crop / level tables
+        std::vector<MtCropGeo> cg(n);
+        std::vector<MtLevelGeo> lg(levels.size());
+        long long seg = 0, tmp_bytes = 0, tab = 0;
+        {
+            size_t li = 0;
+            for (int c = 0; c < n; ++c) {
+                MtCropGeo& g = cg[c];
+                g = MtCropGeo{imgs[c].src, (long long)imgs[c].stride, imgs[c].h, imgs[c].w, (int)li, 0, seg, tmp_bytes, (int)tab, 0};
+                long long crop_cells = 0;
+                while (li < levels.size() && levels[li].crop == c) {
+                    const Level& L = levels[li];
+                    if ((long long)std::max(L.oh, 0) * std::max(L.ow, 0) >= (1ll << 27)) return DFD_OK;       // cell index field: host path
+                    lg[li] = MtLevelGeo{L.cell_off, L.oh, L.ow, (float)L.scale, 0};
+                    crop_cells += (long long)std::max(L.oh, 0) * std::max(L.ow, 0);
+                    ++li;
+                    ++g.nlevels;
+                }
+                if (g.nlevels > 31) return DFD_OK;
+                seg += std::min<long long>(crop_cells, kMtCap2);
+                tmp_bytes += ((long long)imgs[c].h * 160 * 3 + 255) & ~255ll;
+                tab += 160ll * pil_ksize(imgs[c].w) + 320 + 160ll * pil_ksize(imgs[c].h) + 320;
+                if (tab > (1ll << 30) || seg > (1ll << 30)) return DFD_OK;
+            }
+        }
+        if ((rc = upload(&S->d_cg, cg))) return rc;
+        if ((rc = upload(&S->d_lg, lg))) return rc;
+        const size_t segn = (size_t)std::max<long long>(seg, 1);
+        if ((rc = ensure(h, &S->cnt, ((size_t)n * 3 + 2 + 4) * 4))) return rc;
+        if ((rc = ensure(h, &S->rows_a, segn * sizeof(MtRow)))) return rc;
+        if ((rc = ensure(h, &S->wins_a, segn * sizeof(MtSrcWindow)))) return rc;
+        if ((rc = ensure(h, &S->rows_b, segn * sizeof(MtRow)))) return rc;
+        if ((rc = ensure(h, &S->wins_b, segn * sizeof(MtSrcWindow)))) return rc;
+        if ((rc = ensure(h, &S->res, (size_t)n * 8 * 4))) return rc;
+        if ((rc = ensure(h, &S->coef, (size_t)std::max<long long>(tab, 4) * 4))) return rc;
+        if ((rc = ensure(h, &S->bnd, (size_t)n * sizeof(MtFaceJob)))) return rc;
+        if ((rc = ensure(h, &S->tmp, (size_t)std::max<long long>(tmp_bytes, 16)))) return rc;
+        if (tap_name && (rc = ensure(h, &S->taprows, (size_t)kMtCap1 * sizeof(MtRow)))) return rc;
+        int* counts = (int*)S->cnt.p;
+        int *first_a = counts + n, *first_b = first_a + n + 1, *meta = first_b + n + 1;
+        const MtCropGeo* dcg = (const MtCropGeo*)S->d_cg.p;
+        MtRow *rows_a = (MtRow*)S->rows_a.p, *rows_b = (MtRow*)S->rows_b.p, *taprows = tap_name ? (MtRow*)S->taprows.p : nullptr;
+        MtSrcWindow *wins_a = (MtSrcWindow*)S->wins_a.p, *wins_b = (MtSrcWindow*)S->wins_b.p;
+        DFD_HIP_TRY(h, hipMemsetAsync(S->cnt.p, 0, ((size_t)n * 3 + 2 + 4) * 4, s));
+        // rows of crop 0 after a stage (parity taps): meta[2] of them at taprows
+        auto tap_stage = [&](const char* name, const int* meta_host) -> int {
+            if (!want(name)) return DFD_OK;
+            const int k = std::min(meta_host[2], kMtCap1);
+            std::vector<float> rows;
+            int rc2 = download(S->taprows.p, (size_t)k * 5, &rows);
+            if (rc2) return rc2;
+            *tap = rows;
+            tap_dims[0] = k; tap_dims[1] = 5; tap_dims[2] = 1;
+            return DFD_OK;
+        };
+        // first_x[0 .. cnt) of crop 0: the network's outputs of its windows (parity taps)
+        auto tap_net = [&](const char* pname, const char* rname, int cnt0) -> int {
+            if (cnt0 <= 0) return DFD_OK;
+            if (want(pname)) {
+                int rc2 = download(S->prob.p, (size_t)cnt0, tap);
+                if (rc2) return rc2;
+                tap_dims[0] = cnt0; tap_dims[1] = 1; tap_dims[2] = 1;
+            }
+            if (want(rname)) {
+                int rc2 = download(S->reg.p, (size_t)cnt0 * 4, tap);
+                if (rc2) return rc2;
+                tap_dims[0] = cnt0; tap_dims[1] = 4; tap_dims[2] = 1;
+            }
+            return DFD_OK;
+        };
+        // the count words after a stage: {windows of all crops, overflow, rows of crop 0} + windows of crop 0 (first[1])
+        auto read_meta = [&](const int* first, int out[4]) -> int {
+            const int* pm = (const int*)mailbox_d2h(h, meta, 12);
+            const int* pf = (const int*)mailbox_d2h(h, first + 1, 4);
+            if (!pm || !pf) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
+            DFD_HIP_TRY(h, hipGetLastError());
+            DFD_HIP_TRY(h, stream_sync(h));
+            out[0] = pm[0]; out[1] = pm[1]; out[2] = pm[2]; out[3] = pf[0];
+            return DFD_OK;
+        };
+        int mh[4] = {0, 0, 0, 0};
+        int m2 = 0, m3 = 0;
+        if (!levels.empty()) {
+            launch_mt_stage1_boxes(dcg, (const MtLevelGeo*)S->d_lg.p, n, (const float*)S->prob.p, (const float*)S->reg.p, 0.6f,
+                                   rows_a, wins_a, counts, meta, taprows, s);
+            launch_mt_compact(counts, n, dcg, nullptr, rows_a, wins_a, rows_b, wins_b, first_a, meta, s);
+            if ((rc = read_meta(first_a, mh))) return rc;
+            mark("s1 gpu: boxes + count");
+            if (mh[1]) {
+                if (verbose) fprintf(stderr, "[dfd] mtcnn: a crop exceeds the device box capacity - host path\n");
+                return DFD_OK;
+            }
+            if ((rc = tap_stage("stage1", mh))) return rc;
+            m2 = mh[0];
+        }
+        else if (want("stage1")) {
+            tap->clear();
+            tap_dims[0] = 0; tap_dims[1] = 5; tap_dims[2] = 1;
+        }
+        if (verbose) fprintf(stderr, "[dfd] mtcnn %d crops (device boxes): stage 1 -> %d windows\n", n, m2);
+        if (m2 > 0) {
+            if ((rc = refine_gpu(false, wins_b, m2))) return rc;
+            if ((rc = tap_net("rnet.prob", "rnet.reg", mh[3]))) return rc;
+            launch_mt_refine_boxes(2, dcg, first_a, n, rows_b, (const float*)S->prob.p, (const float*)S->reg.p, 0.7f, 0.7f, rows_a, wins_a,
+                                   counts, nullptr, nullptr, nullptr, taprows, meta, s);
+            launch_mt_compact(counts, n, dcg, first_a, rows_a, wins_a, rows_b, wins_b, first_b, meta, s);
+            if ((rc = read_meta(first_b, mh))) return rc;
+            mark("s2 gpu: R-Net + boxes + count");
+            if ((rc = tap_stage("stage2", mh))) return rc;
+            m3 = mh[0];
+            if (verbose) fprintf(stderr, "[dfd] mtcnn stage 2 (device boxes): %d windows -> %d\n", m2, m3);
+        } else if (want("stage2")) {
+            tap->clear();
+            tap_dims[0] = 0; tap_dims[1] = 5; tap_dims[2] = 1;
+        }
+        if (m3 > 0) {
+            if ((rc = refine_gpu(true, wins_b, m3))) return rc;
+            if ((rc = tap_net("onet.prob", "onet.reg", mh[3]))) return rc;
+        }
+        // (with no window left first_b is all zero: every crop gets a zero-filled face and found = 0)
+        launch_mt_refine_boxes(3, dcg, first_b, n, rows_b, (const float*)S->prob.p, (const float*)S->reg.p, 0.7f, 0.7f, nullptr, nullptr,
+                               nullptr, (MtFaceJob*)S->bnd.p, (float*)S->res.p, (int*)S->coef.p, taprows, meta, s);
+        launch_mt_extract_faces((const MtFaceJob*)S->bnd.p, n, (const int*)S->coef.p, faces_out, (uint8_t*)S->tmp.p, s);
+        DFD_HIP_TRY(h, hipGetLastError());
+        const float* pr = (const float*)mailbox_d2h(h, S->res.p, (size_t)n * 8 * 4);
+        const int* pm = (const int*)mailbox_d2h(h, meta, 12);
+        if (!pr || !pm) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
+        DFD_HIP_TRY(h, stream_sync(h));
+        mark("s3 gpu: O-Net + boxes + extract");
+        int m3h[3] = {pm[0], pm[1], pm[2]};
+        for (int i = 0; i < n; ++i) {
+            const float* r = pr + (size_t)i * 8;
+            found[i] = r[0] != 0.f;
+            if (boxes_out && r[1] != 0.f) memcpy(boxes_out + 5 * i, r + 2, 5 * sizeof(float));
+        }
+        if (want("stage3")) {
+            if (m3 > 0) {
+                if ((rc = tap_stage("stage3", m3h))) return rc;
+            } else {
+                tap->clear();
+                tap_dims[0] = 0; tap_dims[1] = 5; tap_dims[2] = 1;
+            }
+        }
+        *done = true;
         return DFD_OK;
     }
 };
@@ -709,8 +902,16 @@ int mtcnn_align_batch_device(dfd_handle* h, const MtImage* imgs, int n, uint8_t*
         if (imgs[i].h <= 0 || imgs[i].w <= 0) return fail(h, DFD_ERR_ARG, "mtcnn: empty image");
     Cascade c{h, S, imgs, n, tap_name, tap, tap_dims};
     std::vector<std::vector<Box>> boxes;
-    int rc = c.run(&boxes);
-    if (rc) return rc;
+    int rc;
+    // box bookkeeping on the device unless DFD_MT_DEVICE_BOXES=0 (read per call: the tests switch it); a step that does
+    // not fit the device blocks falls through to the host path with its P-Net results already in HBM
+    const char* dv = getenv("DFD_MT_DEVICE_BOXES");
+    if (!(dv && atoi(dv) == 0)) {
+        bool done = false;
+        if ((rc = c.run_device(faces_out, boxes_out, found, &done))) return rc;
+        if (done) return DFD_OK;
+    }
+    if ((rc = c.run(&boxes))) return rc;
     hipStream_t s = h->stream;
     // selection + extract_face geometry on the host; all resize coefficient tables and the job list in one upload each,
     // all crops resampled by two launches

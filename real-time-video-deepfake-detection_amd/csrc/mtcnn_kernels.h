@@ -60,4 +60,23 @@ struct MtFaceJob { const uint8_t* src; long long stride; int x1, y1, cw, ch, kx,
 void launch_mt_extract_faces(const MtFaceJob* jobs_dev, int n, const int* tables_dev, uint8_t* faces, uint8_t* tmp, hipStream_t s);
 void launch_mt_face_chw(const uint8_t* bgr, float* out, int hw, hipStream_t s);
 
+// ---- box bookkeeping on the device (mtcnn_boxes.hip): one block per crop and stage
+constexpr int kMtCap1 = 8192;    // P-Net candidates of one crop the stage-1 block holds
+constexpr int kMtCap2 = 4096;    // windows of one crop the stage-2 / stage-3 blocks hold
+// a crop of the step: image, its run of pyramid levels in the level table, offset of its segment in the stage-1 output
+// arenas, offset (ints) of its resize tables, offset (bytes) of its horizontal-pass intermediate
+struct MtCropGeo { const uint8_t* src; long long stride; int h, w, level0, nlevels; long long seg_off; long long tmp_off; int tab_off, pad; };
+struct MtLevelGeo { long long cell_off; int oh, ow; float scale; int pad; };      // P-Net output grid of a level, first cell, (float) scale
+struct MtRow { float x1, y1, x2, y2, score; };
+// meta[0] = windows of all crops (compact kernel), meta[1] = overflow flag (zeroed by the caller), meta[2] = rows of crop 0
+void launch_mt_stage1_boxes(const MtCropGeo* crops, const MtLevelGeo* levels, int n, const float* prob, const float* reg, float thr,
+                            MtRow* rows_seg, MtSrcWindow* wins_seg, int* counts, int* meta, MtRow* tap_rows, hipStream_t s);
+void launch_mt_compact(const int* counts, int n, const MtCropGeo* crops, const int* seg_first, const MtRow* rows_seg,
+                       const MtSrcWindow* wins_seg, MtRow* rows_out, MtSrcWindow* wins_out, int* first_out, int* meta, hipStream_t s);
+// stage 2: R-Net prob / reg of the windows first[c] .. first[c + 1] -> rows / windows at first[c] of the segment arenas, counts;
+// stage 3: O-Net prob / reg -> jobs[c], results[c][8] = {found, has box, x1, y1, x2, y2, prob, 0}, resize tables
+void launch_mt_refine_boxes(int stage, const MtCropGeo* crops, const int* first, int n, const MtRow* rows_in, const float* prob,
+                            const float* reg, float thr_p, float thr_nms, MtRow* rows_seg, MtSrcWindow* wins_seg, int* counts,
+                            MtFaceJob* jobs, float* results, int* tables, MtRow* tap_rows, int* meta, hipStream_t s);
+
 }  // namespace dfd

@@ -139,3 +139,54 @@ def test_threaded_box_logic_equals_serial(pkg, mt_handle, monkeypatch):
     serial = mt_handle.classify_crops(frame, boxes, apply_clahe=True).reshape(-1)
     assert np.array_equal(threaded, serial, equal_nan=True), (threaded, serial)
     assert not np.isnan(threaded).all()
+
+
+def test_device_box_logic_equals_host_path(pkg, mt_handle, monkeypatch):
+    """The box bookkeeping between the networks runs on the device (mtcnn_boxes.hip: one block per crop and stage);
+    DFD_MT_DEVICE_BOXES=0 keeps it on the library's host side.  Same arithmetic in the same order: every stage's rows,
+    the selected box, the 160x160 crop and the logits are IDENTICAL, on the dense funnel (hundreds to thousands of
+    candidates per crop, ties included) and on a crop without any level."""
+    rs = np.random.RandomState(5)
+    for hh, ww in ((150, 170), (96, 210), (230, 190), (12, 40)):
+        bgr = _bgr(mt_images.textured(hh, ww, int(rs.randint(1 << 30))))
+        got = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("DFD_MT_DEVICE_BOXES", flag)
+            rows = []
+            if min(hh, ww) >= 20:
+                for st, net in (("stage1", "rnet"), ("stage2", "onet"), ("stage3", None)):
+                    rows.append(mt_handle.mtcnn_tap(bgr, st))
+                    if net and len(rows[-1]):
+                        rows += [mt_handle.mtcnn_tap(bgr, net + ".prob"), mt_handle.mtcnn_tap(bgr, net + ".reg")]
+            got[flag] = (rows, mt_handle.mtcnn_align(bgr))
+        (rd, (fd, bd)), (rh, (fh, bh)) = got["1"], got["0"]
+        assert len(rd) == len(rh)
+        for a, b in zip(rd, rh):
+            assert a.shape == b.shape and np.array_equal(a, b), (hh, ww, a.shape, b.shape)
+        if min(hh, ww) >= 20:
+            assert len(rd[0]) > 20, "the dense cascade should hand many boxes to R-Net"
+        assert (fd is None) == (fh is None)
+        if fd is not None:
+            assert np.array_equal(bd, bh) and np.array_equal(fd, fh)
+    frame = np.random.default_rng(7).integers(50, 200, (2, 1080, 1920, 3), dtype=np.uint8)[0]
+    boxes = np.array([[200, 150, 120, 140], [900, 300, 156, 156], [1400, 500, 100, 180], [600, 700, 224, 124]], np.int32)
+    monkeypatch.setenv("DFD_MT_DEVICE_BOXES", "1")
+    dev = mt_handle.classify_crops(frame, boxes, apply_clahe=True).reshape(-1)
+    monkeypatch.setenv("DFD_MT_DEVICE_BOXES", "0")
+    host = mt_handle.classify_crops(frame, boxes, apply_clahe=True).reshape(-1)
+    assert np.array_equal(dev, host, equal_nan=True), (dev, host)
+    assert not np.isnan(dev).all()
+
+
+def test_box_capacity_overflow_falls_back_to_the_host_path(pkg, mt_handle, monkeypatch):
+    """A crop with more P-Net candidates than a device block holds (the random-init cascade on a 700 x 900 crop: ~20 %
+    of ~100k cells) raises the overflow flag; the step then runs on the host path - same result as with the device
+    path switched off."""
+    bgr = _bgr(mt_images.textured(700, 900, 3))
+    monkeypatch.setenv("DFD_MT_DEVICE_BOXES", "1")
+    fd, bd = mt_handle.mtcnn_align(bgr)
+    monkeypatch.setenv("DFD_MT_DEVICE_BOXES", "0")
+    fh, bh = mt_handle.mtcnn_align(bgr)
+    assert (fd is None) == (fh is None)
+    if fd is not None:
+        assert np.array_equal(bd, bh) and np.array_equal(fd, fh)
