@@ -112,6 +112,12 @@ void destroy_impl(dfd_handle* h) {
         if (h->slot_free[i]) hipEventDestroy(h->slot_free[i]);
     }
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
+    if (h->aux_stream) {
+        hipStreamSynchronize(h->aux_stream);
+        hipStreamDestroy(h->aux_stream);
+        hipEventDestroy(h->aux_go);
+        hipEventDestroy(h->aux_done);
+    }
     if (h->jpeg_host) hipHostFree(h->jpeg_host);
     if (h->mailbox) hipHostFree(h->mailbox);
     for (char* p : h->mailbox_old) hipHostFree(p);
@@ -159,6 +165,7 @@ int dfd_set_option(dfd_handle* h, const char* name, int value) {
     if (strcmp(name, "fuse_stem") == 0) { h->fuse_stem = value != 0; return DFD_OK; }
     if (strcmp(name, "split_gemm") == 0) { h->split_gemm = value != 0; return DFD_OK; }
     if (strcmp(name, "mtcnn") == 0) { h->use_mtcnn = value != 0; return DFD_OK; }
+    if (strcmp(name, "overlap_forensics") == 0) { h->overlap_forensics = value != 0; return DFD_OK; }
     if (strcmp(name, "bf16_activations") == 0) { h->act_bf16 = value != 0; return DFD_OK; }
     if (strcmp(name, "bf16_weight_planes") == 0) {
         if (value != 1 && value != 3) return fail(h, DFD_ERR_ARG, "bf16_weight_planes must be 1 or 3");

@@ -91,6 +91,10 @@ struct dfd_handle {
     size_t mailbox_cap = 0, mailbox_head = 0, mailbox_lap_end = 0;
     size_t mailbox_live = 0, mailbox_live_prev = 0;   // bytes handed out since the last / between the last two stream_sync
     std::vector<char*> mailbox_old, mailbox_old_prev; // replaced blocks: freed two stream_syncs after their retirement
+    // second compute stream: the forensic launch set of a batch call runs beside detector / classifier
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_go = nullptr, aux_done = nullptr;
+    bool overlap_forensics = true;
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done[2] = {nullptr, nullptr}, slot_free[2] = {nullptr, nullptr};
     dfd::DevBuf stage[2];
@@ -162,6 +166,7 @@ int ensure(dfd_handle* h, DevBuf* b, size_t bytes);
 hipError_t stream_sync(dfd_handle* h);
 int mailbox_h2d(dfd_handle* h, void* dst_dev, const void* src, size_t bytes);
 const void* mailbox_d2h(dfd_handle* h, const void* src_dev, size_t bytes);
+void copy_kernel_async(void* dst, const void* src, size_t bytes, hipStream_t s);
 // builds h->color from the "lut.*" tensors of the blob (imgproc_api.hip)
 int color_tables_init(dfd_handle* h);
 
@@ -190,6 +195,11 @@ int jpeg_decode_batch_to(dfd_handle* h, const uint8_t* const* jpegs, const size_
 // stateless six-signal forensic probability of `n` device frames (temporal signal = first-frame value 0)
 int forensics_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes,
                         double* prob_out, double* scores_out);
+// the same in two halves: begin enqueues the launch set on the handle's second stream (ordered after what the main
+// stream holds at that moment) and returns; end waits for it and scores on the host.  Nothing else may use the
+// forensic work buffers in between.
+int forensics_batch_begin(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes);
+int forensics_batch_end(dfd_handle* h, int n, double* prob_out, double* scores_out);
 
 // mtcnn_api.hip: MTCNN.forward on a BGR image in HBM -> selected box (x1,y1,x2,y2,prob), *found, and the
 // 160x160 BGR u8 crop at mtcnn_face_dev(h).  tap_* are for parity tests (null otherwise).

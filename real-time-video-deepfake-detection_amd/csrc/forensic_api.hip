@@ -25,9 +25,12 @@ struct ForensicState {
     float2* twiddle = nullptr;
     double* diff_part = nullptr;   // 256 partial sums
     DevBuf pair_idx, pair_part;    // dfd_forensic_signals_device: predecessor indices, [n][256] partial sums
+    double* host_res = nullptr;    // pinned: statistics of a batch that ran on the second stream (forensics_batch_begin)
+    size_t host_res_cap = 0;
 };
 
 void forensic_destroy(dfd_handle* h) {
+    if (h->forensic && h->forensic->host_res) hipHostFree(h->forensic->host_res);
     delete h->forensic;
     h->forensic = nullptr;
 }
@@ -294,6 +297,56 @@ int forensics_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh,
     if (!st || !noise || !ela) return fail(h, DFD_ERR_HIP, "forensics: mailbox allocation failed");
     DFD_HIP_TRY(h, stream_sync(h));
     DFD_HIP_TRY(h, hipGetLastError());
+    const double w[6] = {0.25, 0.20, 0.20, 0.15, 0.10, 0.10};
+    for (int f = 0; f < n; ++f) {
+        double sc[6], ex[10];
+        static_scores(&st[(size_t)f * FORENSIC_STATS], &noise[(size_t)f * 64], &ela[(size_t)f * 64], true, sc, ex);
+        double comb = 0.0;
+        for (int i = 0; i < 6; ++i) comb += sc[i] * w[i];
+        prob_out[f] = clip01(comb);
+        if (scores_out)
+            for (int i = 0; i < 6; ++i) scores_out[(size_t)f * 6 + i] = sc[i];
+    }
+    return DFD_OK;
+}
+
+int forensics_batch_begin(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes) {
+    if (!h->has_color) return fail(h, DFD_ERR_STATE, "forensics needs the colour tables (blob packed without luts)");
+    int rc = state_init(h, n);
+    if (rc) return rc;
+    ForensicState& F = *h->forensic;
+    if (!h->aux_stream) {
+        DFD_HIP_TRY(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+        DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->aux_go, hipEventDisableTiming));
+        DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->aux_done, hipEventDisableTiming));
+    }
+    const size_t per = FORENSIC_STATS + 128, need = (size_t)n * per * 8;
+    if (need > F.host_res_cap) {
+        if (F.host_res) DFD_HIP_TRY(h, hipHostFree(F.host_res));
+        F.host_res = nullptr;
+        F.host_res_cap = 0;
+        DFD_HIP_TRY(h, hipHostMalloc((void**)&F.host_res, need, hipHostMallocDefault));
+        F.host_res_cap = need;
+    }
+    // the frames are complete where the main stream stands now (an upload it waited for, a decode it ran)
+    DFD_HIP_TRY(h, hipEventRecord(h->aux_go, h->stream));
+    DFD_HIP_TRY(h, hipStreamWaitEvent(h->aux_stream, h->aux_go, 0));
+    launch_resize_bgr(frames_dev, n, hh, ww, stride, frame_bytes, F.buf.rs, 256, 256, h->aux_stream);
+    launch_forensics(F.buf, n, true, h->color, F.twiddle, h->aux_stream);
+    copy_kernel_async(F.host_res, F.buf.stats, (size_t)n * FORENSIC_STATS * 8, h->aux_stream);
+    copy_kernel_async(F.host_res + (size_t)n * FORENSIC_STATS, F.buf.stats_noise, (size_t)n * 64 * 8, h->aux_stream);
+    copy_kernel_async(F.host_res + (size_t)n * (FORENSIC_STATS + 64), F.buf.stats_ela, (size_t)n * 64 * 8, h->aux_stream);
+    DFD_HIP_TRY(h, hipGetLastError());
+    DFD_HIP_TRY(h, hipEventRecord(h->aux_done, h->aux_stream));
+    return DFD_OK;
+}
+
+int forensics_batch_end(dfd_handle* h, int n, double* prob_out, double* scores_out) {
+    ForensicState& F = *h->forensic;
+    DFD_HIP_TRY(h, hipEventSynchronize(h->aux_done));
+    const double* st = F.host_res;
+    const double* noise = F.host_res + (size_t)n * FORENSIC_STATS;
+    const double* ela = F.host_res + (size_t)n * (FORENSIC_STATS + 64);
     const double w[6] = {0.25, 0.20, 0.20, 0.15, 0.10, 0.10};
     for (int f = 0; f < n; ++f) {
         double sc[6], ex[10];

@@ -78,6 +78,14 @@ static void mailbox_launch(dfd_handle* h, void* dst, const void* src, size_t byt
     hipLaunchKernelGGL(mailbox_copy_kernel, dim3(blocks), dim3(256), 0, h->stream, (unsigned*)dst, (const unsigned*)src, words);
 }
 
+// device -> pinned host memory with the copy kernel on any stream (results of work that runs beside the main stream)
+void copy_kernel_async(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    const size_t words = (bytes + 3) / 4;
+    if (!words) return;
+    const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 256);
+    hipLaunchKernelGGL(mailbox_copy_kernel, dim3(blocks), dim3(256), 0, s, (unsigned*)dst, (const unsigned*)src, words);
+}
+
 int mailbox_h2d(dfd_handle* h, void* dst_dev, const void* src, size_t bytes) {
     if (!bytes) return DFD_OK;
     char* p = mailbox_alloc(h, bytes);

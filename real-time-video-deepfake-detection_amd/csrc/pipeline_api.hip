@@ -5,6 +5,8 @@
 // except the small DetectionOutput read-back that sizes the crop batch).
 #include <algorithm>
 #include <cmath>
+#include <utility>
+#include <vector>
 #include "b0_kernels.h"
 #include "dfd_common.h"
 
@@ -25,8 +27,20 @@ int dfd_analyze_batch_device(dfd_handle* h, const uint8_t* frames_dev, int n, in
     const int stride = ww * 3;
     const size_t frame_bytes = (size_t)hh * stride;
     int rc;
-    if (with_forensics && (rc = forensics_batch_run(h, frames_dev, n, hh, ww, stride, frame_bytes, forensic_prob_out, nullptr)))
-        return rc;
+    // the six signals depend on the frames only: their launch set runs on the handle's second stream beside the detector
+    // and the classifier (it fills the detector's small tail layers and the waits for detection / window counts) and is
+    // collected at the end of the call; option overlap_forensics = 0: in front of the detector on the main stream
+    const bool beside = with_forensics && h->overlap_forensics;
+    if (with_forensics) {
+        rc = beside ? forensics_batch_begin(h, frames_dev, n, hh, ww, stride, frame_bytes)
+                    : forensics_batch_run(h, frames_dev, n, hh, ww, stride, frame_bytes, forensic_prob_out, nullptr);
+        if (rc) return rc;
+    }
+    struct Collect {                                                 // every exit waits for the second stream
+        dfd_handle* h; bool on; int n; double* out;
+        int finish() { if (!on) return DFD_OK; on = false; return forensics_batch_end(h, n, out, nullptr); }
+        ~Collect() { if (on) hipEventSynchronize(h->aux_done); }
+    } collect{h, beside, n, forensic_prob_out};
     // detector on every frame (its boxes are used unless the caller forces boxes)
     std::vector<int32_t> det((size_t)n * max_faces * 4);
     std::vector<int> ndet(n);
@@ -64,7 +78,7 @@ int dfd_analyze_batch_device(dfd_handle* h, const uint8_t* frames_dev, int n, in
     int k = 0;
     for (int f = 0; f < n; ++f)
         for (int i = 0; i < n_faces_out[f]; ++i) logits_out[(size_t)f * max_faces + i] = logits[k++];
-    return DFD_OK;
+    return collect.finish();
 }
 
 
@@ -194,19 +208,23 @@ int dfd_analyze_frames_host(dfd_handle* h, const uint8_t* frames_host, int n_tot
     }
     for (int i = 0; i < 2; ++i)
         if ((rc = ensure(h, &h->stage[i], (size_t)batch * frame_bytes))) return rc;
-    auto upload = [&](int k) -> int {                       // batch k -> staging slot k & 1, on the copy stream
-        const int slot = k & 1, first = k * batch, cnt = std::min(batch, n_total - first);
-        if (k >= 2) DFD_HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->slot_free[slot], 0));   // batch k - 2 done with it
+    // chunks of `batch` frames (measured, bench.py e2e.detect_classify_h2d: 64 / 32 / 16 frames per chunk land within 3 %
+    // of each other and tapering the last chunk does not pay - the gap to the pure upload rate is not a chunking effect)
+    std::vector<std::pair<int, int>> chunks;                 // (first frame, count)
+    for (int first = 0; first < n_total; first += batch) chunks.push_back({first, std::min(batch, n_total - first)});
+    auto upload = [&](int k) -> int {                       // chunk k -> staging slot k & 1, on the copy stream
+        const int slot = k & 1, first = chunks[k].first, cnt = chunks[k].second;
+        if (k >= 2) DFD_HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->slot_free[slot], 0));   // chunk k - 2 done with it
         DFD_HIP_TRY(h, hipMemcpyAsync(h->stage[slot].p, frames_host + (size_t)first * frame_bytes, (size_t)cnt * frame_bytes,
                                       hipMemcpyHostToDevice, h->copy_stream));
         DFD_HIP_TRY(h, hipEventRecord(h->copy_done[slot], h->copy_stream));
         return DFD_OK;
     };
-    const int nb = (n_total + batch - 1) / batch;
+    const int nb = (int)chunks.size();
     if ((rc = upload(0))) return rc;
     for (int k = 0; k < nb; ++k) {
-        const int slot = k & 1, first = k * batch, cnt = std::min(batch, n_total - first);
-        if (k + 1 < nb && (rc = upload(k + 1))) return rc;              // in flight while batch k computes
+        const int slot = k & 1, first = chunks[k].first, cnt = chunks[k].second;
+        if (k + 1 < nb && (rc = upload(k + 1))) return rc;              // in flight while chunk k computes
         DFD_HIP_TRY(h, hipStreamWaitEvent(h->stream, h->copy_done[slot], 0));
         rc = dfd_analyze_batch_device(h, (const uint8_t*)h->stage[slot].p, cnt, hh, ww,
                                       forced_xywh ? forced_xywh + (size_t)first * forced_k * 4 : nullptr, forced_k, conf_thr,
