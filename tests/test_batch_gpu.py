@@ -62,3 +62,27 @@ def test_batch_ragged_frame_sizes(b0_handle, h, w):
     for f in range(3):
         assert free[f] == b0_handle.detect_faces(frames[f], 0.5)[:3]
     dev.free()
+
+
+def test_forensics_beside_the_detector_equals_forensics_in_front(b0_handle):
+    """the batch call runs the six-signal launch set on a second stream beside detector / classifier (default) or in front
+    of them on the main stream (option overlap_forensics = 0): the same probabilities, boxes and logits, call after call
+    (the second stream's buffers and events are reused)"""
+    frames = np.ascontiguousarray(np.stack([F.natural_like(480, 640, 90 + i) for i in range(7)]))
+    dev = b0_handle.alloc(frames.nbytes).upload(frames)
+    got = {}
+    try:
+        for flag in (1, 0, 1):
+            b0_handle.set_option("overlap_forensics", flag)
+            got.setdefault(flag, []).append(b0_handle.analyze_batch_device(dev.ptr, 7, 480, 640, max_faces=4, with_forensics=True))
+            got[flag].append(b0_handle.analyze_batch_device(dev.ptr, 5, 480, 640, max_faces=4, with_forensics=True))
+    finally:
+        b0_handle.set_option("overlap_forensics", 1)
+    ref = got[0]
+    for k, run in enumerate(got[1]):
+        boxes, logits, fprob = run
+        rb, rl, rp = ref[k % 2]
+        assert boxes == rb and list(fprob) == list(rp)
+        for a, b in zip(logits, rl):
+            assert np.array_equal(a, b)
+    dev.free()
