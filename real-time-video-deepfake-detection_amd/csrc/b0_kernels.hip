@@ -1585,7 +1585,6 @@ static void mb_late_launch(const XT* X, const unsigned short* We3, int plane, in
     OP(6, 3, 1, 56, 144, 24, 16, 14, 28, 7, 1, 256, true)          \
     OP(7, 3, 1, 56, 144, 24, 16, 28, 28, 7, 1, 512, true)          \
     OP(8, 3, 1, 56, 144, 24, 16, 14, 28, 7, 1, 512, true)          \
-    OP(9, 3, 1, 56, 144, 24, 48, 14, 28, 7, 1, 256, true)          \
     OP(10, 3, 1, 56, 144, 24, 16, 28, 28, 7, 1, 512, false)        \
     OP(6, 5, 2, 56, 144, 24, 16, 7, 14, 7, 1, 256, true)           \
     OP(7, 5, 2, 56, 144, 24, 16, 14, 14, 7, 1, 512, true)          \

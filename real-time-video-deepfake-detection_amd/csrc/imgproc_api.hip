@@ -59,6 +59,7 @@ static char* mailbox_alloc(dfd_handle* h, size_t bytes) {
         const size_t cap = std::max(std::max(kCap, bytes * 16), h->mailbox ? h->mailbox_cap * 2 : (size_t)0);
         char* p = nullptr;
         if (hipHostMalloc((void**)&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (getenv("DFD_MAILBOX_VERBOSE")) fprintf(stderr, "[dfd] mailbox: new block of %zu bytes (request %zu, head %zu, live %zu)\n", cap, bytes, h->mailbox_head, live);
         if (h->mailbox) h->mailbox_old.push_back(h->mailbox);
         h->mailbox = p;
         h->mailbox_cap = cap;

@@ -33,10 +33,10 @@ struct MtcnnState {
     const float* p1w_pad = nullptr;       // P-Net conv1 weights in a 288-float buffer (scalar loads read 16 at a time)
     const float *p2m = nullptr, *p3m = nullptr;   // P-Net conv2 / conv3 in the MFMA kernel's K layout ([16][96], [32][160])
     MtGemmConv r2g, r3g, o2g, o3g, o4g;
-    DevBuf in, a0, a1, prob, reg, win, coef, bnd, tmp, face, d_lv, d_items, d_pre, bs, cand;
+    DevBuf in, a0, a1, prob, reg, win, coef, bnd, tmp, face, d_lv, bs, cand;       // d_lv: every descriptor table of a step
     // box bookkeeping on the device (mtcnn_boxes.hip): crop / level tables, counts + prefix arrays + meta words, segmented and
     // compact row / window arenas, per-crop result rows, rows of crop 0 for the parity taps
-    DevBuf d_cg, d_lg, cnt, rows_a, wins_a, rows_b, wins_b, res, taprows;
+    DevBuf cnt, rows_a, wins_a, rows_b, wins_b, res, taprows;
 };
 
 void mtcnn_destroy(dfd_handle* h) {
@@ -334,6 +334,21 @@ struct Cascade {
     std::vector<Level> levels;             // pyramid levels of all crops (stage1_gpu)
     long long cells = 0;                   // P-Net output cells of all levels
     std::vector<float> tap_prob, tap_reg;  // whole P-Net maps (parity taps only)
+    std::vector<MtCropGeo> cg;             // device box path: per-crop / per-level tables, output arena sizes
+    std::vector<MtLevelGeo> lg;
+    bool geo_ok = false;
+    long long seg = 0, tmp_bytes = 0, tab = 0;
+    const MtLevel* d_levels = nullptr;     // device copies of the step's tables (one upload)
+    const MtItem* d_items = nullptr;
+    const long long* d_pre = nullptr;
+    const MtCropGeo* dcg = nullptr;
+    const MtLevelGeo* dlg = nullptr;
+
+    // Pillow's kernel size for a 160-wide axis read from in_size pixels (pil_coeffs)
+    static int pil_ksize(int in_size) {
+        const double scale = (double)in_size / 160;
+        return (int)std::ceil(scale < 1.0 ? 1.0 : scale) * 2 + 1;
+    }
 
     // ---- stage 1, device half: P-Net over all pyramid levels of all crops -> prob / reg maps + candidate list in HBM
     int stage1_gpu() {
@@ -368,21 +383,68 @@ struct Cascade {
                 minl *= 0.709;
             }
         }
+        // crop / level tables of the device box path (mtcnn_boxes.hip); geo_ok = false: a field would overflow - host path
+        cg.assign(n, MtCropGeo{});
+        lg.assign(levels.size(), MtLevelGeo{});
+        geo_ok = true;
+        seg = tmp_bytes = tab = 0;
+        {
+            size_t li = 0;
+            for (int c = 0; c < n; ++c) {
+                MtCropGeo& g = cg[c];
+                g = MtCropGeo{imgs[c].src, (long long)imgs[c].stride, imgs[c].h, imgs[c].w, (int)li, 0, seg, tmp_bytes, (int)tab, 0};
+                long long crop_cells = 0;
+                while (li < levels.size() && levels[li].crop == c) {
+                    const Level& L = levels[li];
+                    const long long lc = (long long)std::max(L.oh, 0) * std::max(L.ow, 0);
+                    if (lc >= (1ll << 27)) geo_ok = false;           // cell index field of the sort key
+                    lg[li] = MtLevelGeo{L.cell_off, L.oh, L.ow, (float)L.scale, 0};
+                    crop_cells += lc;
+                    ++li;
+                    ++g.nlevels;
+                }
+                if (g.nlevels > 31) geo_ok = false;
+                seg += std::min<long long>(crop_cells, kMtCap2);
+                tmp_bytes += ((long long)imgs[c].h * 160 * 3 + 255) & ~255ll;
+                tab += 160ll * pil_ksize(imgs[c].w) + 320 + 160ll * pil_ksize(imgs[c].h) + 320;
+                if (tab > (1ll << 30) || seg > (1ll << 30)) geo_ok = false;
+            }
+        }
         mark("s1 host: pyramid tables");
         const int nl = (int)levels.size();
-        if (nl) {
-            // descriptors through the mailbox (copied before the call returns)
-            if ((rc = upload(&S->d_lv, lv))) return rc;
+        // counters of the step in ONE zeroed block: [candidate count (4 words)][counts n][first_a n + 1][first_b n + 1][meta 4]
+        if ((rc = ensure(h, &S->cnt, ((size_t)n * 3 + 2 + 8) * 4))) return rc;
+        DFD_HIP_TRY(h, hipMemsetAsync(S->cnt.p, 0, ((size_t)n * 3 + 2 + 8) * 4, s));
+        {
+            // every descriptor table of the step in ONE upload through the mailbox (copied before the call returns):
+            // levels | items of the three ragged launches | their running totals | crop geometry | level geometry
             std::vector<MtItem> items;
             std::vector<long long> pres;
             const std::vector<MtItem>* its[3] = {&it_f, &it_c2, &it_c3};
             const std::vector<long long>* prs[4] = {&pre_in, &pre_p, &pre_c2, &pre_c3};
             for (auto* v : its) items.insert(items.end(), v->begin(), v->end());
             for (auto* v : prs) pres.insert(pres.end(), v->begin(), v->end());
-            if ((rc = upload(&S->d_items, items))) return rc;
-            if ((rc = upload(&S->d_pre, pres))) return rc;
-            const MtItem* di = (const MtItem*)S->d_items.p;
-            const long long* dp = (const long long*)S->d_pre.p;
+            auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+            const size_t o_lv = 0, o_items = al(o_lv + lv.size() * sizeof(MtLevel)), o_pre = al(o_items + items.size() * sizeof(MtItem)),
+                         o_cg = al(o_pre + pres.size() * 8), o_lg = al(o_cg + cg.size() * sizeof(MtCropGeo)),
+                         total = al(o_lg + lg.size() * sizeof(MtLevelGeo)) + 16;
+            std::vector<char> blob(total, 0);
+            if (!lv.empty()) memcpy(blob.data() + o_lv, lv.data(), lv.size() * sizeof(MtLevel));
+            if (!items.empty()) memcpy(blob.data() + o_items, items.data(), items.size() * sizeof(MtItem));
+            memcpy(blob.data() + o_pre, pres.data(), pres.size() * 8);
+            memcpy(blob.data() + o_cg, cg.data(), cg.size() * sizeof(MtCropGeo));
+            if (!lg.empty()) memcpy(blob.data() + o_lg, lg.data(), lg.size() * sizeof(MtLevelGeo));
+            if ((rc = upload(&S->d_lv, blob))) return rc;
+            const char* base = (const char*)S->d_lv.p;
+            d_levels = (const MtLevel*)(base + o_lv);
+            d_items = (const MtItem*)(base + o_items);
+            d_pre = (const long long*)(base + o_pre);
+            dcg = (const MtCropGeo*)(base + o_cg);
+            dlg = (const MtLevelGeo*)(base + o_lg);
+        }
+        if (nl) {
+            const MtItem* di = d_items;
+            const long long* dp = d_pre;
             auto item_at = [&](int k) { return di + (size_t)k * nl; };
             auto pre_at = [&](int k) { return dp + (size_t)k * (nl + 1); };
             if ((rc = ensure(h, &S->in, pre_in.back() * 4))) return rc;
@@ -391,12 +453,11 @@ struct Cascade {
             if ((rc = ensure(h, &S->prob, cells * 4))) return rc;
             if ((rc = ensure(h, &S->reg, cells * 16))) return rc;
             float *in = (float*)S->in.p, *a0 = (float*)S->a0.p, *a1 = (float*)S->a1.p;
-            launch_mt_area_resize_ragged((const MtLevel*)S->d_lv.p, pre_at(0), nl, pre_in.back(), in, s);
+            launch_mt_area_resize_ragged(d_levels, pre_at(0), nl, pre_in.back(), in, s);
             // candidate list: 16 bytes of counter, then the records
             if ((rc = ensure(h, &S->cand, 16 + (size_t)cells * sizeof(MtCand)))) return rc;
-            unsigned* d_count = (unsigned*)S->cand.p;
+            unsigned* d_count = (unsigned*)S->cnt.p;                 // zeroed above
             MtCand* d_cand = (MtCand*)((char*)S->cand.p + 16);
-            DFD_HIP_TRY(h, hipMemsetAsync(d_count, 0, 16, s));
             const MtPnetHeads heads{S->p41.w, S->p41.b, S->p42.w, S->p42.b, (float*)S->prob.p, (float*)S->reg.p,
                                     d_cand, d_count, (unsigned)cells, 0.6f};                  // thresholds[0], >=, float32
             // conv1 + PReLU + pool in one launch (the 10-channel conv map is never stored), conv2, then conv3 with both
@@ -451,7 +512,7 @@ struct Cascade {
         out->assign(n, {});
         std::vector<MtCand> cands;
         if (!levels.empty()) {
-            const unsigned* d_count = (const unsigned*)S->cand.p;
+            const unsigned* d_count = (const unsigned*)S->cnt.p;
             const MtCand* d_cand = (const MtCand*)((const char*)S->cand.p + 16);
             // the candidates (cells at or above the threshold), not the maps: count first, then that many records, both
             // through the mailbox; the atomic append order is restored to (level, y, x) by sorting on the cell
@@ -662,12 +723,6 @@ struct Cascade {
         return DFD_OK;
     }
 
-    // Pillow's kernel size for a 160-wide axis read from in_size pixels (pil_coeffs)
-    static int pil_ksize(int in_size) {
-        const double scale = (double)in_size / 160;
-        return (int)std::ceil(scale < 1.0 ? 1.0 : scale) * 2 + 1;
-    }
-
     // The whole step with the box bookkeeping on the device (mtcnn_boxes.hip): per stage one block per crop does what the
     // host path does between the networks; the host reads back the window count of all crops after stages 1 and 2
     // (launch sizes of the next network) and one result row per crop at the end - three stream waits, no box on the
@@ -680,35 +735,8 @@ struct Cascade {
         static const bool verbose = getenv("DFD_MT_VERBOSE") != nullptr;
         if ((rc = stage1_gpu())) return rc;
         stage1_done = true;
-        // crop / level tables
-        std::vector<MtCropGeo> cg(n);
-        std::vector<MtLevelGeo> lg(levels.size());
-        long long seg = 0, tmp_bytes = 0, tab = 0;
-        {
-            size_t li = 0;
-            for (int c = 0; c < n; ++c) {
-                MtCropGeo& g = cg[c];
-                g = MtCropGeo{imgs[c].src, (long long)imgs[c].stride, imgs[c].h, imgs[c].w, (int)li, 0, seg, tmp_bytes, (int)tab, 0};
-                long long crop_cells = 0;
-                while (li < levels.size() && levels[li].crop == c) {
-                    const Level& L = levels[li];
-                    if ((long long)std::max(L.oh, 0) * std::max(L.ow, 0) >= (1ll << 27)) return DFD_OK;       // cell index field: host path
-                    lg[li] = MtLevelGeo{L.cell_off, L.oh, L.ow, (float)L.scale, 0};
-                    crop_cells += (long long)std::max(L.oh, 0) * std::max(L.ow, 0);
-                    ++li;
-                    ++g.nlevels;
-                }
-                if (g.nlevels > 31) return DFD_OK;
-                seg += std::min<long long>(crop_cells, kMtCap2);
-                tmp_bytes += ((long long)imgs[c].h * 160 * 3 + 255) & ~255ll;
-                tab += 160ll * pil_ksize(imgs[c].w) + 320 + 160ll * pil_ksize(imgs[c].h) + 320;
-                if (tab > (1ll << 30) || seg > (1ll << 30)) return DFD_OK;
-            }
-        }
-        if ((rc = upload(&S->d_cg, cg))) return rc;
-        if ((rc = upload(&S->d_lg, lg))) return rc;
+        if (!geo_ok) return DFD_OK;
         const size_t segn = (size_t)std::max<long long>(seg, 1);
-        if ((rc = ensure(h, &S->cnt, ((size_t)n * 3 + 2 + 4) * 4))) return rc;
         if ((rc = ensure(h, &S->rows_a, segn * sizeof(MtRow)))) return rc;
         if ((rc = ensure(h, &S->wins_a, segn * sizeof(MtSrcWindow)))) return rc;
         if ((rc = ensure(h, &S->rows_b, segn * sizeof(MtRow)))) return rc;
@@ -718,12 +746,10 @@ struct Cascade {
         if ((rc = ensure(h, &S->bnd, (size_t)n * sizeof(MtFaceJob)))) return rc;
         if ((rc = ensure(h, &S->tmp, (size_t)std::max<long long>(tmp_bytes, 16)))) return rc;
         if (tap_name && (rc = ensure(h, &S->taprows, (size_t)kMtCap1 * sizeof(MtRow)))) return rc;
-        int* counts = (int*)S->cnt.p;
+        int* counts = (int*)S->cnt.p + 4;                        // (behind the candidate counter; zeroed by stage1_gpu)
         int *first_a = counts + n, *first_b = first_a + n + 1, *meta = first_b + n + 1;
-        const MtCropGeo* dcg = (const MtCropGeo*)S->d_cg.p;
         MtRow *rows_a = (MtRow*)S->rows_a.p, *rows_b = (MtRow*)S->rows_b.p, *taprows = tap_name ? (MtRow*)S->taprows.p : nullptr;
         MtSrcWindow *wins_a = (MtSrcWindow*)S->wins_a.p, *wins_b = (MtSrcWindow*)S->wins_b.p;
-        DFD_HIP_TRY(h, hipMemsetAsync(S->cnt.p, 0, ((size_t)n * 3 + 2 + 4) * 4, s));
         // rows of crop 0 after a stage (parity taps): meta[2] of them at taprows
         auto tap_stage = [&](const char* name, const int* meta_host) -> int {
             if (!want(name)) return DFD_OK;
@@ -750,23 +776,22 @@ struct Cascade {
             }
             return DFD_OK;
         };
-        // the count words after a stage: {windows of all crops, overflow, rows of crop 0} + windows of crop 0 (first[1])
-        auto read_meta = [&](const int* first, int out[4]) -> int {
-            const int* pm = (const int*)mailbox_d2h(h, meta, 12);
-            const int* pf = (const int*)mailbox_d2h(h, first + 1, 4);
-            if (!pm || !pf) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
+        // the count words after a stage: {windows of all crops, overflow, rows of crop 0, windows of crop 0}
+        auto read_meta = [&](int out[4]) -> int {
+            const int* pm = (const int*)mailbox_d2h(h, meta, 16);
+            if (!pm) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
             DFD_HIP_TRY(h, hipGetLastError());
             DFD_HIP_TRY(h, stream_sync(h));
-            out[0] = pm[0]; out[1] = pm[1]; out[2] = pm[2]; out[3] = pf[0];
+            out[0] = pm[0]; out[1] = pm[1]; out[2] = pm[2]; out[3] = pm[3];
             return DFD_OK;
         };
         int mh[4] = {0, 0, 0, 0};
         int m2 = 0, m3 = 0;
         if (!levels.empty()) {
-            launch_mt_stage1_boxes(dcg, (const MtLevelGeo*)S->d_lg.p, n, (const float*)S->prob.p, (const float*)S->reg.p, 0.6f,
+            launch_mt_stage1_boxes(dcg, dlg, n, (const float*)S->prob.p, (const float*)S->reg.p, 0.6f,
                                    rows_a, wins_a, counts, meta, taprows, s);
             launch_mt_compact(counts, n, dcg, nullptr, rows_a, wins_a, rows_b, wins_b, first_a, meta, s);
-            if ((rc = read_meta(first_a, mh))) return rc;
+            if ((rc = read_meta(mh))) return rc;
             mark("s1 gpu: boxes + count");
             if (mh[1]) {
                 if (verbose) fprintf(stderr, "[dfd] mtcnn: a crop exceeds the device box capacity - host path\n");
@@ -786,7 +811,7 @@ struct Cascade {
             launch_mt_refine_boxes(2, dcg, first_a, n, rows_b, (const float*)S->prob.p, (const float*)S->reg.p, 0.7f, 0.7f, rows_a, wins_a,
                                    counts, nullptr, nullptr, nullptr, taprows, meta, s);
             launch_mt_compact(counts, n, dcg, first_a, rows_a, wins_a, rows_b, wins_b, first_b, meta, s);
-            if ((rc = read_meta(first_b, mh))) return rc;
+            if ((rc = read_meta(mh))) return rc;
             mark("s2 gpu: R-Net + boxes + count");
             if ((rc = tap_stage("stage2", mh))) return rc;
             m3 = mh[0];
@@ -805,11 +830,11 @@ struct Cascade {
         launch_mt_extract_faces((const MtFaceJob*)S->bnd.p, n, (const int*)S->coef.p, faces_out, (uint8_t*)S->tmp.p, s);
         DFD_HIP_TRY(h, hipGetLastError());
         const float* pr = (const float*)mailbox_d2h(h, S->res.p, (size_t)n * 8 * 4);
-        const int* pm = (const int*)mailbox_d2h(h, meta, 12);
-        if (!pr || !pm) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
+        const int* pm = tap_name ? (const int*)mailbox_d2h(h, meta, 12) : nullptr;
+        if (!pr || (tap_name && !pm)) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
         DFD_HIP_TRY(h, stream_sync(h));
         mark("s3 gpu: O-Net + boxes + extract");
-        int m3h[3] = {pm[0], pm[1], pm[2]};
+        int m3h[3] = {0, 0, pm ? pm[2] : 0};
         for (int i = 0; i < n; ++i) {
             const float* r = pr + (size_t)i * 8;
             found[i] = r[0] != 0.f;

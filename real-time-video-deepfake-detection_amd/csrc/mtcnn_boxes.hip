@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256) void mt_compact_kernel(const int* __restrict__
     }
     if (tid == 0) {
         first_out[c] = off;
+        if (c == 0) meta[3] = m;
         if (c == n - 1) {
             first_out[n] = off + m;
             meta[0] = off + m;

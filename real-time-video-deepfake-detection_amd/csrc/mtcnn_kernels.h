@@ -68,7 +68,8 @@ constexpr int kMtCap2 = 4096;    // windows of one crop the stage-2 / stage-3 bl
 struct MtCropGeo { const uint8_t* src; long long stride; int h, w, level0, nlevels; long long seg_off; long long tmp_off; int tab_off, pad; };
 struct MtLevelGeo { long long cell_off; int oh, ow; float scale; int pad; };      // P-Net output grid of a level, first cell, (float) scale
 struct MtRow { float x1, y1, x2, y2, score; };
-// meta[0] = windows of all crops (compact kernel), meta[1] = overflow flag (zeroed by the caller), meta[2] = rows of crop 0
+// meta[0] = windows of all crops, meta[3] = windows of crop 0 (compact kernel), meta[1] = overflow flag (zeroed by the
+// caller), meta[2] = rows of crop 0
 void launch_mt_stage1_boxes(const MtCropGeo* crops, const MtLevelGeo* levels, int n, const float* prob, const float* reg, float thr,
                             MtRow* rows_seg, MtSrcWindow* wins_seg, int* counts, int* meta, MtRow* tap_rows, hipStream_t s);
 void launch_mt_compact(const int* counts, int n, const MtCropGeo* crops, const int* seg_first, const MtRow* rows_seg,

@@ -268,7 +268,6 @@ __global__ __launch_bounds__(256) void mt_area_resize_ragged_kernel(const MtLeve
     const long long r = t - pre[i] / 3;
     const unsigned ru = (unsigned)r, uow = (unsigned)L.ow, uoh = (unsigned)L.oh;
     const unsigned oyu = ru / uow, oxu = ru - oyu * uow;
-    const int ox = (int)oxu, oy = (int)oyu;
     const int y0 = (int)(oyu * (unsigned)L.h / uoh), y1 = (int)(((oyu + 1u) * (unsigned)L.h + uoh - 1u) / uoh);
     const int x0 = (int)(oxu * (unsigned)L.w / uow), x1 = (int)(((oxu + 1u) * (unsigned)L.w + uow - 1u) / uow);
     int sb = 0, sg = 0, sr = 0;
@@ -914,7 +913,7 @@ __global__ __launch_bounds__(256) void mt_area_resize_multi_kernel(const MtSrcWi
     if (t >= (long long)n * oh * ow) return;
     const unsigned tu = (unsigned)t, uow = (unsigned)ow, uoh = (unsigned)oh;   // n * oh * ow < 2^31 (kChunk windows of <= 48 x 48)
     const unsigned rowi = tu / uow, oxu = tu - rowi * uow, iu = rowi / uoh, oyu = rowi - iu * uoh;
-    const int ox = (int)oxu, oy = (int)oyu, i = (int)iu;
+    const int i = (int)iu;
     const MtSrcWindow w = win[i];
     const int y0 = (int)(oyu * (unsigned)w.h / uoh), y1 = (int)(((oyu + 1u) * (unsigned)w.h + uoh - 1u) / uoh);
     const int x0 = (int)(oxu * (unsigned)w.w / uow), x1 = (int)(((oxu + 1u) * (unsigned)w.w + uow - 1u) / uow);
