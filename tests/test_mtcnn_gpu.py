@@ -190,3 +190,32 @@ def test_box_capacity_overflow_falls_back_to_the_host_path(pkg, mt_handle, monke
     assert (fd is None) == (fh is None)
     if fd is not None:
         assert np.array_equal(bd, bh) and np.array_equal(fd, fh)
+
+
+def test_device_box_logic_at_the_bench_size(pkg, seeded_sd):
+    """bench.py's MTCNN rows (64 x 1080p frames, 4 forced crops each, selective cascade): the 256 logits of the device box
+    path equal the host path's bit for bit, NaN positions included - the property that holds at any size."""
+    import os
+
+    W = pkg.weights
+    sel = W.seeded_mtcnn_state_dict(0, W.MTCNN_SELECTIVE)
+    n = 64
+    h = pkg._lib.Handle(W.pack_all(seeded_sd, W.seeded_ssd_state_dict(0), sel), device=0, max_batch=4 * n)
+    try:
+        frames = np.random.default_rng(7).integers(50, 200, (n, 1080, 1920, 3), dtype=np.uint8)
+        boxes = [[(200, 150, 320, 400), (900, 300, 256, 256), (1400, 500, 400, 480), (600, 700, 224, 224)]] * n
+        fd = h.alloc(frames.nbytes).upload(frames)
+        got = {}
+        for flag in ("1", "0"):
+            os.environ["DFD_MT_DEVICE_BOXES"] = flag
+            res = h.analyze_batch_device(fd.ptr, n, 1080, 1920, forced_boxes=boxes, max_faces=4)
+            got[flag] = np.concatenate([np.asarray(l, np.float32).reshape(-1) for l in res[1]])
+        os.environ.pop("DFD_MT_DEVICE_BOXES", None)
+        assert got["1"].size == 4 * n
+        assert np.array_equal(got["1"], got["0"], equal_nan=True)
+        found = int((~np.isnan(got["1"])).sum())
+        assert 0 < found < 4 * n
+        fd.free()
+    finally:
+        os.environ.pop("DFD_MT_DEVICE_BOXES", None)
+        h.close()
