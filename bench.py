@@ -177,8 +177,8 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, w
             pinned[r * frames_per_step:(r + 1) * frames_per_step] = frames
         hboxes = boxes * reps
         # chunk size: measured, not assumed
-        h.warmup(32 * K, 32)
-        h.warmup(16 * K, 16)
+        h.warmup(min(32 * K, h.max_batch), 32)
+        h.warmup(min(16 * K, h.max_batch), 16)
         by_chunk = {}
         for chunk in (64, 32, 16):
             h.analyze_frames_host(pinned, chunk, forced_boxes=hboxes, max_faces=K)
