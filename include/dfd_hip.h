@@ -68,6 +68,9 @@ int dfd_max_batch(const dfd_handle* h);
  *   the split-precision GEMM (each fp32 operand = exact sum of three bf16 terms, six products on the bf16
  *   MFMA, fp32 accumulate: fp32-dot-product accuracy); 0 = the fp32 MFMA kernel everywhere.
  *   "mtcnn" (default 1): align every crop with the MTCNN cascade when the blob carries one.
+ *   "overlap_forensics" (default 1): dfd_analyze_batch_device / dfd_analyze_frames_host run the six forensic signals of
+ *   a batch on the handle's second stream beside the detector and the classifier and collect them at the end of the call;
+ *   0 = in front of the detector on the main stream.  Same results.
  *   "profile_stride" (default 1): between dfd_b0_profile_begin/end only every k-th forward records events. */
 int dfd_set_option(dfd_handle* h, const char* name, int value);
 /*   "gemm_tile" (default -1): >= 0 forces split-GEMM instance number value % (candidates of the shape) for every
@@ -211,7 +214,10 @@ int dfd_detect_faces_haar(dfd_handle* h, const uint8_t* bgr, int height, int wid
  * carries "mtcnn.*" tensors (weights.pack_mtcnn_tensors); the classify entry points
  * (dfd_classify_crops, dfd_preprocess_crops, dfd_analyze_frame, dfd_analyze_batch_device) then align
  * every crop with it and return a NaN logit where it finds no face (the reference returns None
- * there); dfd_set_option(h, "mtcnn", 0) bypasses the stage.
+ * there); dfd_set_option(h, "mtcnn", 0) bypasses the stage.  The box bookkeeping between the three networks (NMS,
+ * regression, squaring, clipping, selection, extract_face geometry and resize tables) runs on the device, one thread
+ * block per crop and stage (csrc/mtcnn_boxes.hip); environment DFD_MT_DEVICE_BOXES=0 keeps it on the library's host
+ * side (identical results; also the fallback when a crop has more than 8192 P-Net candidates or 4096 windows).
  *   face_chw_out : NULL or 3*160*160 floats, RGB planes 0..255 (what MTCNN.forward returns)
  *   box_out      : NULL or 5 floats (x1, y1, x2, y2, probability) of the selected box
  *   found        : 1 / 0 */

@@ -1,10 +1,13 @@
 // MTCNN align/crop stage: the cascade the reference runs on every cropped face before the
 // classifier (reference deepfake_detection.py:24-28, 376-380 -> facenet-pytorch MTCNN.forward: detect_face,
 // select by probability, extract_face to 160x160).  All crops of a call go through the three stages together: the
-// networks, the resamplers and the P-Net candidate compaction run as HIP kernels (mtcnn_kernels.hip, gemm_split.hip);
-// the box bookkeeping between the stages (NMS, regression, squaring, clipping - float32 arithmetic in the package's
-// operation order, restated line by line from oracle/mtcnn_ref.py) runs here on the host side of the library, as the
-// package does it in numpy / torch glue: grid-local per-level NMS, SoA sweeps, host threads when the funnel is dense.
+// networks, the resamplers and the P-Net candidate compaction run as HIP kernels (mtcnn_kernels.hip, gemm_split.hip).
+// The box bookkeeping between the stages (NMS, regression, squaring, clipping, selection, extract_face geometry - float32
+// arithmetic in the package's operation order, restated line by line from oracle/mtcnn_ref.py) runs on the device too
+// (mtcnn_boxes.hip, Cascade::run_device: one block per crop and stage; the host reads back two window counts and one
+// result row per crop - three stream waits per step).  The same logic on the host side of the library (Cascade::run:
+// grid-local per-level NMS, SoA sweeps, host threads when the funnel is dense) is the reference the device path is
+// tested against bit for bit (DFD_MT_DEVICE_BOXES=0) and takes over when a crop exceeds the device blocks' capacity.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
