@@ -496,23 +496,48 @@ __global__ __launch_bounds__(256) void mt_pnet_conv1_pool_kernel(const float* __
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int o = 0; o < CO; ++o) acc[p][o] = 0.f;
-    sf16 wn = sload16<0>(w);
+    // 17 groups of 16 weights (flat index = tap * 10 + channel), two register groups used in turn: while one feeds the
+    // FMAs the other is in flight.  Two output channels per instruction: v_pk_fma_f32 with the SGPR weight pair as one
+    // operand (each half an IEEE fma: the bits of fmaf); 10 and 16 are even, so (idx, idx + 1) is a channel pair of one
+    // tap inside one group.
+    auto use = [&](const sf16& wc, int g) {
 #pragma unroll
-    for (int g = 0; g < 17; ++g) {                           // 17 groups of 16 weights: flat index = tap * 10 + channel
-        swait1(wn);
-        const sf16 wc = wn;
-        if (g + 1 < 17) wn = sload16s(w, (g + 1) * 64);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < 16; j += 2) {
             const int idx = g * 16 + j;
             if (idx < 270) {
                 const int tap = idx / CO, o = idx % CO, c = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
 #pragma unroll
-                for (int p = 0; p < 4; ++p) acc[p][o] = fmaf(patch[(p >> 1) + ky][(p & 1) + kx][c], wc[j], acc[p][o]);
+                for (int p = 0; p < 4; ++p) {
+                    const float xv = patch[(p >> 1) + ky][(p & 1) + kx][c];
+                    const v2f x2 = {xv, xv};
+                    v2f a = {acc[p][o], acc[p][o + 1]};
+                    a = __builtin_elementwise_fma(x2, (v2f){wc[j], wc[j + 1]}, a);
+                    acc[p][o] = a.x; acc[p][o + 1] = a.y;
+                }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);                   // the group's FMAs stay before the next wait / load: two groups live
+    };
+    sf16 wa = sload16<0>(w), wb;
+#pragma unroll
+    for (int g = 0; g < 17; g += 2) {
+        swait1(wa);
+        if (g + 1 < 17) wb = sload16s(w, (g + 1) * 64);
+        use(wa, g);
+        __builtin_amdgcn_sched_barrier(0);                   // the group's FMAs stay before the next wait / load
+        if (g + 1 < 17) {
+            swait1(wb);
+            if (g + 2 < 17) wa = sload16s(w, (g + 2) * 64);
+            use(wb, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+    // the accumulators are pinned here: pixels 1-3 are used under `vx` / `vy` below, and with that as their only use the
+    // optimiser sinks their FMAs into those branches - behind every scalar load, with all 17 weight groups spilled lane by
+    // lane and restored there (208 v_writelane + 208 v_readlane in the packed-FMA build)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        asm volatile("" : "+v"(acc[p][0]), "+v"(acc[p][1]), "+v"(acc[p][2]), "+v"(acc[p][3]), "+v"(acc[p][4]), "+v"(acc[p][5]),
+                          "+v"(acc[p][6]), "+v"(acc[p][7]), "+v"(acc[p][8]), "+v"(acc[p][9]));
     float out[CO];
 #pragma unroll
     for (int o = 0; o < CO; ++o) {

@@ -32,7 +32,7 @@ def test_scalar_operand_kernels_have_no_sgpr_spills_after_their_loads():
                         os.path.join(CSRC, "mtcnn_kernels.hip"), "-o", out], check=True, cwd=CSRC)
         lines = open(out).read().split("\n")
     for prefix, n_loads, fma_op, n_fma in (("_ZN3dfd20mt_conv1_pool_kernel", 29, "v_pk_fma_f32", 27 * 24),
-                                           ("_ZN3dfd25mt_pnet_conv1_pool_kernel", 17, None, 0)):
+                                           ("_ZN3dfd25mt_pnet_conv1_pool_kernel", 17, "v_pk_fma_f32", 27 * 5 * 4)):
         body, meta = _kernel_body(lines, prefix)
         ops = [m.group(1) for l in body for m in [re.match(r"\s+([a-z_0-9]+)", l)] if m]
         assert ops.count("s_load_dwordx16") >= n_loads, prefix                       # weights as SGPR operands
