@@ -316,7 +316,12 @@ int forensics_batch_begin(dfd_handle* h, const uint8_t* frames_dev, int n, int h
     if (rc) return rc;
     ForensicState& F = *h->forensic;
     if (!h->aux_stream) {
-        DFD_HIP_TRY(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+        // LOWEST priority: the signals have the whole call to finish; their workgroups should take the CUs the main
+        // stream leaves idle (DetectionOutput runs 64 blocks on 256 CUs, the detector's tail layers and the cascade's
+        // R-/O-Net are small, four waits on the host) instead of competing with its large launches
+        int least = 0, greatest = 0;
+        DFD_HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        DFD_HIP_TRY(h, hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, least));
         DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->aux_go, hipEventDisableTiming));
         DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->aux_done, hipEventDisableTiming));
     }
