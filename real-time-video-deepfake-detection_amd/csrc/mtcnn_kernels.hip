@@ -190,6 +190,33 @@ __device__ __forceinline__ int mt_find(const long long* __restrict__ pre, int n,
     return lo;
 }
 
+// The same search by one WAVE for two elements at once (lanes 0-31: t0, lanes 32-63: t1): every round the 32 lanes of a
+// half probe 32 evenly spaced entries of the current range together and a ballot picks the sub-range - two or three
+// rounds of loads for n <= 32768 instead of log2(n) dependent ones.  The binary search by threads 0 and 1 in front of
+// the block's first barrier was 11 dependent loads for ~2000 pyramid levels: ~5 us during which none of the block's
+// other waves could start (s_memtime; a third of the pyramid-resize launch).  Call with all 64 lanes of a wave;
+// returns the item of t0 in every lane's .x, of t1 in .y.
+__device__ __forceinline__ int2 mt_find2_wave(const long long* __restrict__ pre, int n, long long t0, long long t1) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+    const long long t = half ? t1 : t0;
+    int lo = 0, hi = n;                                            // pre[lo] <= t < pre[hi], per half
+    while (__any(hi - lo > 1)) {
+        const int span = hi - lo, step = (span + 31) >> 5;         // >= 1
+        const int idx = lo + l32 * step;
+        const bool le = idx < hi && pre[idx] <= t;                 // monotone in l32; lane 0 of a half is always true
+        const unsigned long long m = __ballot(le);
+        const unsigned mh = (unsigned)(half ? (m >> 32) : (m & 0xFFFFFFFFull));
+        const int k = __popc(mh) - 1;                              // last probe at or below t
+        if (hi - lo > 1) {
+            const int nlo = lo + k * step, nhi = nlo + step < hi ? nlo + step : hi;
+            lo = nlo;
+            hi = nhi;
+        }
+    }
+    const int r0 = __shfl(lo, 0), r1 = __shfl(lo, 32);
+    return make_int2(r0, r1);
+}
+
 // Exact integer sums of the three channels over the window rows [y0, y1) x pixels [x0, x1) of a packed BGR image.
 // A row's 3 * (x1 - x0) bytes are read as unaligned dwords, 12 bytes (four pixels) per step, instead of one byte per
 // load: the ragged pyramid resize issued 740 M byte loads per 256 crops (every level reads the whole crop) and was bound
@@ -254,9 +281,10 @@ __global__ __launch_bounds__(256) void mt_area_resize_ragged_kernel(const MtLeve
     const unsigned nb = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, qq = nb >> 3, rr = nb & 7;
     const unsigned bidx = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + slot;
     const long long t = (long long)bidx * 256 + threadIdx.x;
-    if (threadIdx.x < 2) {
-        const long long e = ((long long)bidx * 256 + (threadIdx.x ? 255 : 0)) * 3;
-        lohi[threadIdx.x] = mt_find(pre, n, e < pre[n] ? e : pre[n] - 1);
+    if (threadIdx.x < 64) {
+        const long long tot = pre[n], e0 = (long long)bidx * 256 * 3, e1 = ((long long)bidx * 256 + 255) * 3;
+        const int2 f = mt_find2_wave(pre, n, e0 < tot ? e0 : tot - 1, e1 < tot ? e1 : tot - 1);
+        if (threadIdx.x == 0) { lohi[0] = f.x; lohi[1] = f.y; }
     }
     __syncthreads();
     if (t * 3 >= pre[n]) return;
@@ -465,9 +493,10 @@ __global__ __launch_bounds__(256) void mt_pnet_conv1_pool_kernel(const float* __
     const long long npix = pre[n] / CO;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long q = t < npix ? t : npix - 1;             // surplus threads redo the last pixel (uniform control flow)
-    if (threadIdx.x < 2) {
-        const long long e = (long long)blockIdx.x * 256 + (threadIdx.x ? 255 : 0);
-        lohi[threadIdx.x] = mt_find(pre, n, (e < npix ? e : npix - 1) * CO);
+    if (threadIdx.x < 64) {
+        const long long e0 = (long long)blockIdx.x * 256, e1 = e0 + 255;
+        const int2 f = mt_find2_wave(pre, n, (e0 < npix ? e0 : npix - 1) * CO, (e1 < npix ? e1 : npix - 1) * CO);
+        if (threadIdx.x == 0) { lohi[0] = f.x; lohi[1] = f.y; }
     }
     __syncthreads();
     const int i = mt_find_in(pre, lohi, q * CO);
