@@ -122,6 +122,16 @@ def cpu_baseline(sd_np, with_e2e=True):
     return out
 
 
+# DFD_BENCH_REHEARSE=1: the --gpus N code path of this file on a box with fewer GPUs than ranks (ranks share devices,
+# torch.distributed over gloo with CPU tensors, vote exchange on the documented torch fallback) - a rehearsal of the
+# multi-rank control flow on real hardware, never a measurement
+REHEARSE = os.environ.get("DFD_BENCH_REHEARSE") == "1"
+
+
+def _red_dev(local_rank):
+    return "cpu" if REHEARSE else f"cuda:{local_rank}"
+
+
 def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, warmup=3):
     """BASELINE.json configs[2]/[3] as an extra: 1080p synthetic frames resident in HBM ->
     SSD detect (every frame) + 4 forced >=224x224 boxes per frame -> CLAHE -> 224x224 -> B0, without and
@@ -145,7 +155,7 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, w
         h.sync()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            t = torch.tensor([dt], dtype=torch.float64, device=_red_dev(local_rank))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -462,14 +472,14 @@ def config5_streams(h, rank, world, dist, local_rank, waves=32, n_streams=8, ver
             note = f"dfd_comm_unique_id failed: {e}"
     if dist is not None:
         dist.broadcast_object_list(cid, src=0)
-    ok = cid[0] is not None
+    ok = cid[0] is not None and not REHEARSE                   # (ranks that share a device cannot form an RCCL communicator)
     if ok:
         try:
             h.comm_init(cid[0], rank, world)
         except Exception as e:                                   # noqa: BLE001 - any failure -> documented fallback
             ok, note = False, f"dfd_comm_init failed: {e}"
     if dist is not None:
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{local_rank}" if on_gpu else "cpu")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_red_dev(local_rank) if on_gpu else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
     if not ok:
@@ -510,7 +520,7 @@ def config5_streams(h, rank, world, dist, local_rank, waves=32, n_streams=8, ver
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if on_gpu else "cpu")
+        tt = torch.tensor([dt], dtype=torch.float64, device=_red_dev(local_rank) if on_gpu else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     for fd, _ in staged:
@@ -586,8 +596,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if REHEARSE:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     sd = rtdfd_amd.weights.seeded_state_dict(0)
     blob = rtdfd_amd.weights.pack_all(sd, rtdfd_amd.weights.seeded_ssd_state_dict(0))
@@ -624,7 +639,7 @@ def main():
     dt = time.perf_counter() - t0
     steps_seen, layers = h.profile_end()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=_red_dev(local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
