@@ -51,4 +51,4 @@ def test_two_rank_launch_of_the_bench_rehearsed_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert abs(d["ms_per_step"] * d["value"] / 1e3 - 2 * 256) < 2.0                        # whole-job aggregate over both ranks
     c5 = d["config5"]
-    assert c5["transport"] == "torch" and c5["verdicts_equal_single_gpu"] is True and c5["verified_frames_per_stream"] == 32
+    assert c5["transport"] == "torch" and c5["verdicts_equal_single_gpu"] is True and c5["verified_frames_per_stream"] == 32 * 2      # every frame of every stream (32 waves x 2 ranks)
