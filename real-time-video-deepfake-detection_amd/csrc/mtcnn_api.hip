@@ -610,9 +610,7 @@ struct Cascade {
                 launch_mt_maxpool(a0, a1, m, 9, 9, 64, 3, 2, s);                                    // 4
                 if ((rc = gemm_conv_prelu(h, S->r3g, a1, a0, m, 4, 4))) return rc;                  // 3 -> [m][3][3][64]
                 if ((rc = gemm_dense_prelu(h, S->r4, a0, a1, m))) return rc;                        // 576 -> 128
-                launch_mt_dense(a1, S->r51.w, S->r51.b, nullptr, a0, m, 128, 2, s);
-                launch_mt_softmax_face(a0, pr, m, s);
-                launch_mt_dense(a1, S->r52.w, S->r52.b, nullptr, rg, m, 128, 4, s);
+                launch_mt_heads(a1, S->r51.w, S->r51.b, S->r52.w, S->r52.b, pr, rg, m, 128, s);
             } else {
                 // conv1 (46) + PReLU + pool (23) in one launch
                 if (!launch_mt_conv1_pool(in, S->o1.w, S->o1.b, S->o1.a, a1, m, 48, 48, 32, s)) return fail(h, DFD_ERR_STATE, "mtcnn: conv1+pool shape");
@@ -622,9 +620,7 @@ struct Cascade {
                 launch_mt_maxpool(a0, a1, m, 8, 8, 64, 2, 2, s);                                    // 4
                 if ((rc = gemm_conv_prelu(h, S->o4g, a1, a0, m, 4, 4))) return rc;                  // 3 -> [m][3][3][128]
                 if ((rc = gemm_dense_prelu(h, S->o5, a0, a1, m))) return rc;                        // 1152 -> 256
-                launch_mt_dense(a1, S->o61.w, S->o61.b, nullptr, a0, m, 256, 2, s);
-                launch_mt_softmax_face(a0, pr, m, s);
-                launch_mt_dense(a1, S->o62.w, S->o62.b, nullptr, rg, m, 256, 4, s);
+                launch_mt_heads(a1, S->o61.w, S->o61.b, S->o62.w, S->o62.b, pr, rg, m, 256, s);
                 // dense6_3 (landmarks) does not influence the selected crop: not evaluated
             }
             DFD_HIP_TRY(h, hipGetLastError());

@@ -15,11 +15,9 @@ struct MtItem { long long in_off, out_off; int ih, iw; };
 
 int mt_pool_out(int in, int k, int st);   // MaxPool2d(k, st, ceil_mode=True) output size
 void launch_mt_maxpool(const float* x, float* y, int n, int ih, int iw, int c, int k, int st, hipStream_t s);
-// y[n][out] = x[n][in] . w[in][out] + b (+ PReLU)
-void launch_mt_dense(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int in, int out,
-                     hipStream_t s);
-// z [n][2] -> softmax(z)[1]
-void launch_mt_softmax_face(const float* z, float* p, long long n, hipStream_t s);
+// both output heads of R-Net / O-Net in one launch: prob [n] = softmax(f . w1 + b1)[1], reg [n][4] = f . w2 + b2 (w1 [in][2], w2 [in][4])
+void launch_mt_heads(const float* f, const float* w1, const float* b1, const float* w2, const float* b2, float* prob, float* reg,
+                     int n, int in, hipStream_t s);
 // ragged variants: `n` images of different sizes per launch; pre[n + 1] = running total of output elements
 void launch_mt_area_resize_ragged(const MtLevel* lv_dev, const long long* pre_dev, int n, long long total, float* dst,
                                   hipStream_t s);

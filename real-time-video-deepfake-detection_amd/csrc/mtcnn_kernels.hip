@@ -8,7 +8,7 @@
 //   mt_convpx (ragged)               P-Net conv2, conv3 (+ both heads, softmax, candidate compaction)
 //   mt_conv1_pool                    R-/O-Net conv1 + PReLU + MaxPool(3, 2, ceil)
 //   mt_maxpool                       MaxPool2d(k, s, ceil_mode=True) behind the GEMM convolutions
-//   mt_dense, mt_softmax_face        the 2- / 4-wide heads of R-/O-Net
+//   mt_heads                         the 2- / 4-wide heads of R-/O-Net + softmax in one launch (eight lanes per window)
 //   mt_extract_h / _v                extract_face of all crops: Pillow's 8-bit fixed-point Image.resize passes
 // Every convolution accumulates its products as fmaf in (ci, ky, kx) order, then + bias, then PReLU - the order a
 // direct convolution over the weight tensor [co][ci][ky][kx] walks.
@@ -72,39 +72,46 @@ void launch_mt_maxpool(const float* x, float* y, int n, int ih, int iw, int c, i
     }
 }
 
-__global__ __launch_bounds__(256) void mt_dense_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ b, const float* __restrict__ slope,
-                                                       float* __restrict__ y, int n, int in, int out) {
+// The two output heads of R-Net / O-Net in ONE launch: face probability = softmax(f . W1 + b1)[1], regression = f . W2 + b2
+// for `n` feature rows f[in] (in = 128 / 256).  Eight lanes share a row: lane l sums the terms c = l, l + 8, ... of all six
+// dot products, three xor-shuffles fold them, lane 0 of the group finishes.  As three launches (a thread per output
+// element walking `in` dependent FMAs, softmax, again) the heads took 36 + 64 us per step for a few hundred windows.
+__global__ __launch_bounds__(256) void mt_heads_kernel(const float* __restrict__ f, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, const float* __restrict__ w2,
+                                                       const float* __restrict__ b2, float* __restrict__ prob,
+                                                       float* __restrict__ reg, int n, int in) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long long)n * out) return;
-    const int o = (int)(t % out), i = (int)(t / out);
-    const float* xp = x + (size_t)i * in;
-    float acc = 0.f;
-    for (int c = 0; c < in; ++c) acc = fmaf(xp[c], w[(size_t)c * out + o], acc);
-    acc += b[o];
-    if (slope) acc = acc >= 0.f ? acc : acc * slope[o];
-    y[t] = acc;
+    const int l = (int)(t & 7);
+    const long long row = t >> 3;
+    const long long rc = row < n ? row : (long long)n - 1;     // surplus groups redo the last row (uniform shuffles)
+    const float* fp = f + (size_t)rc * in;
+    float z0 = 0.f, z1 = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+    for (int c = l; c < in; c += 8) {
+        const float v = fp[c];
+        const float2 a = *reinterpret_cast<const float2*>(w1 + (size_t)c * 2);
+        const float4 q = *reinterpret_cast<const float4*>(w2 + (size_t)c * 4);
+        z0 = fmaf(v, a.x, z0); z1 = fmaf(v, a.y, z1);
+        r0 = fmaf(v, q.x, r0); r1 = fmaf(v, q.y, r1); r2 = fmaf(v, q.z, r2); r3 = fmaf(v, q.w, r3);
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        z0 += __shfl_xor(z0, off); z1 += __shfl_xor(z1, off);
+        r0 += __shfl_xor(r0, off); r1 += __shfl_xor(r1, off); r2 += __shfl_xor(r2, off); r3 += __shfl_xor(r3, off);
+    }
+    if (l == 0 && row < n) {
+        z0 += b1[0]; z1 += b1[1];
+        const float m = fmaxf(z0, z1);
+        const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+        prob[row] = e1 / (e0 + e1);
+        *reinterpret_cast<float4*>(reg + (size_t)row * 4) = make_float4(r0 + b2[0], r1 + b2[1], r2 + b2[2], r3 + b2[3]);
+    }
 }
 
-void launch_mt_dense(const float* x, const float* w, const float* b, const float* slope, float* y, int n, int in, int out,
-                     hipStream_t s) {
-    const long long total = (long long)n * out;
-    if (total <= 0) return;
-    hipLaunchKernelGGL(mt_dense_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, b, slope, y, n, in, out);
-}
-
-__global__ __launch_bounds__(256) void mt_softmax_face_kernel(const float* __restrict__ z, float* __restrict__ p, long long n) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    const float z0 = z[2 * t], z1 = z[2 * t + 1];
-    const float m = fmaxf(z0, z1);
-    const float e0 = expf(z0 - m), e1 = expf(z1 - m);
-    p[t] = e1 / (e0 + e1);
-}
-
-void launch_mt_softmax_face(const float* z, float* p, long long n, hipStream_t s) {
+void launch_mt_heads(const float* f, const float* w1, const float* b1, const float* w2, const float* b2, float* prob, float* reg,
+                     int n, int in, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(mt_softmax_face_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z, p, n);
+    const long long threads = (long long)n * 8;
+    hipLaunchKernelGGL(mt_heads_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, f, w1, b1, w2, b2, prob, reg, n, in);
 }
 
 // extract_face for all crops of a step in two launches (blockIdx.y = crop): the horizontal pass of every crop whose
@@ -610,11 +617,18 @@ void launch_mt_pnet_conv1_pool(const float* x, const float* w_padded, const floa
 // 1.5x the convolution arithmetic (columns 2p+2 / 2p are evaluated by both neighbours).  Weights, bias and slopes are
 // SGPR operands (sload16, one tap ahead): no LDS or VGPR traffic for them.
 // blockIdx.y = channel half: 16 of the 32 output channels per thread (3 waves per SIMD without spills)
+// blockIdx.z = row segment: pooled rows [seg * pseg, (seg + 1) * pseg) - a few hundred windows of a selective cascade are
+// 158 blocks of threads that each walk 46 rows; split in segments the same work is four times as many, shorter walks
+// (the convolution row two segments share is evaluated by both)
 __global__ __launch_bounds__(256, 3) void mt_conv1_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ b, const float* __restrict__ slope,
-                                                               float* __restrict__ y, int n, int ih, int iw, int ph, int pw) {
+                                                               float* __restrict__ y, int n, int ih, int iw, int ph, int pw,
+                                                               int pseg) {
     constexpr int CO = 32, CH = 16;
     const int half = blockIdx.y;
+    const int p0 = blockIdx.z * pseg, p1 = min(p0 + pseg, ph);          // this block's pooled rows
+    if (p0 >= ph) return;
+    const int y_begin = 2 * p0;                                          // first convolution row of the segment (even)
     w += half * CH;
     b += half * CH;
     slope += half * CH;
@@ -634,15 +648,18 @@ __global__ __launch_bounds__(256, 3) void mt_conv1_pool_kernel(const float* __re
     for (int j = 0; j < 5; ++j)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            rows[1][j][c] = xi[col[j] + c];
-            rows[2][j][c] = xi[(size_t)iw * 3 + col[j] + c];
-            nxt[j][c] = xi[(size_t)2 * iw * 3 + col[j] + c];
+            rows[1][j][c] = xi[(size_t)min(y_begin, ih - 1) * iw * 3 + col[j] + c];
+            rows[2][j][c] = xi[(size_t)min(y_begin + 1, ih - 1) * iw * 3 + col[j] + c];
+            nxt[j][c] = xi[(size_t)min(y_begin + 2, ih - 1) * iw * 3 + col[j] + c];
         }
     float m[CH];
 #pragma unroll
     for (int o = 0; o < CH; ++o) m[o] = 0.f;
+    // rows 2 p0 .. 2 p1 close the pooled rows p0 .. p1 - 1 (row 2 p1, if it exists, only completes row p1 - 1); the last
+    // segment runs to the map's end and also writes the clipped last window
+    const int y_end = p1 == ph ? oh : min(2 * p1 + 1, oh);
 #pragma unroll 1
-    for (int yy = 0; yy < oh; ++yy) {
+    for (int yy = y_begin; yy < y_end; ++yy) {
         sf16 wn = sload16<0>(w);
         // the row needed by the NEXT iteration is requested now: a whole row of arithmetic hides its latency (the SQ
         // counters of the version that loaded row y+2 at the top of iteration y showed 69 % of the wave cycles waiting)
@@ -699,7 +716,7 @@ __global__ __launch_bounds__(256, 3) void mt_conv1_pool_kernel(const float* __re
             acc[0][o] = full;
             m[o] = even ? h : full;                         // an even row also opens pooled row yy / 2
         }
-        if (even && yy > 0 && t == tc) {
+        if (even && yy > y_begin && t == tc) {                   // (row y_begin opens the segment's first window: nothing to store)
             float* yp = yo + (size_t)(yy / 2 - 1) * pw * CO;
 #pragma unroll
             for (int o = 0; o < CH; o += 4)
@@ -707,7 +724,7 @@ __global__ __launch_bounds__(256, 3) void mt_conv1_pool_kernel(const float* __re
         }
     }
     // the clipped last window (ceil mode): rows 2(ph-1) .. oh-1 are in m
-    if (t == tc) {
+    if (t == tc && p1 == ph) {
         float* yp = yo + (size_t)(ph - 1) * pw * CO;
 #pragma unroll
         for (int o = 0; o < CH; o += 4) *reinterpret_cast<float4*>(yp + o) = make_float4(m[o], m[o + 1], m[o + 2], m[o + 3]);
@@ -723,8 +740,13 @@ bool launch_mt_conv1_pool(const float* x, const float* w, const float* b, const 
         return false;
     const long long threads = (long long)n * pw;
     if (threads <= 0) return true;
-    hipLaunchKernelGGL(mt_conv1_pool_kernel, dim3((unsigned)((threads + 255) / 256), 2), dim3(256), 0, s, x, w, b, slope, y, n, ih,
-                       iw, ph, pw);
+    // row segments while the launch would not fill the chip otherwise (256 CUs x 3 blocks): up to 4, at least 3 pooled rows each
+    const long long blocks = (threads + 255) / 256 * 2;
+    int segs = (int)std::min<long long>(4, std::max<long long>(1, 768 / std::max<long long>(blocks, 1)));
+    segs = std::max(1, std::min(segs, ph / 3));
+    const int pseg = (ph + segs - 1) / segs;
+    hipLaunchKernelGGL(mt_conv1_pool_kernel, dim3((unsigned)((threads + 255) / 256), 2, (unsigned)((ph + pseg - 1) / pseg)), dim3(256), 0, s,
+                       x, w, b, slope, y, n, ih, iw, ph, pw, pseg);
     return true;
 }
 
