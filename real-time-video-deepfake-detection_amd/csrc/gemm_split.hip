@@ -3,6 +3,7 @@
 #include "gemm_split_impl.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -44,7 +45,11 @@ void launch_split_weights(const float* W, unsigned short* out, int N, int K, hip
                        reinterpret_cast<__bf16*>(out), N, K, Np, Kp, transposed ? 1 : 0);
 }
 
-// Heuristic tile (shapes nobody warmed up): the biggest per-wave pw6 tile that still fills the chip.
+// Heuristic tile (shapes nobody warmed up - e.g. the cascade's R-/O-Net layers, whose row count is the number of
+// windows of the step): the biggest per-wave pw6 tile that still fills the chip; when even that tile leaves the chip
+// under-filled (fewer blocks than CUs) the launch lasts as long as ONE block, so the rule turns around: rounds of
+// resident blocks x (tile area + a fixed per-block prologue / epilogue share) / useful share of the padded width -
+// R-Net's dense4 at 1,193 windows ran as 10 blocks of 128 x 128 on 256 CUs (36 us), now as 152 blocks of 64 x 16 (10 us).
 static S6Tile pick_tile6(int M, int N) {
     const int tiles = (N + 15) / 16;
     S6Tile best = make_tile6(M, N, 1, 1);
@@ -57,6 +62,17 @@ static S6Tile pick_tile6(int M, int N) {
             const double fill = blocks >= 512.0 ? 1.0 : blocks / 512.0;
             const double score = mt * nt * useful * fill * (t.nblocks == 1 ? 1.15 : 1.0);
             if (score > best_score) { best_score = score; best = t; }
+        }
+    if ((long long)best.mblocks * best.nblocks >= 256) return best;
+    double best_cost = 1e300;
+    for (int mt = 1; mt <= 2; ++mt)
+        for (int nt = 1; nt <= 8; ++nt) {
+            const S6Tile t = make_tile6(M, N, mt, nt);
+            const double blocks = (double)t.mblocks * t.nblocks;
+            const double useful = (double)tiles / ((double)t.nblocks * nt);
+            const double rounds = std::max(1.0, std::ceil(blocks / 512.0));
+            const double cost = rounds * (mt * nt + 1.5) / useful;
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = t; }
         }
     return best;
 }
