@@ -205,8 +205,11 @@ int forensics_batch_end(dfd_handle* h, int n, double* prob_out, double* scores_o
 // 160x160 BGR u8 crop at mtcnn_face_dev(h).  tap_* are for parity tests (null otherwise).
 struct MtImage { const uint8_t* src; int h, w; size_t stride; };
 // the same for `n` images of a step at once: faces_out [n][160*160*3] (device), boxes_out [n][5] or null, found [n]
+// defer = true: the step may return before its `found` flags have reached the host (they are all 1 until then); the
+// caller must call mtcnn_collect(h) right after its next stream_sync and before it reads `found`
 int mtcnn_align_batch_device(dfd_handle* h, const MtImage* imgs, int n, uint8_t* faces_out, float* boxes_out, char* found,
-                             const char* tap_name, std::vector<float>* tap, int* tap_dims);
+                             const char* tap_name, std::vector<float>* tap, int* tap_dims, bool defer = false);
+void mtcnn_collect(dfd_handle* h, bool discard = false);      // discard: forget a step whose caller failed before its wait
 int mtcnn_align_device(dfd_handle* h, const uint8_t* img_dev, int hh, int ww, size_t stride, float* box_out, int* found,
                        const char* tap_name, std::vector<float>* tap, int* tap_dims);
 const uint8_t* mtcnn_face_dev(dfd_handle* h);

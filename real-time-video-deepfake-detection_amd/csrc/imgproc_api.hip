@@ -216,6 +216,7 @@ int preprocess_on_device(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww
         launch_clahe(frame_dev, stride, dd, n, (uint8_t*)h->lab_buf.p, (uint8_t*)h->lut_buf.p,
                      (uint8_t*)h->crop_buf.p, h->color, mp, h->stream);
     }
+    mtcnn_collect(h, true);                                  // (a previous call that failed between its cascade and its wait)
     h->crop_valid.assign(n, 1);
     if (h->use_mtcnn && h->mtcnn) {
         // reference deepfake_detection.py:376-380: MTCNN.forward on the (CLAHE'd) crop picks the face window and
@@ -235,7 +236,7 @@ int preprocess_on_device(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww
             fd[i] = CropDesc{0, 0, 160, 160, 0, (size_t)i * 160 * 160 * 3};
         }
         if ((rc = mtcnn_align_batch_device(h, imgs.data(), n, (uint8_t*)h->face_batch.p, nullptr, h->crop_valid.data(), nullptr,
-                                           nullptr, nullptr)))
+                                           nullptr, nullptr, true)))      // flags collected after the caller's stream wait
             return rc;
         if ((rc = mailbox_h2d(h, h->desc_buf.p, fd.data(), n * sizeof(CropDesc)))) return rc;
         launch_crop_norm((const uint8_t*)h->face_batch.p, 160 * 3, nullptr, dd, n, h->in_nchw, false, h->stream);
@@ -322,6 +323,7 @@ int analyze_frame_resident(dfd_handle* h, int stream_id, int hh, int ww, int str
         if ((rc = b0_forward(h, h->in_nchw, m, h->logits, nullptr, nullptr))) return rc;
         DFD_HIP_TRY(h, hipMemcpyAsync(logits_out + start, h->logits, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
         DFD_HIP_TRY(h, stream_sync(h));
+        mtcnn_collect(h);
         for (int i = 0; i < m; ++i)
             if (!h->crop_valid[i]) logits_out[start + i] = NAN;      // MTCNN found no face in this crop
     }
@@ -403,6 +405,7 @@ int dfd_preprocess_crops(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int 
     if ((rc = preprocess_on_device(h, (const uint8_t*)h->frame_buf.p, hh, ww, stride, xywh, n, apply_clahe))) return rc;
     DFD_HIP_TRY(h, hipMemcpyAsync(nchw_out, h->in_nchw, (size_t)n * 3 * 224 * 224 * 4, hipMemcpyDeviceToHost, h->stream));
     DFD_HIP_TRY(h, stream_sync(h));
+    mtcnn_collect(h);
     return DFD_OK;
 }
 
@@ -417,6 +420,7 @@ int dfd_classify_crops(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int st
     if ((rc = b0_forward(h, h->in_nchw, n, h->logits, nullptr, nullptr))) return rc;
     DFD_HIP_TRY(h, hipMemcpyAsync(logits_out, h->logits, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     DFD_HIP_TRY(h, stream_sync(h));
+    mtcnn_collect(h);
     for (int i = 0; i < n; ++i)
         if (!h->crop_valid[i]) logits_out[i] = NAN;      // MTCNN found no face in this crop
     return DFD_OK;

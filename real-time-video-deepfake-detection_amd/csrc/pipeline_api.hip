@@ -73,6 +73,7 @@ int dfd_analyze_batch_device(dfd_handle* h, const uint8_t* frames_dev, int n, in
         if (!lg) return fail(h, DFD_ERR_HIP, "analyze_batch: mailbox allocation failed");
         DFD_HIP_TRY(h, hipGetLastError());
         DFD_HIP_TRY(h, stream_sync(h));
+        mtcnn_collect(h);
         for (int i = 0; i < m; ++i) logits[start + i] = h->crop_valid[i] ? lg[i] : NAN;      // NaN: MTCNN found no face in this crop
     }
     int k = 0;
@@ -162,6 +163,7 @@ int dfd_analyze_stream_batch(dfd_handle* h, int stream_id, int n, const uint8_t*
         if (!lg) return fail(h, DFD_ERR_HIP, "analyze_stream_batch: mailbox allocation failed");
         DFD_HIP_TRY(h, hipGetLastError());
         DFD_HIP_TRY(h, stream_sync(h));
+        mtcnn_collect(h);
         for (int i = 0; i < m; ++i) logits[start + i] = h->crop_valid[i] ? lg[i] : NAN;
     }
     int k = 0;
