@@ -8,7 +8,7 @@
 //   mt_convpx (ragged)               P-Net conv2, conv3 (+ both heads, softmax, candidate compaction)
 //   mt_conv1_pool                    R-/O-Net conv1 + PReLU + MaxPool(3, 2, ceil)
 //   mt_maxpool                       MaxPool2d(k, s, ceil_mode=True) behind the GEMM convolutions
-//   mt_heads                         the 2- / 4-wide heads of R-/O-Net + softmax in one launch (eight lanes per window)
+//   mt_heads                         the 2- / 4-wide heads of R-/O-Net + softmax in one launch (sixteen lanes per window)
 //   mt_extract_h / _v                extract_face of all crops: Pillow's 8-bit fixed-point Image.resize passes
 // Every convolution accumulates its products as fmaf in (ci, ky, kx) order, then + bias, then PReLU - the order a
 // direct convolution over the weight tensor [co][ci][ky][kx] walks.
@@ -73,20 +73,21 @@ void launch_mt_maxpool(const float* x, float* y, int n, int ih, int iw, int c, i
 }
 
 // The two output heads of R-Net / O-Net in ONE launch: face probability = softmax(f . W1 + b1)[1], regression = f . W2 + b2
-// for `n` feature rows f[in] (in = 128 / 256).  Eight lanes share a row: lane l sums the terms c = l, l + 8, ... of all six
-// dot products, three xor-shuffles fold them, lane 0 of the group finishes.  As three launches (a thread per output
+// for `n` feature rows f[in] (in = 128 / 256).  Sixteen lanes share a row: lane l sums the terms c = l, l + 16, ... of all six
+// dot products, four xor-shuffles fold them, lane 0 of the group finishes.  As three launches (a thread per output
 // element walking `in` dependent FMAs, softmax, again) the heads took 36 + 64 us per step for a few hundred windows.
 __global__ __launch_bounds__(256) void mt_heads_kernel(const float* __restrict__ f, const float* __restrict__ w1,
                                                        const float* __restrict__ b1, const float* __restrict__ w2,
                                                        const float* __restrict__ b2, float* __restrict__ prob,
                                                        float* __restrict__ reg, int n, int in) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int l = (int)(t & 7);
-    const long long row = t >> 3;
+    constexpr int LANES = 16;
+    const int l = (int)(t & (LANES - 1));
+    const long long row = t / LANES;
     const long long rc = row < n ? row : (long long)n - 1;     // surplus groups redo the last row (uniform shuffles)
     const float* fp = f + (size_t)rc * in;
     float z0 = 0.f, z1 = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
-    for (int c = l; c < in; c += 8) {
+    for (int c = l; c < in; c += LANES) {
         const float v = fp[c];
         const float2 a = *reinterpret_cast<const float2*>(w1 + (size_t)c * 2);
         const float4 q = *reinterpret_cast<const float4*>(w2 + (size_t)c * 4);
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void mt_heads_kernel(const float* __restrict__
         r0 = fmaf(v, q.x, r0); r1 = fmaf(v, q.y, r1); r2 = fmaf(v, q.z, r2); r3 = fmaf(v, q.w, r3);
     }
 #pragma unroll
-    for (int off = 1; off < 8; off <<= 1) {
+    for (int off = 1; off < LANES; off <<= 1) {
         z0 += __shfl_xor(z0, off); z1 += __shfl_xor(z1, off);
         r0 += __shfl_xor(r0, off); r1 += __shfl_xor(r1, off); r2 += __shfl_xor(r2, off); r3 += __shfl_xor(r3, off);
     }
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void mt_heads_kernel(const float* __restrict__
 void launch_mt_heads(const float* f, const float* w1, const float* b1, const float* w2, const float* b2, float* prob, float* reg,
                      int n, int in, hipStream_t s) {
     if (n <= 0) return;
-    const long long threads = (long long)n * 8;
+    const long long threads = (long long)n * 16;
     hipLaunchKernelGGL(mt_heads_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, f, w1, b1, w2, b2, prob, reg, n, in);
 }
 
