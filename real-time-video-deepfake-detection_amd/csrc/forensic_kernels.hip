@@ -146,12 +146,27 @@ __global__ __launch_bounds__(256) void noise_block_kernel(const uint8_t* __restr
 
 // ---------------------------------------------------------------------------------- JPEG
 // libjpeg integer pipeline per 8x8 block, one thread per block (64 coefficients in registers).
-__constant__ int kLumaQ[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57,
-                               69, 56, 14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64,
-                               81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
-__constant__ int kChromaQ[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99,
-                                 99, 99, 47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
-                                 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+// quantise + dequantise at quality 90 with the divisors as compile-time constants (the tables again as constexpr: after
+// unrolling every `/ dv` is a multiply-shift; with the divisor read from __constant__ memory each of the 64 divisions
+// per block was a ~25-instruction sequence - a quarter of this kernel's instructions)
+template <bool CHROMA>
+__device__ __forceinline__ void jpeg_quant_q90(int* d) {
+    constexpr int L[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57,
+                           69, 56, 14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64,
+                           81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+    constexpr int C[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99,
+                           99, 99, 47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                           99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {                                // quality 90: scale = 200 - 2*90 = 20
+        const int q0 = CHROMA ? C[i] : L[i];
+        int qv = (q0 * 20 + 50) / 100;
+        qv = qv < 1 ? 1 : (qv > 255 ? 255 : qv);
+        const int dv = qv << 3, a = d[i] < 0 ? -d[i] : d[i];
+        const int lev = (a + (dv >> 1)) / dv;
+        d[i] = (d[i] < 0 ? -lev : lev) * qv;                       // quantise, then dequantise
+    }
+}
 
 // (libjpeg fixed-point colour conversion and jfdctint / jidctint passes: jpeg_dct.h, shared with jpeg_decode.hip)
 // blocks 0..1023: Y (32x32 blocks); 1024..1279: Cb (16x16); 1280..1535: Cr
@@ -161,7 +176,6 @@ __global__ __launch_bounds__(64) void jpeg_block_kernel(const uint8_t* __restric
     if (b >= 1536) return;
     const uint8_t* img = bgr + (size_t)blockIdx.y * FPIX * 3;
     int d[64];
-    const int* q;
     uint8_t* dst;
     int dstride;
     if (b < 1024) {
@@ -171,7 +185,6 @@ __global__ __launch_bounds__(64) void jpeg_block_kernel(const uint8_t* __restric
             const uint8_t* p = img + ((by + (i >> 3)) * FS + bx + (i & 7)) * 3;
             d[i] = ycc_y(p[2], p[1], p[0]) - 128;
         }
-        q = kLumaQ;
         dst = yp + (size_t)blockIdx.y * FPIX + by * FS + bx;
         dstride = FS;
     } else {
@@ -189,7 +202,6 @@ __global__ __launch_bounds__(64) void jpeg_block_kernel(const uint8_t* __restric
             }
             d[i] = ((s + ((cx & 1) ? 2 : 1)) >> 2) - 128;          // h2v2_downsample, bias 1,2,1,2,...
         }
-        q = kChromaQ;
         dst = (is_cr ? crp : cbp) + (size_t)blockIdx.y * (FPIX / 4) + by * (FS / 2) + bx;
         dstride = FS / 2;
     }
@@ -197,14 +209,8 @@ __global__ __launch_bounds__(64) void jpeg_block_kernel(const uint8_t* __restric
     for (int r = 0; r < 8; ++r) fdct8<true>(d + 8 * r, 1);
 #pragma unroll
     for (int c = 0; c < 8; ++c) fdct8<false>(d + c, 8);
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {                                // quality 90: scale = 200 - 2*90 = 20
-        int qv = (q[i] * 20 + 50) / 100;
-        qv = qv < 1 ? 1 : (qv > 255 ? 255 : qv);
-        const int dv = qv << 3, a = d[i] < 0 ? -d[i] : d[i];
-        const int lev = (a + (dv >> 1)) / dv;
-        d[i] = (d[i] < 0 ? -lev : lev) * qv;                       // quantise, then dequantise
-    }
+    if (b < 1024) jpeg_quant_q90<false>(d);                     // (wave-uniform: 64-thread blocks, 1024 = 16 x 64)
+    else jpeg_quant_q90<true>(d);
 #pragma unroll
     for (int c = 0; c < 8; ++c) idct8<true>(d + c, 8);
 #pragma unroll
