@@ -576,10 +576,12 @@ __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__
     __shared__ int kept[NMS_TOPK];
     __shared__ int hist[2048];
     __shared__ int n_kept, n_valid, n_sel, cut_bin, cut_above, cut_sub;
+    __shared__ int rows_done[16];                                   // overlap rows finished by each producing wave
     static_assert(MASK_AT + NMS_TOPK * WORDS <= NMS_SORT, "the overlap words live in the sort buffer");
     const int tid = threadIdx.x, img = blockIdx.x, lane = tid & 63;
     const float* pr = prob + (size_t)img * n_priors;
     if (tid == 0) { n_valid = 0; n_sel = 0; n_kept = 0; }
+    if (tid < 16) rows_done[tid] = 0;
     for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
     unsigned long long mine[NMS_SORT / 1024];
     __syncthreads();
@@ -673,54 +675,76 @@ __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__
     // takes a row i, its lanes 64 consecutive j: one box per lane (conflict-free 16-byte LDS reads), one ballot per word.
     // (One thread per (row, word) with a 64-step loop read boxes 1 KB apart from every lane - the same LDS bank - and
     // took 153k of the kernel's 270k cycles.)
+    // The mask and the walk run TOGETHER: waves 1-15 produce the rows in increasing order (wave v: rows v - 1, v + 14, ...)
+    // and publish how many each has finished; wave 0 walks the candidates and waits - inside the workgroup, on LDS words -
+    // only for the eight rows it is about to read.  As two phases behind a barrier they were ~60k + ~65k cycles of a block
+    // that owns one CU; the producers never wait for anything, so the walker's wait always ends.
     unsigned long long* ovl = key + MASK_AT;
     {
         const int wave = tid >> 6;
         const float thr_f = (float)nms_thr;
-        for (int i = wave; i < ncand; i += 16) {
-            const v4f bi = *reinterpret_cast<const v4f*>(cand[i]);
-            const float ai = box_area(cand[i]);
-            for (int w = i >> 6; w < WORDS; ++w) {
-                const int j = w * 64 + lane;
-                const int jc = j < ncand ? j : i;
-                const v4f bj = *reinterpret_cast<const v4f*>(cand[jc]);
-                const float b4[4] = {bj.x, bj.y, bj.z, bj.w};
-                const bool hit = j > i && j < ncand && jaccard_above(bi, ai, bj, box_area(b4), thr_f, nms_thr);
-                const unsigned long long bits = __ballot(hit);
-                if (lane == 0) ovl[i * WORDS + w] = bits;
-            }
-            if (lane < (i >> 6)) ovl[i * WORDS + lane] = 0ull;        // words entirely below the diagonal
-        }
-    }
-    __syncthreads();
-    if (tid < 64) {                                                 // one wave: lane w holds word w of the removed set
-        unsigned long long removed = 0ull;
-        int nk = 0;
-        for (int w = 0; w * 64 < ncand; ++w) {
-            // the word that covers candidates 64 w .. 64 w + 63, wave-uniform (two readlanes: no LDS round trip)
-            unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(removed >> 32), w) << 32) |
-                                     (unsigned)__builtin_amdgcn_readlane((int)(removed & 0xFFFFFFFFull), w);
-            for (int b0 = 0; b0 < 64 && w * 64 + b0 < ncand; b0 += 8) {
-                unsigned long long rows8[8];                        // eight rows requested together: one LDS latency per eight steps
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int i = w * 64 + b0 + e;
-                    rows8[e] = (lane < WORDS && i < ncand) ? ovl[i * WORDS + lane] : 0ull;
+        if (wave > 0) {
+            int done = 0;
+            for (int i = wave - 1; i < ncand; i += 15) {
+                const v4f bi = *reinterpret_cast<const v4f*>(cand[i]);
+                const float ai = box_area(cand[i]);
+                for (int w = i >> 6; w < WORDS; ++w) {
+                    const int j = w * 64 + lane;
+                    const int jc = j < ncand ? j : i;
+                    const v4f bj = *reinterpret_cast<const v4f*>(cand[jc]);
+                    const float b4[4] = {bj.x, bj.y, bj.z, bj.w};
+                    const bool hit = j > i && j < ncand && jaccard_above(bi, ai, bj, box_area(b4), thr_f, nms_thr);
+                    const unsigned long long bits = __ballot(hit);
+                    if (lane == 0) ovl[i * WORDS + w] = bits;
                 }
+                if (lane < (i >> 6)) ovl[i * WORDS + lane] = 0ull;        // words entirely below the diagonal
+                ++done;
+                // the row's words are written (LDS operations of a wave complete in order); publish the count
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(&rows_done[wave], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {                                                    // one wave: lane w holds word w of the removed set
+            unsigned long long removed = 0ull;
+            int nk = 0;
+            for (int w = 0; w * 64 < ncand; ++w) {
+                // the word that covers candidates 64 w .. 64 w + 63, wave-uniform (two readlanes: no LDS round trip)
+                unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(removed >> 32), w) << 32) |
+                                         (unsigned)__builtin_amdgcn_readlane((int)(removed & 0xFFFFFFFFull), w);
+                for (int b0 = 0; b0 < 64 && w * 64 + b0 < ncand; b0 += 8) {
+                    // rows i0 .. i0 + 7 must have been published by their producers (row i: wave i % 15 + 1, its
+                    // (i / 15 + 1)-th row); lane e < 8 checks row i0 + e.  The spin is bounded: a guard against a hang,
+                    // not a code path - producers cannot stall
+                    {
+                        const int i = w * 64 + b0 + (lane & 7);
+                        const bool mine = lane < 8 && i < ncand;
+                        for (int spin = 0; spin < (1 << 22); ++spin) {
+                            const int have = mine ? __hip_atomic_load(&rows_done[i % 15 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+                            if (!__any(mine && have <= i / 15)) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                    unsigned long long rows8[8];                        // eight rows requested together: one LDS latency per eight steps
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int b2 = b0 + e, i = w * 64 + b2;
-                    if (i < ncand && !((cur >> b2) & 1ull)) {       // wave-uniform
-                        if (lane == 0) kept[nk] = i;
-                        ++nk;
-                        removed |= rows8[e];
-                        cur |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(rows8[e] >> 32), w) << 32) |
-                               (unsigned)__builtin_amdgcn_readlane((int)(rows8[e] & 0xFFFFFFFFull), w);
+                    for (int e = 0; e < 8; ++e) {
+                        const int i = w * 64 + b0 + e;
+                        rows8[e] = (lane < WORDS && i < ncand) ? ovl[i * WORDS + lane] : 0ull;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int b2 = b0 + e, i = w * 64 + b2;
+                        if (i < ncand && !((cur >> b2) & 1ull)) {       // wave-uniform
+                            if (lane == 0) kept[nk] = i;
+                            ++nk;
+                            removed |= rows8[e];
+                            cur |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(rows8[e] >> 32), w) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)(rows8[e] & 0xFFFFFFFFull), w);
+                        }
                     }
                 }
             }
+            if (lane == 0) n_kept = nk;
         }
-        if (lane == 0) n_kept = nk;
     }
     __syncthreads();
     const int nk = n_kept < keep_top_k ? n_kept : keep_top_k;
