@@ -533,8 +533,8 @@ __device__ __forceinline__ float jaccard(const float* a, const float* b) {
 //      that holds the top_k-th score, and only the keys at or above it are sorted (round 2 sorted every valid prior:
 //      on a detector with many weak responses that was the full 16384-slot bitonic network, 105 barrier stages);
 //   2. bitonic sort of those (a power of two >= 512), top_k = 400 candidates;
-//   3. greedy NMS as a bitmask: all 400 x 400 overlap tests at once into 400 x 7 64-bit words, then ONE wave walks the
-//      candidates in order with the `removed` set in registers (lane w = word w) - the 400 block-wide barriers of the
+//   3. greedy NMS as a bitmask: all 400 x 400 overlap tests into 400 x 7 64-bit words by 15 waves, WHILE one wave walks
+//      the candidates in order with the `removed` set in registers (lane w = word w; it waits only for the rows it reads next) - the 400 block-wide barriers of the
 //      one-candidate-at-a-time loop were most of the kernel (192 us per 64 frames at VALU 0.01 busy).
 // Same tests on the same values in the same order: rows identical to the round-2 kernel.
 // score -> 2048 linear bins (monotone: p * 2048 is exact), and inside one bin 2048 sub-bins of width 2^-22
