@@ -42,6 +42,30 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     return r;
 }
 
+// N block-wide sums at once: the same shuffle tree and the same wave-order fold per value as block_sum (identical bits),
+// one barrier pair for all of them instead of one per value (fft_band: 7, hsv_stats: 4, sobel_lap: 2 - the barriers were
+// most of what these 256-pixel blocks did after their loads).  Results valid in thread 0.
+template <int NT, int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double* sh) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[j] += __shfl_xor(v[j], off);
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int j = 0; j < N; ++j) sh[(tid >> 6) * N + j] = v[j];
+    __syncthreads();
+    if (tid == 0)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double r = 0.0;
+            for (int i = 0; i < NT / 64; ++i) r += sh[i * N + j];
+            v[j] = r;
+        }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------- gray
 __global__ __launch_bounds__(256) void gray_kernel(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ gray) {
     const size_t i = (size_t)blockIdx.y * FPIX + blockIdx.x * 256 + threadIdx.x;
@@ -82,7 +106,7 @@ __global__ __launch_bounds__(128) void fft256_kernel(const uint8_t* __restrict__
 __global__ __launch_bounds__(128) void fft_band_kernel(const float2* __restrict__ in, double* __restrict__ part,
                                                        const float2* __restrict__ tw) {
     __shared__ float2 x[256];
-    __shared__ double red[2];
+    __shared__ double red[2 * 7];
     const int tid = threadIdx.x, k1 = blockIdx.x;
     const float2* src = in + (size_t)blockIdx.y * FPIX + (size_t)k1 * FS;
     for (int i = tid; i < 256; i += 128) x[__brev((unsigned)i) >> 24] = src[i];
@@ -99,11 +123,10 @@ __global__ __launch_bounds__(128) void fft_band_kernel(const float2* __restrict_
         else if (d2 <= 128 * 128) { acc[5] += m; acc[6] += 1.0; }
     }
     double* p = part + ((size_t)blockIdx.y * FS + k1) * 7;
+    block_sum_n<128, 7>(acc, red);
+    if (tid == 0)
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const double v = block_sum<128>(acc[j], red);
-        if (tid == 0) p[j] = v;
-    }
+        for (int j = 0; j < 7; ++j) p[j] = acc[j];
 }
 
 // --------------------------------------------------------------------------------- noise
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(256) void ela_block_kernel(const uint8_t* __restric
 // partial sums (sum, sum of squares as exact integers).
 __global__ __launch_bounds__(256) void sobel_lap_kernel(const uint8_t* __restrict__ gray, short2* __restrict__ grad,
                                                         double* __restrict__ part) {
-    __shared__ double red[4];
+    __shared__ double red[4 * 2];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * 256 + tid;
     const uint8_t* g = gray + (size_t)blockIdx.y * FPIX;
@@ -273,11 +296,11 @@ __global__ __launch_bounds__(256) void sobel_lap_kernel(const uint8_t* __restric
     const int dx = (c + 2 * f + l) - (a + 2 * d + h), dy = (h + 2 * k + l) - (a + 2 * b + c);
     grad[(size_t)blockIdx.y * FPIX + i] = make_short2((short)dx, (short)dy);
     const int lap = g[r101(y - 1) * FS + x] + g[r101(y + 1) * FS + x] + g[y * FS + r101(x - 1)] + g[y * FS + r101(x + 1)] - 4 * e;
-    const double s1 = block_sum<256>((double)lap, red);
-    const double s2 = block_sum<256>((double)lap * (double)lap, red);
+    double ss[2] = {(double)lap, (double)lap * (double)lap};
+    block_sum_n<256, 2>(ss, red);
     if (tid == 0) {
-        part[((size_t)blockIdx.y * 256 + blockIdx.x) * 2] = s1;
-        part[((size_t)blockIdx.y * 256 + blockIdx.x) * 2 + 1] = s2;
+        part[((size_t)blockIdx.y * 256 + blockIdx.x) * 2] = ss[0];
+        part[((size_t)blockIdx.y * 256 + blockIdx.x) * 2 + 1] = ss[1];
     }
 }
 
@@ -386,7 +409,7 @@ __global__ __launch_bounds__(1024) void canny_hyst_kernel(const uint8_t* __restr
 // --------------------------------------------------------------------------------- colour
 __global__ __launch_bounds__(256) void hsv_stats_kernel(const uint8_t* __restrict__ bgr, double* __restrict__ part,
                                                         unsigned* __restrict__ hue_bits, ColorTables T) {
-    __shared__ double red[4];
+    __shared__ double red[4 * 4];
     __shared__ unsigned bits[6];
     const int tid = threadIdx.x;
     if (tid < 6) bits[tid] = 0;
@@ -402,11 +425,10 @@ __global__ __launch_bounds__(256) void hsv_stats_kernel(const uint8_t* __restric
     atomicOr(&bits[h >> 5], 1u << (h & 31));
     double acc[4] = {(double)s, (double)s * s, (double)v, (double)v * v};
     double* o = part + ((size_t)blockIdx.y * 256 + blockIdx.x) * 4;
+    block_sum_n<256, 4>(acc, red);
+    if (tid == 0)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const double t = block_sum<256>(acc[j], red);
-        if (tid == 0) o[j] = t;
-    }
+        for (int j = 0; j < 4; ++j) o[j] = acc[j];
     __syncthreads();
     if (tid < 6 && bits[tid]) atomicOr(&hue_bits[(size_t)blockIdx.y * 6 + tid], bits[tid]);   // integer OR: order-free
 }
