@@ -402,25 +402,33 @@ def bf16_classify(h, xd, yd, batch, steps, logits_fp32, dw_bytes_bf16):
     return out
 
 
-def late_fusion(h, xd, yd, batch, steps, logits_fp32):
-    """The same fp32 step with option "fuse_late": blocks 6-10 / 12-15 compute their 1x1 expand inside the depthwise
-    launch (whole images per block).  Faster per step, but the launches the roofline object prices
-    then contain the expand's MFMA work: NOT the headline configuration - reported beside it."""
-    h.set_option("fuse_late", 1)
+def separate_late_launches(h, xd, yd, batch, steps, logits_fp32):
+    """The same fp32 step with option "fuse_late" OFF (round 3's headline configuration): blocks 6-15 as expand GEMM +
+    depthwise kernel, the expanded tensor through memory.  Slower per step; its 16 depthwise launches hold no expand work
+    for blocks 6-15, so the SURVEY 8(d) fraction of those launches is higher - reported beside the headline so that both
+    numbers stay comparable across rounds."""
+    h.set_option("fuse_late", 0)
     try:
         h.warmup(batch, 0)
         for _ in range(3):
             h.classify_device(xd.ptr, batch, yd.ptr)
         h.sync()
+        h.set_option("profile_stride", 4)
+        h.profile_begin()
         t0 = time.perf_counter()
         for _ in range(steps):
             h.classify_device(xd.ptr, batch, yd.ptr)
         h.sync()
         dt = time.perf_counter() - t0
+        seen, layers = h.profile_end()
         y = yd.download((batch, 1))
     finally:
-        h.set_option("fuse_late", 0)
+        h.set_option("fuse_late", 1)
+    dw_ms = sum(ms for name, ms in layers if name.endswith(".dw")) / max(seen, 1)
     return {"crops_per_s": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+            "dw_family_ms_per_step": round(dw_ms, 4),
+            "ms_by_kind": {k: round(sum(ms for n_, ms in layers if n_.split(".")[-1] == k) / max(seen, 1), 3)
+                           for k in ("dw", "se", "proj", "exp", "head", "avgpool", "mlp")},
             "max_abs_logit_diff_vs_headline_run": float(np.abs(y - logits_fp32).max())}
 
 
@@ -663,13 +671,26 @@ def main():
     all_ms = sum(ms for _, ms in layers) / max(steps_seen, 1)
     dw_bytes = b0_arch.depthwise_bytes_per_image() * args.batch       # per step = 16 launches
     achieved = dw_bytes / (dw_ms * 1e-3) / 1e9 if dw_ms > 0 else 0.0
-    traffic = None
+    traffic, traffic_stamp, stamp_now = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("dw_hbm_bytes_per_step")
+            tj = json.load(open(tpath))
+            traffic, traffic_stamp = tj.get("dw_hbm_bytes_per_step"), tj.get("stamp")
         except Exception:
             traffic = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        import source_stamp
+
+        stamp_now = source_stamp.stamp()
+    except Exception:
+        stamp_now = None
+    traffic_current = bool(traffic_stamp and stamp_now and
+                           traffic_stamp.get("kernel_sources_sha16") == stamp_now.get("kernel_sources_sha16"))
+    # bytes really moved (PMC) / the same launches' time: what the contract fraction cannot say once a launch carries more
+    # than depthwise work (fused expand: the expanded tensor is never read, so traffic < algorithmic bytes)
+    moved = traffic / (dw_ms * 1e-3) / 1e9 if (traffic and dw_ms > 0) else None
 
     # per depthwise launch: algorithmic bytes of that layer (input + output + k*k*C weights, fp32) / its duration
     per_layer = []
@@ -694,17 +715,28 @@ def main():
                                  "relative); DFD_SPLIT_GEMM=0 runs the same GEMMs on the fp32 MFMA instead"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "dfd::dw_kernel<...> / dfd::mbconv_kernel<...> (the 16 depthwise launches per step; blocks 1-5 compute their 1x1 expand inside the launch)",
+                     # the contract's fraction prices ALGORITHMIC depthwise bytes (25.11 MB per crop) against the 16 launches'
+                     # time; with the expand convs inside those launches (blocks 1-10, 12-15) their time also holds 302 of the
+                     # net's 385 MMAC per crop, so beside it: the bytes the launches really moved (PMC) over the same time
+                     "frac_bytes_moved": round(moved / HBM_PEAK_GBS, 4) if moved else None,
+                     "achieved_bytes_moved": round(moved, 1) if moved else None,
+                     "kernel": "the 16 depthwise launches per step: dfd::stem_dw_kernel (stem + block 0), dfd::mbconv_kernel / "
+                               "mbconv2_kernel (blocks 1-5: 1x1 expand + depthwise), dfd::mbconv_late_kernel (blocks 6-10, 12-15: "
+                               "expand + depthwise of whole images; option fuse_late, default on), dfd::dw_kernel (block 11)",
                      "algorithmic_bytes_per_step": dw_bytes, "ms_per_step": round(dw_ms, 4),
                      "share_of_step": round(dw_ms / all_ms, 4) if all_ms else None,
                      "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                       "profiles/b0_profile_driver.py at this commit; counters cannot be read inside the run)",
+                                       "profiles/b0_profile_driver.py; counters cannot be read inside the run)",
+                     "traffic_stamp": traffic_stamp, "stamp_of_this_run": stamp_now,
+                     "traffic_measured_on_these_kernel_sources": traffic_current,
                      "per_layer": per_layer},
         "kernel_ms_per_step": round(all_ms, 3),
         "parity": {"rows": 8, "max_abs_logit_err_vs_oracle": parity, "tol": 1e-3},
     }
     if rank == 0 and world == 1:
-        out["fuse_late"] = late_fusion(h, xd, yd, args.batch, min(args.steps, 20), logits)
+        out["ms_by_kind"] = {k: round(sum(ms for n_, ms in layers if n_.split(".")[-1] == k) / max(steps_seen, 1), 3)
+                             for k in ("dw", "se", "proj", "exp", "head", "avgpool", "mlp")}
+        out["fuse_late_off"] = separate_late_launches(h, xd, yd, args.batch, min(args.steps, 20), logits)
         out["bf16"] = bf16_classify(h, xd, yd, args.batch, min(args.steps, 20), logits, b0_arch.depthwise_bytes_per_image(2) * args.batch)
     if not args.no_e2e:
         out["e2e"] = e2e_frames(h, rank, dist, local_rank)
@@ -716,7 +748,7 @@ def main():
             if rank == 0:
                 out["config5"] = {"error": "timed out after 240 s (collective set-up?)"}
                 print(json.dumps(out), file=json_out, flush=True)
-            os._exit(0)
+            os._exit(3)                                          # the partial line is out; a wedged run is not a success
 
         guard = threading.Timer(240.0, bail)
         guard.daemon = True

@@ -59,9 +59,9 @@ int dfd_max_batch(const dfd_handle* h);
 /* Tuning switches (results stay within the parity tolerances either way):
  *   "fuse_expand" (default 1, env DFD_FUSE_EXPAND): MBConv blocks 1-5 compute the 1x1 expand conv
  *   inside the depthwise kernel instead of writing the expanded tensor to HBM.
- *   "fuse_late" (default 0, env DFD_FUSE_LATE; needs "fuse_expand"): blocks 6-10 and 12-15 (14 x 14 / 7 x 7 maps) do the
- *   same with whole images per thread block (slightly faster per step, not the configuration the
- *   depthwise roofline is quoted on).
+ *   "fuse_late" (default 1 since round 4, env DFD_FUSE_LATE; needs "fuse_expand"): blocks 6-10 and 12-15 (14 x 14 / 7 x 7
+ *   maps) do the same with whole images per thread block - the faster configuration; 0 = expand
+ *   GEMM and depthwise kernel as separate launches.
  *   "fuse_stem" (default 1, env DFD_FUSE_STEM): the stem conv is computed inside block 0's depthwise
  *   kernel (the 112x112x32 stem activation stays in LDS).
  *   "split_gemm" (default 1, env DFD_SPLIT_GEMM): 1x1 convs (N >= 16) and the detector's k x k convs run on
@@ -73,7 +73,13 @@ int dfd_max_batch(const dfd_handle* h);
  *   0 = in front of the detector on the main stream.  Same results.
  *   "profile_stride" (default 1): between dfd_b0_profile_begin/end only every k-th forward records events. */
 int dfd_set_option(dfd_handle* h, const char* name, int value);
-/*   "gemm_tile" (default -1): >= 0 forces split-GEMM instance number value % (candidates of the shape) for every
+/*   "fuse_se" (default 0): the squeeze-excite gate is computed by the last-arriving block of each image inside the
+ *   depthwise launch (measured slower than the separate launch: DESIGN.md section 5; kept for the measurement).
+ *   "bf16_activations" (default 0): every classifier activation that reaches HBM is stored as bf16 (arithmetic,
+ *   accumulators, SE pools / gates and the MLP head stay fp32): BASELINE.json configs[3], DESIGN.md section 4a.
+ *   "bf16_weight_planes" (3 or 1, default 3): with bf16 activations, the 1x1 convs multiply against the three exact
+ *   bf16 planes of the fp32 weights (3) or against bf16-rounded weights (1).
+ *   "gemm_tile" (default -1): >= 0 forces split-GEMM instance number value % (candidates of the shape) for every
  *   1x1 / k x k conv - parity tests walk 0 .. dfd_gemm_tile_count()-1 and require identical bits; -1 = the
  *   handle's tile table (measured by dfd_warmup, heuristic for shapes it has not seen). */
 int dfd_gemm_tile_count(void);
@@ -160,8 +166,9 @@ int dfd_tta_augment(dfd_handle* h, const uint8_t* bgr, int height, int width, in
 
 /* crop (reference backend_server.py:160-161 / deepfake_detection.py:612) -> optional CLAHE ->
  * BGR->RGB, bilinear 224x224 (align_corners=False), /255, ImageNet normalise (reference
- * deepfake_detection.py:376,382-389; the MTCNN re-crop at :377 is bypassed).
- * nchw_out: (n,3,224,224) float32. */
+ * deepfake_detection.py:376,382-389).  When the blob carries an MTCNN cascade and option "mtcnn" is on, the re-crop at
+ * :377 runs in between (P-/R-/O-Net, best face resampled to 160x160; a crop without a face gives the zero-filled
+ * face's row here and NaN from the classify entry points).  nchw_out: (n,3,224,224) float32. */
 int dfd_preprocess_crops(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,
                          const int32_t* xywh, int n, int apply_clahe, float* nchw_out);
 
@@ -191,6 +198,10 @@ int dfd_has_detector(const dfd_handle* h);
 /* Number of detections of the last dfd_detect_faces / dfd_analyze_frame call BEFORE the max_out / max_faces cut:
  * `len(faces)` of the reference (backend_server.py:181 reports it while classifying faces[0] only). */
 int dfd_last_detection_count(const dfd_handle* h);
+/* Crops the classifier has been run on since dfd_create (sum of its batch sizes over every entry point).  With the MTCNN
+ * stage on, a crop the cascade rejects is never classified (reference deepfake_detection.py:377-380 returns before the
+ * model runs): a call with n boxes of which k keep a face advances this by k.  Tests read it before / after a call. */
+int dfd_classifier_crop_count(const dfd_handle* h, unsigned long long* total);
 /* One named detector intermediate for parity tests: a layer name of ssd_arch.LAYERS,
  * "<source>.head", "prob", "boxes" (per prior) or "rows" (DetectionOutput: score,x1,y1,x2,y2). */
 int dfd_ssd_tap(dfd_handle* h, const uint8_t* bgr, int height, int width, int stride,

@@ -71,7 +71,11 @@ def main():
         if "dw_kernel" in k or "mbconv" in k or "dw_rows7" in k:             # fused stem/expand + depthwise launches are depthwise launches
             dw_bytes += fe + wr
     here = os.path.dirname(os.path.abspath(__file__))
-    json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {forwards} forwards of batch 256 ({tag})",
+    sys.path.insert(0, here)
+    import source_stamp
+
+    json.dump({"stamp": source_stamp.stamp(),
+               "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, {forwards} forwards of batch 256 ({tag})",
                "correction": "FETCH_SIZE x2 (gfx950), KiB -> bytes", "dw_hbm_bytes_per_step": round(dw_bytes),
                "per_kernel": rows}, open(os.path.join(here, out_json), "w"), indent=1)
     with open(os.path.join(here, f"{tag}_pmc_traffic.md"), "w") as o:

@@ -65,6 +65,7 @@ SIGNATURES = {
                                    C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dfd_has_detector": (C.c_int, [C.c_void_p]),
     "dfd_last_detection_count": (C.c_int, [C.c_void_p]),
+    "dfd_classifier_crop_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "dfd_ssd_tap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p,
                               C.c_size_t, C.POINTER(C.c_size_t)]),
     "dfd_has_haar": (C.c_int, [C.c_void_p]),
@@ -550,6 +551,12 @@ class Handle:
             _ptr(xy), _ptr(nf), _ptr(lg), _ptr(fp)))
         boxes = [[tuple(int(v) for v in xy[f, i]) for i in range(nf[f])] for f in range(n)]
         return boxes, [lg[f, : nf[f]].copy() for f in range(n)], (fp if with_forensics else None)
+
+    def classifier_crop_count(self) -> int:
+        """crops the classifier has run on since the handle was created (a crop the MTCNN stage rejects is not one)"""
+        v = C.c_ulonglong(0)
+        self._check(self._lib.dfd_classifier_crop_count(self._p, C.byref(v)))
+        return int(v.value)
 
     def last_detection_count(self) -> int:
         """len(faces) of the last detect_faces / analyze_frame call, before its max_out / max_faces cut"""

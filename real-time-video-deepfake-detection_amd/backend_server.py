@@ -35,6 +35,11 @@ app = Flask(__name__)
 # cv2.imdecode has no request-size notion; Flask would buffer any body.  32 MiB holds a 4K PNG or a 32-frame JPEG batch.
 app.config['MAX_CONTENT_LENGTH'] = 32 << 20
 MAX_BATCH_FRAMES = 32                     # /analyze_batch: frames per request (one lock hold, one device batch)
+# /analyze_batch: pixels per request, summed over the parts' HEADERS before anything is decoded or allocated (a flat
+# 8192 x 8192 JPEG is ~1 MB: 32 of them fit the body limit and would ask for ~13 GB of pinned coefficients).  32 frames
+# of 1080p; the library enforces its own budget too (dfd_common.h kMaxBatchPixels).
+MAX_BATCH_PIXELS = 32 * 1920 * 1088
+MAX_FRAME_PIXELS = 1 << 26                # one part (the GPU JPEG path's own cap; Pillow's bomb guard is of this order)
 
 
 @app.after_request
@@ -70,12 +75,25 @@ def rate_limit(f):
     return decorated
 
 
+def image_size(image_bytes: bytes):
+    """(width, height) from the file's header alone (nothing is decoded), or None."""
+    from PIL import Image
+
+    try:
+        with Image.open(io.BytesIO(image_bytes)) as im:
+            return im.size
+    except Exception:
+        return None
+
+
 def decode_image(image_bytes: bytes):
     """cv2.imdecode(..., IMREAD_COLOR) stand-in: BGR uint8 (H,W,3) or None (reference :139-145)."""
     from PIL import Image
 
     try:
         with Image.open(io.BytesIO(image_bytes)) as im:
+            if im.size[0] * im.size[1] > MAX_FRAME_PIXELS:
+                return None
             rgb = np.asarray(im.convert("RGB"))
     except Exception:
         return None
@@ -175,9 +193,17 @@ def analyze_batch():
             return jsonify({'error': 'No frame provided'}), 400
         if len(files) > MAX_BATCH_FRAMES:
             return jsonify({'error': f'Too many frames in one request ({len(files)} > {MAX_BATCH_FRAMES})'}), 400
+        blobs = [f.read() for f in files]
+        pixels = 0
+        for k, data in enumerate(blobs):                            # headers only: the budget is checked before any decode
+            size = image_size(data)
+            if size is None:
+                return jsonify({'error': f'Invalid image format (frame {k})'}), 400
+            pixels += size[0] * size[1]
+        if pixels > MAX_BATCH_PIXELS:
+            return jsonify({'error': f'Batch too large ({pixels} pixels > {MAX_BATCH_PIXELS})'}), 400
         items = []
-        for k, f in enumerate(files):
-            data = f.read()
+        for k, data in enumerate(blobs):
             if data[:2] == b'\xff\xd8':
                 items.append(data)                                  # decoded on the device
             else:

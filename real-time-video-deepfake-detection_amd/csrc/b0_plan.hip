@@ -22,36 +22,6 @@ int fail(dfd_handle* h, int code, const char* fmt, ...) {
     return code;
 }
 
-bool parse_blob(const void* blob, size_t len, std::map<std::string, Tensor>* out, std::string* err) {
-    const uint8_t* p = static_cast<const uint8_t*>(blob);
-    if (!p || len < 12 || memcmp(p, "DFDW", 4) != 0) { *err = "blob: bad magic"; return false; }
-    uint32_t ver, cnt;
-    memcpy(&ver, p + 4, 4);
-    memcpy(&cnt, p + 8, 4);
-    if (ver != 1) { *err = "blob: unsupported version"; return false; }
-    const size_t esz = 48 + 4 + 16 + 8 + 8;
-    if (12 + (size_t)cnt * esz > len) { *err = "blob: truncated table"; return false; }
-    for (uint32_t i = 0; i < cnt; ++i) {
-        const uint8_t* e = p + 12 + (size_t)i * esz;
-        char name[49];
-        memcpy(name, e, 48);
-        name[48] = 0;
-        Tensor t;
-        memcpy(&t.ndim, e + 48, 4);
-        memcpy(t.dims, e + 52, 16);
-        uint64_t off, nb;
-        memcpy(&off, e + 68, 8);
-        memcpy(&nb, e + 76, 8);
-        if (t.ndim > 4 || off % 4 || nb > len || off > len - nb) { *err = std::string("blob: bad entry ") + name; return false; }
-        t.count = 1;
-        for (uint32_t d = 0; d < t.ndim; ++d) t.count *= t.dims[d];
-        if (t.count * 4 != nb) { *err = std::string("blob: size mismatch for ") + name; return false; }
-        t.host = reinterpret_cast<const float*>(p + off);
-        (*out)[name] = t;
-    }
-    return true;
-}
-
 namespace {
 
 struct Stage { int rep, k, s, e, ci, co; };
@@ -337,6 +307,7 @@ static int b0_forward_t(dfd_handle* h, const float* x, int n, float* logits_dev,
 // that reaches HBM (depthwise / block / expand / head outputs) with fp32 arithmetic and accumulation throughout:
 // BASELINE.json configs[3].  Squeeze-excite pools, gates, the pooled feature vector and the MLP head stay fp32.
 int b0_forward(dfd_handle* h, const float* x, int n, float* logits_dev, B0Tap* tap, B0Prof* prof) {
+    if (n > 0) h->classifier_crops += (unsigned long long)n;
     return h->act_bf16 ? b0_forward_t<bf16_t>(h, x, n, logits_dev, tap, prof)
                        : b0_forward_t<float>(h, x, n, logits_dev, tap, prof);
 }

@@ -196,6 +196,12 @@ int dfd_warmup(dfd_handle* h, int n_crops, int n_frames) {
     return DFD_OK;
 }
 
+int dfd_classifier_crop_count(const dfd_handle* h, unsigned long long* total) {
+    if (!h || !total) return DFD_ERR_ARG;
+    *total = h->classifier_crops;
+    return DFD_OK;
+}
+
 int dfd_gemm_tile_count(void) { return s6_max_candidates(); }
 
 int dfd_tiles_export(dfd_handle* h, char* text_out, size_t capacity, size_t* length) {

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/dfd_hip.h"
+#include "blob_reader.h"
 #include "imgproc_kernels.h"
 
 namespace dfd {
@@ -34,17 +35,7 @@ struct MtcnnState;      // mtcnn_api.hip
 int mtcnn_init(dfd_handle* h);
 void mtcnn_destroy(dfd_handle* h);
 
-struct Tensor {
-    const float* host = nullptr;   // into the caller's blob (valid during dfd_create only)
-    float* dev = nullptr;          // device copy owned by the handle
-    uint32_t ndim = 0;
-    uint32_t dims[4] = {1, 1, 1, 1};
-    size_t count = 0;
-};
-
-// Blob layout written by weights.serialize(): "DFDW" u32 version u32 count, then
-// {char name[48]; u32 ndim; u32 dims[4]; u64 offset; u64 nbytes} entries, then payloads.
-bool parse_blob(const void* blob, size_t len, std::map<std::string, Tensor>* out, std::string* err);
+// Tensor + parse_blob: blob_reader.h (plain C++, also built into the sanitizer harness)
 
 struct B0Block {
     int kernel, stride, expand, c_in, c_out, c_exp, c_se, h_in, h_out, pad_lo;
@@ -59,6 +50,12 @@ struct B0Plan {
     // workspace (floats per image)
     size_t io_floats = 0, exp_floats = 0, dw_floats = 0, pool_floats = 0, gate_floats = 0;
 };
+
+// Pixel budget of ONE batched request (dfd_analyze_stream_batch / jpeg_decode_batch_to): 2^27 = 64 frames of 1080p.  A
+// flat 8192 x 8192 JPEG is ~1 MB, so a 32-part request inside the server's body limit could otherwise ask for 13 GB of
+// pinned coefficients + 6 GB of frames before anything is rejected; the check runs on the parsed headers, before any
+// allocation (the server mirrors it: backend_server.MAX_BATCH_PIXELS).
+constexpr size_t kMaxBatchPixels = (size_t)1 << 27;
 
 // a device buffer that only ever grows (re-allocated outside of steady state)
 struct DevBuf {
@@ -111,6 +108,8 @@ struct dfd_handle {
     dfd::DevBuf frame_buf, lab_buf, crop_buf, lut_buf, desc_buf, u8_out, face_batch;
     int last_detections = 0;             // detections of the last single-frame detector run, before the max_out cut
     std::vector<char> crop_valid;        // per crop of the last preprocess: 0 = the MTCNN stage found no face
+    int n_compact = 0;                   // rows of in_nchw the last preprocess filled (= crops with a face, in crop order, when it compacts)
+    unsigned long long classifier_crops = 0;   // crops b0_forward has been asked for since dfd_create (dfd_classifier_crop_count)
     dfd::ForensicState* forensic = nullptr;   // per-stream temporal state + work buffers
     dfd::FreqState* freq = nullptr;           // compute_frequency_features tables + scratch
     dfd::SsdState* ssd = nullptr;             // detector plan + workspace (null: blob has no detector)
@@ -120,7 +119,8 @@ struct dfd_handle {
     bool use_mtcnn = true;                    // classify paths align each crop with the cascade when the blob has one
     bool fuse_stem = true;               // stem conv computed inside block 0's depthwise kernel
     bool fuse_expand = true;             // MBConv blocks 1-5: expand conv computed inside the depthwise kernel
-    bool fuse_late = false;              // blocks 6-15: expand + depthwise of whole images in one launch (mbconv_late_kernel); see DESIGN section 5
+    bool fuse_late = true;               // blocks 6-10 / 12-15: expand + depthwise of whole images in one launch (mbconv_late_kernel):
+                                         // the faster configuration (round 3: +2.2-2.6 % per step, strictly fewer bytes), default since round 4
     bool fuse_se = false;                // squeeze-excite gate computed by the last block of each image inside the depthwise launch
                                          // (measured slower than the separate launch: DESIGN.md section 5, round 3; kept as an option)
     unsigned* se_counter = nullptr;      // [max_batch] arrival counters of that hand-off (zero between launches)
@@ -181,6 +181,11 @@ int haar_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride
 // frame_offs: per-crop byte offset of its frame inside frame_dev (null = single frame)
 int preprocess_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, const int32_t* xywh, int n,
                    int apply_clahe, const size_t* frame_offs = nullptr);
+// boxes of resident frame(s) -> logits on the host, m <= max_batch: crop / CLAHE / MTCNN / 224 x 224, then the classifier
+// at the batch of the crops the cascade KEPT (reference deepfake_detection.py:377-380: `mtcnn()` -> None returns before
+// the model runs) - a rejected crop costs no classifier work and gets NaN.  Ends with a stream wait.
+int classify_boxes(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, const int32_t* xywh, int m,
+                   int apply_clahe, const size_t* frame_offs, float* logits_out);
 // DetectionOutput of `n` frames already resized to 300x300 -> rows/count on the host
 int detect_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, int ww, int stride, size_t frame_bytes,
                      float conf_thr, int max_faces, int32_t* xywh_out, int* n_out, int* n_total_out = nullptr);
@@ -205,11 +210,9 @@ int forensics_batch_end(dfd_handle* h, int n, double* prob_out, double* scores_o
 // 160x160 BGR u8 crop at mtcnn_face_dev(h).  tap_* are for parity tests (null otherwise).
 struct MtImage { const uint8_t* src; int h, w; size_t stride; };
 // the same for `n` images of a step at once: faces_out [n][160*160*3] (device), boxes_out [n][5] or null, found [n]
-// defer = true: the step may return before its `found` flags have reached the host (they are all 1 until then); the
-// caller must call mtcnn_collect(h) right after its next stream_sync and before it reads `found`
+// returns after the step's last stream wait: `found` is final (the classifier is then sized by the faces that are left)
 int mtcnn_align_batch_device(dfd_handle* h, const MtImage* imgs, int n, uint8_t* faces_out, float* boxes_out, char* found,
-                             const char* tap_name, std::vector<float>* tap, int* tap_dims, bool defer = false);
-void mtcnn_collect(dfd_handle* h, bool discard = false);      // discard: forget a step whose caller failed before its wait
+                             const char* tap_name, std::vector<float>* tap, int* tap_dims);
 int mtcnn_align_device(dfd_handle* h, const uint8_t* img_dev, int hh, int ww, size_t stride, float* box_out, int* found,
                        const char* tap_name, std::vector<float>* tap, int* tap_dims);
 const uint8_t* mtcnn_face_dev(dfd_handle* h);

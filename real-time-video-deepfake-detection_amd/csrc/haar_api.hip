@@ -21,6 +21,7 @@
 #include <numeric>
 
 #include "dfd_common.h"
+#include "host_boxes.h"
 
 using namespace dfd;
 
@@ -164,64 +165,6 @@ __global__ __launch_bounds__(64) void haar_collect_kernel(const int* __restrict_
         }
         if (r == 0) ++gx;
     }
-}
-
-struct Rect { int x, y, w, h; };
-
-int cv_round(double v) { return (int)std::nearbyint(v); }            // round half to even, as cvRound
-
-// cv::groupRectangles(rects, group_threshold, eps)
-std::vector<Rect> group_rectangles(const std::vector<Rect>& in, int group_threshold, double eps) {
-    const int n = (int)in.size();
-    if (group_threshold <= 0 || n == 0) return in;
-    std::vector<int> parent(n);
-    std::iota(parent.begin(), parent.end(), 0);
-    auto find = [&](int i) { while (parent[i] != i) { parent[i] = parent[parent[i]]; i = parent[i]; } return i; };
-    auto similar = [&](const Rect& a, const Rect& b) {
-        const double delta = eps * (std::min(a.w, b.w) + std::min(a.h, b.h)) * 0.5;
-        return std::abs(a.x - b.x) <= delta && std::abs(a.y - b.y) <= delta && std::abs(a.x + a.w - b.x - b.w) <= delta &&
-               std::abs(a.y + a.h - b.y - b.h) <= delta;
-    };
-    for (int i = 0; i < n; ++i)
-        for (int j = i + 1; j < n; ++j)
-            if (similar(in[i], in[j])) {
-                const int a = find(i), b = find(j);
-                if (a != b) parent[b] = a;
-            }
-    std::vector<int> label(n, -1);
-    int nclasses = 0;
-    std::vector<int> cls(n);
-    for (int i = 0; i < n; ++i) {                                // classes numbered by first appearance
-        const int r = find(i);
-        if (label[r] < 0) label[r] = nclasses++;
-        cls[i] = label[r];
-    }
-    std::vector<long long> sx(nclasses, 0), sy(nclasses, 0), sw(nclasses, 0), sh(nclasses, 0);
-    std::vector<int> cnt(nclasses, 0);
-    for (int i = 0; i < n; ++i) { sx[cls[i]] += in[i].x; sy[cls[i]] += in[i].y; sw[cls[i]] += in[i].w; sh[cls[i]] += in[i].h; ++cnt[cls[i]]; }
-    std::vector<Rect> mean(nclasses);
-    for (int c = 0; c < nclasses; ++c) {
-        const float s = 1.f / (float)cnt[c];
-        mean[c] = Rect{cv_round((float)sx[c] * s), cv_round((float)sy[c] * s), cv_round((float)sw[c] * s), cv_round((float)sh[c] * s)};
-    }
-    std::vector<Rect> out;
-    for (int i = 0; i < nclasses; ++i) {
-        const Rect& r1 = mean[i];
-        const int n1 = cnt[i];
-        if (n1 <= group_threshold) continue;
-        int j = 0;
-        for (; j < nclasses; ++j) {                              // a small rectangle inside a stronger large one goes
-            const int n2 = cnt[j];
-            if (j == i || n2 <= group_threshold) continue;
-            const Rect& r2 = mean[j];
-            const int dx = cv_round(r2.w * eps), dy = cv_round(r2.h * eps);
-            if (r1.x >= r2.x - dx && r1.y >= r2.y - dy && r1.x + r1.w <= r2.x + r2.w + dx && r1.y + r1.h <= r2.y + r2.h + dy &&
-                (n2 > std::max(3, n1) || n1 < 3))
-                break;
-        }
-        if (j == nclasses) out.push_back(r1);
-    }
-    return out;
 }
 
 }  // namespace

@@ -202,8 +202,10 @@ int stage_crops(dfd_handle* h, int hh, int ww, const int32_t* xywh, int n, size_
 }
 
 // frame already on the device -> normalised NCHW crops in h->in_nchw
+// compact: in_nchw receives only the crops the MTCNN stage kept (h->n_compact rows, crop order); without the stage, or
+// with compact = false, all n rows (a rejected crop's row is then the zero-filled face, as facenet-pytorch never returns)
 int preprocess_on_device(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride,
-                         const int32_t* xywh, int n, int apply_clahe, const size_t* frame_offs = nullptr) {
+                         const int32_t* xywh, int n, int apply_clahe, const size_t* frame_offs = nullptr, bool compact = false) {
     size_t total = 0;
     int mp = 0, rc;
     if ((rc = stage_crops(h, hh, ww, xywh, n, &total, &mp, frame_offs))) return rc;
@@ -216,15 +218,14 @@ int preprocess_on_device(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww
         launch_clahe(frame_dev, stride, dd, n, (uint8_t*)h->lab_buf.p, (uint8_t*)h->lut_buf.p,
                      (uint8_t*)h->crop_buf.p, h->color, mp, h->stream);
     }
-    mtcnn_collect(h, true);                                  // (a previous call that failed between its cascade and its wait)
     h->crop_valid.assign(n, 1);
+    h->n_compact = n;
     if (h->use_mtcnn && h->mtcnn) {
         // reference deepfake_detection.py:376-380: MTCNN.forward on the (CLAHE'd) crop picks the face window and
         // resamples it to 160x160; that image, not the detector crop, feeds the 224x224 bilinear + normalise
         // (:382-389).  All crops of the call go through the cascade together; a crop without a face yields no
         // prediction (NaN logit, `None` upstream).
         if ((rc = ensure(h, &h->face_batch, (size_t)n * 160 * 160 * 3))) return rc;
-        std::vector<CropDesc> fd(n);
         std::vector<MtImage> imgs(n);
         size_t off = 0;
         for (int i = 0; i < n; ++i) {
@@ -233,13 +234,21 @@ int preprocess_on_device(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww
                                              : frame_dev + (frame_offs ? frame_offs[i] : 0) + (size_t)y * stride + (size_t)x * 3;
             imgs[i] = MtImage{img, hgt, w, apply_clahe ? (size_t)w * 3 : (size_t)stride};
             off += ((size_t)w * hgt * 3 + 255) & ~(size_t)255;        // as stage_crops lays the packed crops out
-            fd[i] = CropDesc{0, 0, 160, 160, 0, (size_t)i * 160 * 160 * 3};
         }
+        // the cascade returns after its last stream wait with the per-crop flags (one 32-byte row per crop): what the
+        // 224 x 224 resize and the classifier are sized by.  (Round 3 queued both for all n crops behind the extract
+        // launches and read the flags afterwards: on the bench funnel 72 % of the classifier pass was thrown away.)
         if ((rc = mtcnn_align_batch_device(h, imgs.data(), n, (uint8_t*)h->face_batch.p, nullptr, h->crop_valid.data(), nullptr,
-                                           nullptr, nullptr, true)))      // flags collected after the caller's stream wait
+                                           nullptr, nullptr)))
             return rc;
-        if ((rc = mailbox_h2d(h, h->desc_buf.p, fd.data(), n * sizeof(CropDesc)))) return rc;
-        launch_crop_norm((const uint8_t*)h->face_batch.p, 160 * 3, nullptr, dd, n, h->in_nchw, false, h->stream);
+        std::vector<CropDesc> fd;
+        fd.reserve(n);
+        for (int i = 0; i < n; ++i)
+            if (!compact || h->crop_valid[i]) fd.push_back(CropDesc{0, 0, 160, 160, 0, (size_t)i * 160 * 160 * 3});
+        h->n_compact = (int)fd.size();
+        if (fd.empty()) return DFD_OK;
+        if ((rc = mailbox_h2d(h, h->desc_buf.p, fd.data(), fd.size() * sizeof(CropDesc)))) return rc;
+        launch_crop_norm((const uint8_t*)h->face_batch.p, 160 * 3, nullptr, dd, (int)fd.size(), h->in_nchw, false, h->stream);
         DFD_HIP_TRY(h, hipGetLastError());
         return DFD_OK;
     }
@@ -254,6 +263,23 @@ namespace dfd {
 int preprocess_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, const int32_t* xywh, int n,
                    int apply_clahe, const size_t* frame_offs) {
     return preprocess_on_device(h, frame_dev, hh, ww, stride, xywh, n, apply_clahe, frame_offs);
+}
+
+int classify_boxes(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, const int32_t* xywh, int m,
+                   int apply_clahe, const size_t* frame_offs, float* logits_out) {
+    int rc;
+    if ((rc = preprocess_on_device(h, frame_dev, hh, ww, stride, xywh, m, apply_clahe, frame_offs, true))) return rc;
+    const int k = h->n_compact;
+    const float* lg = nullptr;
+    if (k > 0) {
+        if ((rc = b0_forward(h, h->in_nchw, k, h->logits, nullptr, nullptr))) return rc;
+        lg = (const float*)mailbox_d2h(h, h->logits, (size_t)k * 4);
+        if (!lg) return fail(h, DFD_ERR_HIP, "classify: mailbox allocation failed");
+        DFD_HIP_TRY(h, hipGetLastError());
+    }
+    DFD_HIP_TRY(h, stream_sync(h));
+    for (int i = 0, j = 0; i < m; ++i) logits_out[i] = h->crop_valid[i] ? lg[j++] : NAN;      // NaN: MTCNN found no face in this crop
+    return DFD_OK;
 }
 }  // namespace dfd
 
@@ -319,13 +345,7 @@ int analyze_frame_resident(dfd_handle* h, int stream_id, int hh, int ww, int str
     // reference deepfake_detection.py:611-626; dfd_last_detection_count gives len(faces) when max_faces cut the list)
     for (int start = 0; start < n; start += h->max_batch) {
         const int m = n - start < h->max_batch ? n - start : h->max_batch;
-        if ((rc = preprocess_on_device(h, fd, hh, ww, stride, xywh_out + (size_t)start * 4, m, apply_clahe))) return rc;
-        if ((rc = b0_forward(h, h->in_nchw, m, h->logits, nullptr, nullptr))) return rc;
-        DFD_HIP_TRY(h, hipMemcpyAsync(logits_out + start, h->logits, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
-        DFD_HIP_TRY(h, stream_sync(h));
-        mtcnn_collect(h);
-        for (int i = 0; i < m; ++i)
-            if (!h->crop_valid[i]) logits_out[start + i] = NAN;      // MTCNN found no face in this crop
+        if ((rc = classify_boxes(h, fd, hh, ww, stride, xywh_out + (size_t)start * 4, m, apply_clahe, nullptr, logits_out + start))) return rc;
     }
     return DFD_OK;
 }
@@ -405,7 +425,6 @@ int dfd_preprocess_crops(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int 
     if ((rc = preprocess_on_device(h, (const uint8_t*)h->frame_buf.p, hh, ww, stride, xywh, n, apply_clahe))) return rc;
     DFD_HIP_TRY(h, hipMemcpyAsync(nchw_out, h->in_nchw, (size_t)n * 3 * 224 * 224 * 4, hipMemcpyDeviceToHost, h->stream));
     DFD_HIP_TRY(h, stream_sync(h));
-    mtcnn_collect(h);
     return DFD_OK;
 }
 
@@ -416,13 +435,8 @@ int dfd_classify_crops(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int st
     DFD_HIP_TRY(h, hipSetDevice(h->device));
     int rc = upload_frame(h, bgr, hh, ww, stride);
     if (rc) return rc;
-    if ((rc = preprocess_on_device(h, (const uint8_t*)h->frame_buf.p, hh, ww, stride, xywh, n, apply_clahe))) return rc;
-    if ((rc = b0_forward(h, h->in_nchw, n, h->logits, nullptr, nullptr))) return rc;
-    DFD_HIP_TRY(h, hipMemcpyAsync(logits_out, h->logits, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-    DFD_HIP_TRY(h, stream_sync(h));
-    mtcnn_collect(h);
-    for (int i = 0; i < n; ++i)
-        if (!h->crop_valid[i]) logits_out[i] = NAN;      // MTCNN found no face in this crop
+    if (n <= 0 || n > h->max_batch) return fail(h, n <= 0 ? DFD_ERR_ARG : DFD_ERR_CAPACITY, "classify_crops: %d boxes outside 1..%d", n, h->max_batch);
+    if ((rc = classify_boxes(h, (const uint8_t*)h->frame_buf.p, hh, ww, stride, xywh, n, apply_clahe, nullptr, logits_out))) return rc;
     return DFD_OK;
 }
 

@@ -40,10 +40,6 @@ struct MtcnnState {
     // box bookkeeping on the device (mtcnn_boxes.hip): crop / level tables, counts + prefix arrays + meta words, segmented and
     // compact row / window arenas, per-crop result rows, rows of crop 0 for the parity taps
     DevBuf cnt, rows_a, wins_a, rows_b, wins_b, res, taprows;
-    // a step whose result rows are on their way to the host (mtcnn_collect reads them after the caller's next stream wait)
-    const float* pend_res = nullptr;
-    char* pend_found = nullptr;
-    int pend_n = 0;
 };
 
 void mtcnn_destroy(dfd_handle* h) {
@@ -460,6 +456,10 @@ struct Cascade {
             if ((rc = ensure(h, &S->prob, cells * 4))) return rc;
             if ((rc = ensure(h, &S->reg, cells * 16))) return rc;
             float *in = (float*)S->in.p, *a0 = (float*)S->a0.p, *a1 = (float*)S->a1.p;
+            // conv2's MFMA rows (KR = 32 for 3 x 10 floats) read two floats past a window row; zero weight planes cancel
+            // them - unless they are NaN / Inf, which the last pixel of the last level would pick up from this pad
+            // (fresh from hipMalloc, or R-/O-Net leftovers): 0 x NaN = NaN, and `p >= thr` would drop the cell silently
+            DFD_HIP_TRY(h, hipMemsetAsync((char*)a1 + (size_t)std::max(pre_p.back(), (long long)4) * 4, 0, 64, s));
             launch_mt_area_resize_ragged(d_levels, pre_at(0), nl, pre_in.back(), in, s);
             // candidate list: 16 bytes of counter, then the records
             if ((rc = ensure(h, &S->cand, 16 + (size_t)cells * sizeof(MtCand)))) return rc;
@@ -731,7 +731,7 @@ struct Cascade {
     // (launch sizes of the next network) and one result row per crop at the end - three stream waits, no box on the
     // host.  *done = false: a crop exceeded the blocks' capacity (overflow flag) - nothing was written to the outputs
     // and the caller runs the host path on the P-Net results that are already in HBM.
-    int run_device(uint8_t* faces_out, float* boxes_out, char* found, bool* done, bool defer) {
+    int run_device(uint8_t* faces_out, float* boxes_out, char* found, bool* done) {
         hipStream_t s = h->stream;
         int rc;
         *done = false;
@@ -835,16 +835,6 @@ struct Cascade {
         const float* pr = (const float*)mailbox_d2h(h, S->res.p, (size_t)n * 8 * 4);
         const int* pm = tap_name ? (const int*)mailbox_d2h(h, meta, 12) : nullptr;
         if (!pr || (tap_name && !pm)) return fail(h, DFD_ERR_HIP, "mtcnn: mailbox allocation failed");
-        if (defer && !tap_name && !boxes_out) {
-            // the caller goes on queueing (224 x 224 resize, classifier) and reads `found` after its own stream wait
-            // (mtcnn_collect): the faces are complete in stream order, only the flags are late
-            S->pend_res = pr;
-            S->pend_found = found;
-            S->pend_n = n;
-            for (int i = 0; i < n; ++i) found[i] = 1;
-            *done = true;
-            return DFD_OK;
-        }
         DFD_HIP_TRY(h, stream_sync(h));
         mark("s3 gpu: O-Net + boxes + extract");
         int m3h[3] = {0, 0, pm ? pm[2] : 0};
@@ -933,7 +923,7 @@ int mtcnn_init(dfd_handle* h) {
 // crop written to faces_out + i * 160*160*3 (zero-filled when not found).  found = 0: no face passed the cascade,
 // or the selected box is degenerate (the package raises there and the reference call site returns None).
 int mtcnn_align_batch_device(dfd_handle* h, const MtImage* imgs, int n, uint8_t* faces_out, float* boxes_out, char* found,
-                             const char* tap_name, std::vector<float>* tap, int* tap_dims, bool defer) {
+                             const char* tap_name, std::vector<float>* tap, int* tap_dims) {
     MtcnnState* S = h->mtcnn;
     if (!S || !S->ready) return fail(h, DFD_ERR_STATE, "the weights blob holds no MTCNN cascade");
     for (int i = 0; i < n; ++i)
@@ -946,7 +936,7 @@ int mtcnn_align_batch_device(dfd_handle* h, const MtImage* imgs, int n, uint8_t*
     const char* dv = getenv("DFD_MT_DEVICE_BOXES");
     if (!(dv && atoi(dv) == 0)) {
         bool done = false;
-        if ((rc = c.run_device(faces_out, boxes_out, found, &done, defer))) return rc;
+        if ((rc = c.run_device(faces_out, boxes_out, found, &done))) return rc;
         if (done) return DFD_OK;
     }
     if ((rc = c.run(&boxes))) return rc;
@@ -997,17 +987,6 @@ int mtcnn_align_batch_device(dfd_handle* h, const MtImage* imgs, int n, uint8_t*
     return DFD_OK;
 }
 
-// after the stream wait that follows a deferred step: the crops without a face (no-op when nothing is pending)
-void mtcnn_collect(dfd_handle* h, bool discard) {
-    MtcnnState* S = h->mtcnn;
-    if (!S || !S->pend_res) return;
-    if (!discard)
-        for (int i = 0; i < S->pend_n; ++i) S->pend_found[i] = S->pend_res[(size_t)i * 8] != 0.f;
-    S->pend_res = nullptr;
-    S->pend_found = nullptr;
-    S->pend_n = 0;
-}
-
 int mtcnn_align_device(dfd_handle* h, const uint8_t* img_dev, int hh, int ww, size_t stride, float* box_out, int* found,
                        const char* tap_name, std::vector<float>* tap, int* tap_dims) {
     MtcnnState* S = h->mtcnn;
@@ -1017,7 +996,7 @@ int mtcnn_align_device(dfd_handle* h, const uint8_t* img_dev, int hh, int ww, si
     const MtImage img{img_dev, hh, ww, stride};
     char f = 0;
     float box[5] = {0, 0, 0, 0, 0};
-    if ((rc = mtcnn_align_batch_device(h, &img, 1, (uint8_t*)S->face.p, box, &f, tap_name, tap, tap_dims, false))) return rc;
+    if ((rc = mtcnn_align_batch_device(h, &img, 1, (uint8_t*)S->face.p, box, &f, tap_name, tap, tap_dims))) return rc;
     if (box_out) memcpy(box_out, box, sizeof box);
     *found = f;
     return DFD_OK;

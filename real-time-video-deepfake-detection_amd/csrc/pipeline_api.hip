@@ -66,15 +66,9 @@ int dfd_analyze_batch_device(dfd_handle* h, const uint8_t* frames_dev, int n, in
     std::vector<float> logits(total);
     for (int start = 0; start < total; start += h->max_batch) {
         const int m = std::min(h->max_batch, total - start);
-        if ((rc = preprocess_run(h, frames_dev, hh, ww, stride, boxes.data() + (size_t)start * 4, m, apply_clahe, offs.data() + start)))
+        if ((rc = classify_boxes(h, frames_dev, hh, ww, stride, boxes.data() + (size_t)start * 4, m, apply_clahe, offs.data() + start,
+                                 logits.data() + start)))
             return rc;
-        if ((rc = b0_forward(h, h->in_nchw, m, h->logits, nullptr, nullptr))) return rc;
-        const float* lg = (const float*)mailbox_d2h(h, h->logits, (size_t)m * 4);
-        if (!lg) return fail(h, DFD_ERR_HIP, "analyze_batch: mailbox allocation failed");
-        DFD_HIP_TRY(h, hipGetLastError());
-        DFD_HIP_TRY(h, stream_sync(h));
-        mtcnn_collect(h);
-        for (int i = 0; i < m; ++i) logits[start + i] = h->crop_valid[i] ? lg[i] : NAN;      // NaN: MTCNN found no face in this crop
     }
     int k = 0;
     for (int f = 0; f < n; ++f)
@@ -112,6 +106,9 @@ int dfd_analyze_stream_batch(dfd_handle* h, int stream_id, int n, const uint8_t*
     if (!jp.empty() && (rc = jpeg_decode_batch_to(h, jp.data(), jl.data(), (int)jp.size(), nullptr, &hh, &ww))) return rc;
     if (height_out) *height_out = hh;
     if (width_out) *width_out = ww;
+    if ((size_t)n * (size_t)hh * (size_t)ww > kMaxBatchPixels)         // before any allocation or upload (raw parts too)
+        return fail(h, DFD_ERR_UNSUPPORTED, "analyze_stream_batch: %d frames of %d x %d exceed the %zu-pixel budget of one request", n,
+                    ww, hh, kMaxBatchPixels);
     const int stride = ww * 3;
     const size_t frame_bytes = (size_t)hh * stride;
     if ((rc = ensure(h, &h->stage[0], (size_t)n * frame_bytes))) return rc;
@@ -156,15 +153,9 @@ int dfd_analyze_stream_batch(dfd_handle* h, int stream_id, int n, const uint8_t*
     std::vector<float> logits(ncrops);
     for (int start = 0; start < ncrops; start += h->max_batch) {
         const int m = std::min(h->max_batch, ncrops - start);
-        if ((rc = preprocess_run(h, frames, hh, ww, stride, boxes.data() + (size_t)start * 4, m, apply_clahe, offs.data() + start)))
+        if ((rc = classify_boxes(h, frames, hh, ww, stride, boxes.data() + (size_t)start * 4, m, apply_clahe, offs.data() + start,
+                                 logits.data() + start)))
             return rc;
-        if ((rc = b0_forward(h, h->in_nchw, m, h->logits, nullptr, nullptr))) return rc;
-        const float* lg = (const float*)mailbox_d2h(h, h->logits, (size_t)m * 4);
-        if (!lg) return fail(h, DFD_ERR_HIP, "analyze_stream_batch: mailbox allocation failed");
-        DFD_HIP_TRY(h, hipGetLastError());
-        DFD_HIP_TRY(h, stream_sync(h));
-        mtcnn_collect(h);
-        for (int i = 0; i < m; ++i) logits[start + i] = h->crop_valid[i] ? lg[i] : NAN;
     }
     int k = 0;
     for (int f = 0; f < n; ++f)

@@ -5,6 +5,7 @@
 
 #include "b0_kernels.h"
 #include "dfd_common.h"
+#include "host_boxes.h"
 #include "ssd_kernels.h"
 
 using namespace dfd;
@@ -406,34 +407,6 @@ int ssd_warmup(dfd_handle* h, int n) {
     return ssd_forward(h, (const uint8_t*)h->ssd->in_u8.p, n, nullptr, nullptr, 0, nullptr);
 }
 
-// reference face_detection.py:84-105 on one image's DetectionOutput rows
-int ssd_postprocess(const float* rows, int nrows, int hh, int ww, float conf_thr, int32_t* xywh, float* conf,
-                    int max_out, int* total = nullptr) {
-    int k = 0, all = 0;
-    for (int i = 0; i < nrows; ++i) {
-        const float* r = rows + (size_t)i * 5;
-        if (!(r[0] > conf_thr)) continue;                                   // strict '>'
-        // float32 box * int64 [w,h,w,h] is a float64 product in numpy; astype(int) truncates toward zero
-        long long x1 = (long long)((double)r[1] * ww), y1 = (long long)((double)r[2] * hh);
-        long long x2 = (long long)((double)r[3] * ww), y2 = (long long)((double)r[4] * hh);
-        if (x1 < 0) x1 = 0;
-        if (y1 < 0) y1 = 0;
-        if (x2 > ww) x2 = ww;
-        if (y2 > hh) y2 = hh;
-        const long long bw = x2 - x1, bh = y2 - y1;
-        if (bw > 20 && bh > 20) {
-            ++all;                                                   // every detection counts (len(faces)) ...
-            if (k < max_out) {                                       // ... the first max_out are returned
-                xywh[4 * k] = (int32_t)x1; xywh[4 * k + 1] = (int32_t)y1; xywh[4 * k + 2] = (int32_t)bw; xywh[4 * k + 3] = (int32_t)bh;
-                if (conf) conf[k] = r[0];
-                ++k;
-            }
-        }
-    }
-    if (total) *total = all;
-    return k;
-}
-
 // detector on a frame already in HBM (shared by dfd_detect_faces and dfd_analyze_frame)
 int detect_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stride, float conf_thr, int32_t* xywh_out,
                float* conf_out, int max_out, int* n_out) {
@@ -450,6 +423,7 @@ int detect_run(dfd_handle* h, const uint8_t* frame_dev, int hh, int ww, int stri
     DFD_HIP_TRY(h, hipMemcpyAsync(&cnt, h->ssd->count.p, 4, hipMemcpyDeviceToHost, h->stream));
     DFD_HIP_TRY(h, hipMemcpyAsync(rows, h->ssd->rows.p, sizeof rows, hipMemcpyDeviceToHost, h->stream));
     DFD_HIP_TRY(h, stream_sync(h));
+    if (cnt < 0) return fail(h, DFD_ERR_HIP, "detector: DetectionOutput gave up waiting for its overlap rows (ssd_nms_kernel); no boxes returned");
     *n_out = ssd_postprocess(rows, cnt, hh, ww, conf_thr, xywh_out, conf_out, max_out, &h->last_detections);
     return DFD_OK;
 }
@@ -471,6 +445,9 @@ int detect_batch_run(dfd_handle* h, const uint8_t* frames_dev, int n, int hh, in
     if (!cnt || !rows) return fail(h, DFD_ERR_HIP, "detect_batch: mailbox allocation failed");
     DFD_HIP_TRY(h, hipGetLastError());
     DFD_HIP_TRY(h, stream_sync(h));
+    for (int f = 0; f < n; ++f)
+        if (cnt[f] < 0)
+            return fail(h, DFD_ERR_HIP, "detector: DetectionOutput of frame %d gave up waiting for its overlap rows (ssd_nms_kernel); no boxes returned", f);
     for (int f = 0; f < n; ++f)
         n_out[f] = ssd_postprocess(rows + (size_t)f * SSD_KEEP * 5, cnt[f], hh, ww, conf_thr,
                                    xywh_out + (size_t)f * max_faces * 4, nullptr, max_faces, n_total_out ? n_total_out + f : nullptr);
@@ -517,6 +494,7 @@ int dfd_ssd_tap(dfd_handle* h, const uint8_t* bgr, int hh, int ww, int stride, c
         int cnt = 0;
         DFD_HIP_TRY(h, hipMemcpyAsync(&cnt, h->ssd->count.p, 4, hipMemcpyDeviceToHost, h->stream));
         DFD_HIP_TRY(h, stream_sync(h));
+        if (cnt < 0) return fail(h, DFD_ERR_HIP, "detector: DetectionOutput gave up waiting for its overlap rows (ssd_nms_kernel)");
         if ((size_t)cnt * 5 > capacity) return fail(h, DFD_ERR_ARG, "ssd_tap: capacity");
         DFD_HIP_TRY(h, hipMemcpyAsync(out, h->ssd->rows.p, (size_t)cnt * 20, hipMemcpyDeviceToHost, h->stream));
         DFD_HIP_TRY(h, stream_sync(h));

@@ -8,6 +8,8 @@
 //   ssd_nms_kernel     DetectionOutput: per-image bitonic sort in LDS (score desc, index asc =
 //                      stable), top_k, greedy NMS, keep_top_k
 // The 3x3 / 1x1 trunk and head convolutions run on pw_kernel<NT, true> (b0_kernels.hip).
+#include <cstdlib>
+
 #include "ssd_kernels.h"
 #include "kernel_util.h"
 
@@ -568,7 +570,7 @@ __device__ __forceinline__ void nms_cut(const int* hist, int lane, int above0, i
 
 __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ prob,
                                                        int n_priors, float conf_thr, double nms_thr, int keep_top_k,
-                                                       float* __restrict__ rows, int* __restrict__ count) {
+                                                       float* __restrict__ rows, int* __restrict__ count, int spin_bound) {
     constexpr int WORDS = (NMS_TOPK + 63) / 64, SEL_CAP = 4096, MASK_AT = 512;
     __shared__ unsigned long long key[NMS_SORT];
     __shared__ unsigned long long ckey[NMS_TOPK];
@@ -577,10 +579,11 @@ __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__
     __shared__ int hist[2048];
     __shared__ int n_kept, n_valid, n_sel, cut_bin, cut_above, cut_sub;
     __shared__ int rows_done[16];                                   // overlap rows finished by each producing wave
+    __shared__ int spin_expired;                                    // the walker gave up waiting for a row: count[img] = -1
     static_assert(MASK_AT + NMS_TOPK * WORDS <= NMS_SORT, "the overlap words live in the sort buffer");
     const int tid = threadIdx.x, img = blockIdx.x, lane = tid & 63;
     const float* pr = prob + (size_t)img * n_priors;
-    if (tid == 0) { n_valid = 0; n_sel = 0; n_kept = 0; }
+    if (tid == 0) { n_valid = 0; n_sel = 0; n_kept = 0; spin_expired = 0; }
     if (tid < 16) rows_done[tid] = 0;
     for (int i = tid; i < 2048; i += 1024) hist[i] = 0;
     unsigned long long mine[NMS_SORT / 1024];
@@ -713,15 +716,19 @@ __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__
                 for (int b0 = 0; b0 < 64 && w * 64 + b0 < ncand; b0 += 8) {
                     // rows i0 .. i0 + 7 must have been published by their producers (row i: wave i % 15 + 1, its
                     // (i / 15 + 1)-th row); lane e < 8 checks row i0 + e.  The spin is bounded: a guard against a hang,
-                    // not a code path - producers cannot stall
+                    // not a code path - producers cannot stall.  If the bound ever expires the rows below were NOT
+                    // published: the walk goes on (every wave must reach the barrier) but the image's count becomes -1
+                    // and the host turns that into DFD_ERR_HIP - wrong boxes never leave with rc 0
                     {
                         const int i = w * 64 + b0 + (lane & 7);
                         const bool mine = lane < 8 && i < ncand;
-                        for (int spin = 0; spin < (1 << 22); ++spin) {
+                        bool ready = false;
+                        for (int spin = 0; spin < spin_bound; ++spin) {
                             const int have = mine ? __hip_atomic_load(&rows_done[i % 15 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
-                            if (!__any(mine && have <= i / 15)) break;
+                            if (!__any(mine && have <= i / 15)) { ready = true; break; }
                             __builtin_amdgcn_s_sleep(1);
                         }
+                        if (!ready && lane == 0) spin_expired = 1;
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
                     unsigned long long rows8[8];                        // eight rows requested together: one LDS latency per eight steps
@@ -754,13 +761,16 @@ __global__ __launch_bounds__(1024) void ssd_nms_kernel(const float* __restrict__
         o[0] = __uint_as_float((unsigned)(ckey[i] >> 32));
         o[1] = cand[i][0]; o[2] = cand[i][1]; o[3] = cand[i][2]; o[4] = cand[i][3];
     }
-    if (tid == 0) count[img] = nk;
+    if (tid == 0) count[img] = spin_expired ? -1 : nk;
 }
 
 void launch_ssd_nms(const float* boxes, const float* prob, int n, int n_priors, float conf_thr, double nms_thr,
                     int keep_top_k, float* rows, int* count, hipStream_t s) {
+    // DFD_NMS_SPIN_BOUND: the walker's wait bound in polls (default 2^22 ~ seconds); 0 = "expired at once", the
+    // switch tests/test_ssd_gpu.py uses to prove that an expired wait is reported and not walked over
+    static const int spin_bound = getenv("DFD_NMS_SPIN_BOUND") ? atoi(getenv("DFD_NMS_SPIN_BOUND")) : (1 << 22);
     hipLaunchKernelGGL(ssd_nms_kernel, dim3(n), dim3(1024), 0, s, boxes, prob, n_priors, conf_thr, nms_thr, keep_top_k,
-                       rows, count);
+                       rows, count, spin_bound);
 }
 
 }  // namespace dfd

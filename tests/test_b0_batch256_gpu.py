@@ -95,14 +95,64 @@ def test_analyze_batch_1080p_x64_matches_per_frame_path(big):
 
 
 def test_batch256_late_block_launches_agree_with_the_default_path(big, crops):
-    """Option "fuse_late" at the benchmark's size: blocks 6-10 / 12-15 as whole-image launches.  The expand products are
-    the same six exact bf16 cross terms as in the GEMM, summed in a different order: logits agree to fp32 round-off."""
+    """Option "fuse_late" at the benchmark's size: blocks 6-10 / 12-15 as whole-image launches (the default since round 4)
+    against expand GEMM + depthwise kernel as separate launches (round 3's default).  The expand products are the same
+    six exact bf16 cross terms as in the GEMM, summed in a different order: logits agree to fp32 round-off."""
     x = crops.numpy()
-    base = big.classify(x)
-    big.set_option("fuse_late", 1)
+    late = big.classify(x)
+    big.set_option("fuse_late", 0)
     try:
-        late = big.classify(x)
+        base = big.classify(x)
     finally:
-        big.set_option("fuse_late", 0)
+        big.set_option("fuse_late", 1)
     assert np.all(np.isfinite(late))
     assert float(np.abs(late - base).max()) <= 1e-4
+
+
+def test_config4_one_workload_1080p_x64_forensics_bf16(pkg, big):
+    """BASELINE.json configs[3] / SURVEY 8(d) Config 4 as ONE workload: dfd_analyze_batch_device at
+    64 x 1080p frames with the six forensic signals AND bf16 activation storage, against the fp32 run of the same call.
+    Boxes and forensic probabilities identical (detector, CLAHE and the forensic kernels stay integer / fp32), NaN
+    positions equal, logits within the bf16 statistical bars of tests/test_b0_bf16_gpu.py (rms / p95 / max over the 256
+    crops), and the vote table bench.py prints (`bf16.vote_gate`): flipped votes at the reference's thresholds 0.5 / 0.55
+    and at 32 quantile thresholds - zero wherever no fp32 probability lies within the largest bf16 error of the threshold."""
+    import bench
+
+    H, W, K, N = 1080, 1920, 4, 64
+    rng = np.random.default_rng(7)
+    frames = rng.integers(50, 200, (N, H, W, 3), dtype=np.uint8)
+    for f in range(0, N, 5):                       # structure so that the detector fires on some frames
+        frames[f, 200:200 + 480, 300:300 + 640] = F.natural_like(480, 640, seed=60 + f)
+    forced = [[(200, 150, 320, 400), (900, 300, 256, 256), (1400, 500, 400, 480), (600, 700, 224, 224)]] * N
+    fd = big.alloc(frames.nbytes).upload(frames)
+    try:
+        b32, l32, p32 = big.analyze_batch_device(fd.ptr, N, H, W, forced_boxes=forced, max_faces=K, with_forensics=True)
+        d32, dl32, _ = big.analyze_batch_device(fd.ptr, N, H, W, confidence_threshold=0.3, max_faces=K, with_forensics=True)
+        big.set_option("bf16_activations", 1)
+        big.warmup(256, 0)
+        b16, l16, p16 = big.analyze_batch_device(fd.ptr, N, H, W, forced_boxes=forced, max_faces=K, with_forensics=True)
+        d16, dl16, q16 = big.analyze_batch_device(fd.ptr, N, H, W, confidence_threshold=0.3, max_faces=K, with_forensics=True)
+    finally:
+        big.set_option("bf16_activations", 0)
+        fd.free()
+    assert b16 == b32 and d16 == d32                                   # boxes: bit-exact, bf16 never touches the detector
+    assert sum(len(b) for b in d32) > 0
+    assert np.array_equal(np.asarray(p16), np.asarray(p32)) and np.array_equal(np.asarray(q16), np.asarray(p32))
+    a = np.concatenate([np.asarray(v, np.float32).reshape(-1) for v in l32])
+    b = np.concatenate([np.asarray(v, np.float32).reshape(-1) for v in l16])
+    assert a.size == N * K and np.array_equal(np.isnan(a), np.isnan(b)) and not np.isnan(a).any()
+    e = np.abs(a - b)
+    rms, p95, mx = float(np.sqrt(np.mean(e ** 2))), float(np.quantile(e, 0.95)), float(e.max())
+    print(f"configs[3] joint workload: bf16 vs fp32 logits over {a.size} crops: rms {rms:.2e} p95 {p95:.2e} max {mx:.2e}")
+    assert rms <= 1.6e-2 and p95 <= 3.5e-2 and mx <= 1e-1 and mx > 1e-6
+    for x, y in zip(dl32, dl16):                                       # detected boxes: same bars per crop
+        if len(x):
+            assert float(np.abs(np.asarray(x) - np.asarray(y)).max()) <= 1e-1
+    gate = bench.vote_gate(a, b, frames=a.size)
+    print("threshold flipped_votes flipped_verdict_frames frames_within_bf16_error")
+    for r in gate["per_threshold"]:
+        print(f"  {r['threshold']:.5f} {r['flipped_votes']:3d} {r['flipped_verdict_frames']:3d} {r['frames_within_bf16_error']:3d}")
+        if r["frames_within_bf16_error"] == 0:
+            assert r["flipped_votes"] == 0 and r["flipped_verdict_frames"] == 0, r
+        assert r["flipped_votes"] <= r["frames_within_bf16_error"], r
+    assert gate["per_threshold"][0]["threshold"] == 0.5 and gate["per_threshold"][1]["threshold"] == 0.55

@@ -82,7 +82,7 @@ def test_bf16_late_block_launches_stay_within_the_bf16_bars(pkg, bf16, seeded_sd
                 rel = float(np.abs(got - w).max() / max(1e-6, np.abs(w).max()))
                 assert rel <= 2e-2, f"b{i}.{kind}: {rel:.3e} of max|ref|"
     finally:
-        bf16.set_option("fuse_late", 0)
+        bf16.set_option("fuse_late", 1)                    # the default
         xd.free()
 
 

@@ -34,18 +34,20 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous().numpy() if t.dim() == 4 else t.numpy()
 
 
-@pytest.mark.parametrize("fuse", [0, 1])
+@pytest.mark.parametrize("fuse", [0, 1, 2])
 def test_taps_match_oracle(b0_handle, ref, fuse):
     """fuse=0: every layer as its own kernel (the expand outputs exist and are checked);
-    fuse=1: blocks 1-5 compute expand inside the depthwise kernel (the default)."""
+    fuse=1: blocks 1-5 compute expand inside the depthwise kernel, blocks 6-15 as separate launches (round 3's default);
+    fuse=2: the shipped default - blocks 6-10 / 12-15 too (whole-image launches; only block 11 keeps an expand GEMM)."""
     x, _, taps = ref
     n = x.shape[0]
     xd = b0_handle.alloc(x.nbytes).upload(x)
-    b0_handle.set_option("fuse_expand", fuse)
-    b0_handle.set_option("fuse_stem", fuse)            # fused: the stem tap is a side copy out of the fused kernel
+    b0_handle.set_option("fuse_expand", int(fuse > 0))
+    b0_handle.set_option("fuse_stem", int(fuse > 0))   # fused: the stem tap is a side copy out of the fused kernel
+    b0_handle.set_option("fuse_late", int(fuse == 2))
     names = ["stem"]
     for i in range(16):
-        has_exp = i >= 1 and not (fuse and 1 <= i <= 5)
+        has_exp = i >= 1 and not (fuse and 1 <= i <= 5) and not (fuse == 2 and i != 11)
         names += ([f"b{i}.exp"] if has_exp else []) + [f"b{i}.dw", f"b{i}.gate", f"b{i}.out"]
     names += ["head"]
     worst = {}
@@ -62,6 +64,7 @@ def test_taps_match_oracle(b0_handle, ref, fuse):
             b0_handle.tap(xd.ptr, n, "b1.exp", 10)             # not materialised when fused: loud, not silent
     b0_handle.set_option("fuse_expand", 1)
     b0_handle.set_option("fuse_stem", 1)
+    b0_handle.set_option("fuse_late", 1)
     xd.free()
     print("worst tap errors:", sorted(worst.items(), key=lambda kv: -kv[1])[:5])
 
@@ -91,7 +94,7 @@ def test_late_blocks_in_one_launch_match_oracle(b0_handle, ref):
         for m in (1, 2):                                    # 7 x 7 blocks hold four images: ragged last group
             assert np.abs(b0_handle.classify(x[:m]) - want[:m]).max() <= LOGIT_TOL
     finally:
-        b0_handle.set_option("fuse_late", 0)
+        b0_handle.set_option("fuse_late", 1)               # the default
         xd.free()
 
 

@@ -105,7 +105,9 @@ def test_selective_cascade_batch(pkg, seeded_sd):
         frame = np.random.default_rng(7).integers(50, 200, (2, 1080, 1920, 3), dtype=np.uint8)[0]     # the bench's frame 0
         boxes = np.array([[200, 150, 320, 400], [900, 300, 256, 256], [1400, 500, 400, 480], [600, 700, 224, 224],
                           [100, 600, 300, 300], [1200, 80, 280, 330]], np.int32)
+        before = h.classifier_crop_count()
         got = h.classify_crops(frame, boxes, apply_clahe=True).reshape(-1)
+        assert h.classifier_crop_count() - before == int((~np.isnan(got)).sum())      # rejected crops are never classified
         b0 = W.to_torch(seeded_sd)
         found_want, ambiguous = [], []
         for k, (x, y, w, hh) in enumerate(boxes):
@@ -205,16 +207,27 @@ def test_device_box_logic_at_the_bench_size(pkg, seeded_sd):
         frames = np.random.default_rng(7).integers(50, 200, (n, 1080, 1920, 3), dtype=np.uint8)
         boxes = [[(200, 150, 320, 400), (900, 300, 256, 256), (1400, 500, 400, 480), (600, 700, 224, 224)]] * n
         fd = h.alloc(frames.nbytes).upload(frames)
-        got = {}
+        got, classified = {}, {}
         for flag in ("1", "0"):
             os.environ["DFD_MT_DEVICE_BOXES"] = flag
+            before = h.classifier_crop_count()
             res = h.analyze_batch_device(fd.ptr, n, 1080, 1920, forced_boxes=boxes, max_faces=4)
+            classified[flag] = h.classifier_crop_count() - before
             got[flag] = np.concatenate([np.asarray(l, np.float32).reshape(-1) for l in res[1]])
         os.environ.pop("DFD_MT_DEVICE_BOXES", None)
         assert got["1"].size == 4 * n
         assert np.array_equal(got["1"], got["0"], equal_nan=True)
         found = int((~np.isnan(got["1"])).sum())
         assert 0 < found < 4 * n
+        # reference deepfake_detection.py:377-380: `mtcnn()` -> None returns BEFORE the model runs.  A call with 4 n boxes
+        # of which `found` keep a face runs the classifier at batch `found`, not 4 n (round 3 classified the zero-filled
+        # faces of the rejected crops too and overwrote their logits with NaN afterwards)
+        assert classified == {"1": found, "0": found}, (classified, found)
+        h.set_option("mtcnn", 0)
+        before = h.classifier_crop_count()
+        res = h.analyze_batch_device(fd.ptr, n, 1080, 1920, forced_boxes=boxes, max_faces=4)
+        assert h.classifier_crop_count() - before == 4 * n            # stage off: every box is classified
+        h.set_option("mtcnn", 1)
         fd.free()
     finally:
         os.environ.pop("DFD_MT_DEVICE_BOXES", None)

@@ -79,6 +79,40 @@ def test_decode_image_formats(pkg):
     assert pkg.backend_server.decode_image(b"nope") is None
 
 
+def test_analyze_batch_pixel_budget_is_checked_on_the_headers(client, pkg, monkeypatch):
+    """per-part limits alone let one /analyze_batch request carry 32 flat 8192 x 8192 JPEGs (~1 MB
+    each) = ~13 GB of pinned coefficients + 6 GB of frames, allocated under the detector lock before anything is
+    rejected.  The route sums the parts' header sizes first: over MAX_BATCH_PIXELS -> 400, and neither the decoder nor
+    the detector is touched (works without a GPU for that reason)."""
+    srv = pkg.backend_server
+    flat = np.zeros((4096, 8192), np.uint8)                                    # 33.5 M pixels, ~0.5 MB as a gray JPEG
+    buf = io.BytesIO()
+    Image.fromarray(flat).save(buf, format="JPEG", quality=50)
+    big = buf.getvalue()
+    assert len(big) < 2 << 20 and srv.image_size(big) == (8192, 4096)
+    assert 3 * 8192 * 4096 > srv.MAX_BATCH_PIXELS
+
+    def boom(*a, **k):
+        raise AssertionError("the detector was reached")
+    monkeypatch.setattr(srv.detector, "analyze_request_batch", boom)
+    monkeypatch.setattr(srv.detector, "analyze_request", boom)
+    monkeypatch.setattr(srv, "decode_image", boom)
+    srv._last_request_time = 0.0
+    r = client.post("/analyze_batch", data={"frame": [(io.BytesIO(big), f"f{i}.jpg") for i in range(3)]},
+                    content_type="multipart/form-data")
+    assert r.status_code == 400 and "too large" in r.get_json()["error"].lower()
+    srv._last_request_time = 0.0
+    r = client.post("/analyze_batch", data={"frame": [(io.BytesIO(b"junk"), "f.jpg")]}, content_type="multipart/form-data")
+    assert r.status_code == 400                                                # unreadable header: 400 as before
+
+
+def test_decode_image_refuses_single_giant_parts(pkg):
+    srv = pkg.backend_server
+    buf = io.BytesIO()
+    Image.fromarray(np.zeros((8200, 8200), np.uint8)).save(buf, format="JPEG", quality=30)    # 67.2 M pixels > 2^26
+    assert srv.decode_image(buf.getvalue()) is None
+
+
 # ------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("fmt,name,kw", [("JPEG", "frame.png", {"quality": 85}), ("PNG", "frame.png", {}), ("BMP", "f.bmp", {})])

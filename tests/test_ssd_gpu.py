@@ -84,3 +84,37 @@ def test_guards_and_thresholds(b0_handle):
     assert len(boxes) == len(conf) and np.all(conf > 0.5) and np.all(np.diff(conf) <= 0)
     assert b0_handle.detect_faces(f, 0.5) == b0_handle.detect_faces(f, 0.5)         # deterministic
     assert b0_handle.detect_faces(f, 0.5, max_out=3) == boxes[:3]
+
+
+def test_detection_output_wait_expiry_is_loud():
+    """ssd_nms_kernel's walker waits (bounded) for the overlap rows its producer waves publish.  If that bound ever
+    expired the walk used to go on over unpublished rows and return wrong boxes with rc 0 (ADVICE
+    r3).  DFD_NMS_SPIN_BOUND=0 makes every wait "expire at once": the image's count comes back as -1 and the detector
+    entry points must raise DFD_ERR_HIP (-3) - for one frame, for a batch, and for the rows tap - instead of returning boxes.
+    Own process: the bound is read once per process."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import rtdfd_amd as pkg, frames as F
+W = pkg.weights
+h = pkg._lib.Handle(W.pack_all(W.seeded_state_dict(0), W.seeded_ssd_state_dict(0)), device=0, max_batch=8)
+f = F.face_frame()
+codes = []
+for fn in (lambda: h.detect_faces(f, 0.3), lambda: h.ssd_tap(f, "rows", 200 * 5),
+           lambda: h.analyze_batch_device(h.alloc(f.nbytes).upload(f).ptr, 1, f.shape[0], f.shape[1], max_faces=4)):
+    try:
+        fn()
+        codes.append(0)
+    except pkg._lib.DfdError as e:
+        codes.append(e.code)
+        assert "overlap rows" in str(e), str(e)
+print("codes", codes)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DFD_NMS_SPIN_BOUND="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "codes [-3, -3, -3]" in r.stdout, r.stdout
