@@ -62,6 +62,9 @@ int dfd_max_batch(const dfd_handle* h);
  *   "fuse_late" (default 1 since round 4, env DFD_FUSE_LATE; needs "fuse_expand"): blocks 6-10 and 12-15 (14 x 14 / 7 x 7
  *   maps) do the same with whole images per thread block - the faster configuration; 0 = expand
  *   GEMM and depthwise kernel as separate launches.
+ *   "se_in_proj" (default 0, env DFD_SE_IN_PROJ; measured slower, kept for the measurement): where a depthwise launch leaves final per-image pool sums (the
+ *   whole-image launches of "fuse_late") the projection GEMM's blocks evaluate the squeeze-excite gate themselves
+ *   (se_kernel's arithmetic, identical gate bits) instead of a separate launch per block.
  *   "fuse_stem" (default 1, env DFD_FUSE_STEM): the stem conv is computed inside block 0's depthwise
  *   kernel (the 112x112x32 stem activation stays in LDS).
  *   "split_gemm" (default 1, env DFD_SPLIT_GEMM): 1x1 convs (N >= 16) and the detector's k x k convs run on

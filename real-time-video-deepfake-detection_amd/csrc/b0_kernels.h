@@ -57,6 +57,22 @@ struct ConvGeom {
 bool launch_conv_gemm(const float* X, const float* W, const float* bias, const float* R, float* Y,
                       int n_img, const ConvGeom& g, int Cout, int act, bool res_first, hipStream_t s);
 
+// Squeeze-excite computed by the projection GEMM itself (option "se_in_proj", round 4): every block of the gated 1x1
+// conv first evaluates mean -> FC(c_se) + swish -> FC(C) + sigmoid for the (at most four) images its rows belong to -
+// the arithmetic of se_kernel operation by operation, so the gate bits do not depend on who computes them - writes the
+// gate rows to `gate` and goes on as before.  The 10-12 us se_kernel launch between the depthwise launch and the
+// projection (pure latency: three dependent L2 round trips on an otherwise idle chip, plus a launch gap on either
+// side) disappears for every layer whose pool sums are final per image (tiles == 1: the whole-image launches of
+// blocks 6-10 / 12-15).  P == nullptr: off (`gate` was written by launch_se).
+struct SeFuse {
+    const float* P = nullptr;        // [n][C] final per-image channel sums of the depthwise output
+    const float *w1 = nullptr, *b1 = nullptr, *w2t = nullptr, *b2 = nullptr;
+    float inv_hw = 0.f;
+    int c_se = 0;
+};
+constexpr int SE_FUSE_MAX_IMG = 4;   // images one GEMM block (<= 128 rows) can touch when an image has >= 49 rows
+constexpr int SE_FUSE_MAX_SE = 48;
+
 // Split-precision variants (gemm_split.hip): same contracts, the weight operand is the three-plane bf16 split
 // of W [N][K] written by launch_split_weights (out: 3 * split_weights_count(N, K) bf16, zero-padded planes).
 // fp32-exact products, fp32 accumulate.
@@ -82,7 +98,10 @@ int s6_table_import(S6Table* t, const char* text, size_t len);       // -> entri
 // XT = bf16_t: bf16 activation storage in and out, `planes` = 3 (fp32-exact weights) or 1 (bf16 weights).
 template <typename XT>
 bool launch_pointwise_split(S6Table* tab, const XT* X, const unsigned short* W3, const float* bias, const float* gate,
-                            const XT* R, XT* Y, int M, int K, int N, int HW, int act, int planes, hipStream_t s);
+                            const XT* R, XT* Y, int M, int K, int N, int HW, int act, int planes, hipStream_t s,
+                            const SeFuse* se = nullptr);
+// se usable with this shape: an image is at least 49 rows, so a block of <= 128 rows touches <= SE_FUSE_MAX_IMG images
+inline bool se_fuse_supported(int HW, int c_se) { return HW >= 49 && c_se >= 1 && c_se <= SE_FUSE_MAX_SE; }
 template <typename XT>
 bool launch_conv_gemm_split(S6Table* tab, const XT* X, const unsigned short* W3, const float* bias, const XT* R,
                             XT* Y, int n_img, const ConvGeom& g, int Cout, int act, bool res_first, int planes, hipStream_t s);

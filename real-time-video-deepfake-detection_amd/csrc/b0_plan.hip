@@ -126,14 +126,20 @@ const unsigned short* split_weights(dfd_handle* h, const float* W, int N, int K,
 
 // 1x1 conv.  XT = float: split path when enabled and the shape allows, else the fp32 MFMA kernel.
 // XT = bf16_t ("bf16_activations"): always the split GEMM's bf16-activation instances.
+// does this 1x1 conv run on the split GEMM (the only kernels that can evaluate the squeeze-excite gate themselves)?
+template <typename XT>
+static bool pointwise_on_split(const dfd_handle* h, int K, int N) {
+    return (sizeof(XT) == 2 || h->split_gemm) && N >= 16 && split_gemm_supports(K, N);
+}
+
 template <typename XT>
 int pointwise_t(dfd_handle* h, const XT* X, const float* W, const float* bias, const float* gate, const XT* R,
-                XT* Y, int M, int K, int N, int HW, int act) {
+                XT* Y, int M, int K, int N, int HW, int act, const SeFuse* se = nullptr) {
     constexpr bool BF = sizeof(XT) == 2;
     if ((BF || h->split_gemm) && N >= 16 && split_gemm_supports(K, N)) {       // never on M: batch-invariant results
         const unsigned short* w3 = split_weights(h, W, N, K);
         if (!w3) return DFD_ERR_HIP;
-        if (!launch_pointwise_split<XT>(h->gemm, X, w3, bias, gate, R, Y, M, K, N, HW, act, BF ? h->bf16_planes : 3, h->stream))
+        if (!launch_pointwise_split<XT>(h->gemm, X, w3, bias, gate, R, Y, M, K, N, HW, act, BF ? h->bf16_planes : 3, h->stream, se))
             return fail(h, DFD_ERR_CAPACITY, "1x1 conv M=%d K=%d: one image exceeds the 2^31-byte addressing of the split GEMM", M, K);
     } else {
         if constexpr (BF) return fail(h, DFD_ERR_STATE, "1x1 conv K=%d N=%d has no bf16-activation kernel", K, N);
@@ -271,15 +277,24 @@ static int b0_forward_t(dfd_handle* h, const float* x, int n, float* logits_dev,
             mk.mark(layer_name(bi, "dw"));
         }
         if ((rc = tap_out(h, tap, q + ".dw", dwbuf, (size_t)m_out * b.c_exp))) return rc;
-        if (!se_fused) {
+        // option "se_in_proj": where the depthwise launch left FINAL per-image pool sums (tiles == 1: the whole-image
+        // launches of blocks 6-10 / 12-15) the projection GEMM evaluates the gate itself - no se_kernel launch
+        SeFuse sef;
+        const bool se_in_proj = !se_fused && h->se_in_proj && tiles == 1 && se_fuse_supported(b.h_out * b.h_out, b.c_se) &&
+                                pointwise_on_split<XT>(h, b.c_exp, b.c_out);
+        if (se_in_proj) {
+            sef.P = h->pool; sef.w1 = b.se_w1; sef.b1 = b.se_b1; sef.w2t = b.se_w2; sef.b2 = b.se_b2;
+            sef.inv_hw = 1.0f / (float)(b.h_out * b.h_out); sef.c_se = b.c_se;
+        } else if (!se_fused) {
             launch_se(h->pool, tiles, 1.0f / (float)(b.h_out * b.h_out), b.se_w1, b.se_b1, b.se_w2, b.se_b2,
                       h->gate, n, b.c_exp, b.c_se, s);
             mk.mark(layer_name(bi, "se"));
         }
-        if ((rc = tap_out(h, tap, q + ".gate", h->gate, (size_t)n * b.c_exp))) return rc;
+        if (!se_in_proj && (rc = tap_out(h, tap, q + ".gate", h->gate, (size_t)n * b.c_exp))) return rc;
         if ((rc = pointwise_t<XT>(h, dwbuf, b.proj_w, b.proj_b, h->gate, b.skip ? cur : (const XT*)nullptr, nxt, m_out,
-                                  b.c_exp, b.c_out, b.h_out * b.h_out, ACT_NONE))) return rc;
+                                  b.c_exp, b.c_out, b.h_out * b.h_out, ACT_NONE, se_in_proj ? &sef : nullptr))) return rc;
         mk.mark(layer_name(bi, "proj"));
+        if (se_in_proj && (rc = tap_out(h, tap, q + ".gate", h->gate, (size_t)n * b.c_exp))) return rc;   // written by the GEMM's blocks
         if ((rc = tap_out(h, tap, q + ".out", nxt, (size_t)m_out * b.c_out))) return rc;
         XT* t = cur; cur = nxt; nxt = t;
         ++bi;

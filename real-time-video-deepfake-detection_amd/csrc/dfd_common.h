@@ -123,6 +123,9 @@ struct dfd_handle {
                                          // the faster configuration (round 3: +2.2-2.6 % per step, strictly fewer bytes), default since round 4
     bool fuse_se = false;                // squeeze-excite gate computed by the last block of each image inside the depthwise launch
                                          // (measured slower than the separate launch: DESIGN.md section 5, round 3; kept as an option)
+    bool se_in_proj = false;             // squeeze-excite gate evaluated by the projection GEMM's blocks where the pool sums are final
+                                         // per image (blocks 6-10 / 12-15 with fuse_late): no se_kernel launch there.  Built and
+                                         // measured in round 4: gates bit-identical, step SLOWER - off
     unsigned* se_counter = nullptr;      // [max_batch] arrival counters of that hand-off (zero between launches)
     bool split_gemm = true;              // 1x1 / k x k convs on the bf16x3-split MFMA path (gemm_split.hip)
     bool act_bf16 = false;               // classifier activations stored as bf16 (fp32 arithmetic): configs[3]

@@ -186,19 +186,19 @@ long long s6_chunk_rows(long long M, long long row_bytes, long long HW) {
 template <typename XT, int NP>
 static void s6_measure(bool conv, bool gated, const std::vector<S6Tile>& cands, S6Tile* tile, const S6Key& key, const XT* X,
                        const unsigned short* W3, const float* bias, const float* gate, const XT* R, XT* Y, int M,
-                       int K, int N, int HW, int act, const ConvGeom& g, int res_first, hipStream_t s) {
+                       int K, int N, int HW, int act, const ConvGeom& g, int res_first, hipStream_t s, const SeFuse& se) {
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess) return;
     if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return; }
     float best_ms = 1e30f;
     for (const S6Tile& t : cands) {
-        s6_dispatch_any<XT, NP>(conv, gated, t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
+        s6_dispatch_any<XT, NP>(conv, gated, t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se);
         float ms = 1e30f;
         bool ok = true;
         for (int rep = 0; rep < 2 && ok; ++rep) {          // best of two groups of three: robust to a stray hiccup
             hipEventRecord(e0, s);
             for (int r = 0; r < 3; ++r)
-                s6_dispatch_any<XT, NP>(conv, gated, t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
+                s6_dispatch_any<XT, NP>(conv, gated, t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se);
             hipEventRecord(e1, s);
             float m1 = 0.f;
             ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&m1, e0, e1) == hipSuccess;
@@ -219,7 +219,7 @@ static void s6_measure(bool conv, bool gated, const std::vector<S6Tile>& cands, 
 template <typename XT, int NP>
 static void s6_run_one(S6Table* tab, bool conv, bool gated, const XT* X, const unsigned short* W3, const float* bias,
                        const float* gate, const XT* R, XT* Y, int M, int K, int N, int HW, int act, const ConvGeom& g,
-                       int res_first, hipStream_t s) {
+                       int res_first, hipStream_t s, const SeFuse& se) {
     static const bool tune_env = !(getenv("DFD_S6_TUNE") && atoi(getenv("DFD_S6_TUNE")) == 0);
     S6Tile tile;
     if (tab && tab->force >= 0) {
@@ -234,55 +234,59 @@ static void s6_run_one(S6Table* tab, bool conv, bool gated, const XT* X, const u
             mkey = ((M + (1 << sh) - 1) >> sh) << sh;
         }
         const S6Key key{mkey, K, N, (conv ? 1 : 0) | (gated ? 2 : 0) | (sizeof(XT) == 2 ? 4 : 0) | (NP == 1 ? 8 : 0) |
-                                        (conv ? (g.ksize << 8) | (g.stride << 4) : 0)};
+                                        (se.P ? 16 : 0) | (conv ? (g.ksize << 8) | (g.stride << 4) : 0)};
         const bool tuning = tab && tab->tuning && tune_env;
         auto it = tab ? tab->tiles.find(key) : std::map<S6Key, S6Tile>::iterator();
         if (tab && it != tab->tiles.end() && (it->second.measured || !tuning)) {
             tile = it->second;
         } else {
             tile = pick_tile6(M, N);
-            if (tuning) s6_measure<XT, NP>(conv, gated, s6_candidates(M, K, N), &tile, key, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
+            if (tuning) s6_measure<XT, NP>(conv, gated, s6_candidates(M, K, N), &tile, key, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se);
             if (tab) tab->tiles[key] = tile;
         }
         tile = make_tile(M, N, tile.kind, tile.wm, tile.wn, tile.mt, tile.nt, tile.ks);      // block counts for this call's M
     }
-    s6_dispatch_any<XT, NP>(conv, gated, tile, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
+    s6_dispatch_any<XT, NP>(conv, gated, tile, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se);
 }
 
 template <typename XT>
 static void s6_run_np(int planes, S6Table* tab, bool conv, bool gated, const XT* X, const unsigned short* W3, const float* bias,
                       const float* gate, const XT* R, XT* Y, int M, int K, int N, int HW, int act, const ConvGeom& g,
-                      int res_first, hipStream_t s) {
+                      int res_first, hipStream_t s, const SeFuse& se = SeFuse()) {
     if constexpr (sizeof(XT) == 2) {
         if (planes == 1) {
-            s6_run_one<XT, 1>(tab, conv, gated, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
+            s6_run_one<XT, 1>(tab, conv, gated, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se);
             return;
         }
     }
-    s6_run_one<XT, 3>(tab, conv, gated, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);
+    s6_run_one<XT, 3>(tab, conv, gated, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se);
 }
 
 bool split_gemm_supports(int K, int N) { return K % 8 == 0 && K >= 16 && split_weights_count(N, K) * 6 < (1ull << 31); }
 
 template <typename XT>
 bool launch_pointwise_split(S6Table* tab, const XT* X, const unsigned short* W3, const float* bias, const float* gate,
-                            const XT* R, XT* Y, int M, int K, int N, int HW, int act, int planes, hipStream_t s) {
+                            const XT* R, XT* Y, int M, int K, int N, int HW, int act, int planes, hipStream_t s,
+                            const SeFuse* se) {
     const ConvGeom none{};
     if (HW <= 0) HW = 1;
+    if (se && se->P && (!gate || !se_fuse_supported(HW, se->c_se))) return false;
     const long long chunk = s6_chunk_rows(M, (long long)K * (long long)sizeof(XT), gate ? HW : 1);
     if (chunk <= 0) return false;
     for (long long m0 = 0; m0 < M; m0 += chunk) {
         const int mc = (int)std::min<long long>(chunk, M - m0);
+        SeFuse sec = se ? *se : SeFuse();
+        if (sec.P) sec.P += (size_t)(m0 / HW) * K;               // chunks are whole images
         s6_run_np<XT>(planes, tab, false, gate != nullptr, X + (size_t)m0 * K, W3, bias,
                       gate ? gate + (size_t)(m0 / HW) * K : nullptr, R ? R + (size_t)m0 * N : nullptr, Y + (size_t)m0 * N,
-                      mc, K, N, HW, act, none, 0, s);
+                      mc, K, N, HW, act, none, 0, s, sec);
     }
     return true;
 }
 template bool launch_pointwise_split<float>(S6Table*, const float*, const unsigned short*, const float*, const float*,
-                                            const float*, float*, int, int, int, int, int, int, hipStream_t);
+                                            const float*, float*, int, int, int, int, int, int, hipStream_t, const SeFuse*);
 template bool launch_pointwise_split<bf16_t>(S6Table*, const bf16_t*, const unsigned short*, const float*, const float*,
-                                             const bf16_t*, bf16_t*, int, int, int, int, int, int, hipStream_t);
+                                             const bf16_t*, bf16_t*, int, int, int, int, int, int, hipStream_t, const SeFuse*);
 
 template <typename XT>
 bool launch_conv_gemm_split(S6Table* tab, const XT* X, const unsigned short* W3, const float* bias, const XT* R,

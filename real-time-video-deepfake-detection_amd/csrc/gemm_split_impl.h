@@ -76,6 +76,88 @@ __device__ __forceinline__ bf8 bf16x8_gate(const v4f raw, const v4f g0, const v4
     return x;
 }
 
+// Squeeze-excite gate of the images a block's rows belong to (SeFuse, b0_kernels.h), before the K loop.  se_kernel's
+// arithmetic operation by operation: mean = P * inv_hw; FC1 output o by ONE wave (lane l takes channels l, l + 64, ...
+// as a chain of fmas, then the xor-shuffle tree 32 .. 1), + bias, swish; FC2 channel c by one thread, the c_se terms in
+// order as fmas from the bias; sigmoid.  Which wave or thread takes an output never enters the arithmetic, so every
+// tile and both kernels produce the same gate bits, equal to se_kernel's.  zbuf: 4 x 48 floats of LDS that the K loop
+// overwrites afterwards.  The closing barrier is a workgroup release / acquire: the block's own gate rows (global, L2)
+// are visible to its buffer loads below; other blocks that share an image write the same values.
+template <int NTHR>
+__device__ __forceinline__ void s6_se_gate(const SeFuse& se, float* __restrict__ gate, int C, int HW, int M, int m_first,
+                                           int BM, float* __restrict__ zbuf) {
+    // Everything here is latency: the loops have compile-time trip counts and their loads are issued in batches before
+    // the first use (clamped index, masked VALUE - a load under a runtime condition is issued alone behind its own wait).
+    constexpr int NW = NTHR / 64, NI = SE_FUSE_MAX_IMG, STEPS = 1152 / 64, OG = 6;      // C <= 1152; OG outputs per batch
+    constexpr int OPW = (SE_FUSE_MAX_SE + NW - 1) / NW;                               // FC1 outputs per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m_last = m_first + BM - 1 < M - 1 ? m_first + BM - 1 : M - 1;
+    const int img0 = m_first / HW, nimg = m_last / HW - img0 + 1;          // <= NI (host: se_fuse_supported, BM <= 128)
+    const float* pimg[NI];
+#pragma unroll
+    for (int im = 0; im < NI; ++im) pimg[im] = se.P + (size_t)(img0 + (im < nimg ? im : nimg - 1)) * C;
+    // means of the lane's channels (lane, lane + 64, ...) for every image of the block
+    float mean[NI][STEPS];
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        const int c = lane + 64 * i, cc = c < C ? c : 0;
+#pragma unroll
+        for (int im = 0; im < NI; ++im) mean[im][i] = pimg[im][cc];
+    }
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i)
+#pragma unroll
+        for (int im = 0; im < NI; ++im) mean[im][i] = lane + 64 * i < C ? mean[im][i] * se.inv_hw : 0.f;
+    // FC1: wave w owns outputs w, w + NW, ...; OG of them per batch of loads
+#pragma unroll
+    for (int g0 = 0; g0 < OPW; g0 += OG) {
+        float wv[OG][STEPS];
+#pragma unroll
+        for (int k = 0; k < OG; ++k) {
+            const int o = wave + NW * (g0 + k), oo = o < se.c_se ? o : se.c_se - 1;
+#pragma unroll
+            for (int i = 0; i < STEPS; ++i) {
+                const int c = lane + 64 * i;
+                wv[k][i] = se.w1[(size_t)oo * C + (c < C ? c : 0)];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < OG; ++k) {
+            if (g0 + k >= OPW) continue;
+            const int o = wave + NW * (g0 + k);
+            const float bo = se.b1[o < se.c_se ? o : 0];
+#pragma unroll
+            for (int im = 0; im < NI; ++im) {
+                float v = 0.f;
+#pragma unroll
+                for (int i = 0; i < STEPS; ++i) v = __builtin_fmaf(mean[im][i], wv[k][i], v);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if (lane == 0 && o < se.c_se) zbuf[im * SE_FUSE_MAX_SE + o] = swish1(v + bo);
+            }
+        }
+    }
+    __syncthreads();
+    // FC2: channel c by one thread, all c_se weights of a channel requested before the first use
+    constexpr int CPT = (1152 + NTHR - 1) / NTHR;
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) {
+        const int c = tid + NTHR * r, cc = c < C ? c : 0;
+        float wv[SE_FUSE_MAX_SE];
+#pragma unroll
+        for (int o = 0; o < SE_FUSE_MAX_SE; ++o) wv[o] = se.w2t[(size_t)(o < se.c_se ? o : 0) * C + cc];
+        const float bc = se.b2[cc];
+#pragma unroll
+        for (int im = 0; im < NI; ++im) {
+            float sacc = bc;
+#pragma unroll
+            for (int o = 0; o < SE_FUSE_MAX_SE; ++o) sacc = __builtin_fmaf(o < se.c_se ? zbuf[im * SE_FUSE_MAX_SE + (o < se.c_se ? o : 0)] : 0.f, wv[o], sacc);
+            if (im < nimg && c < C) gate[(size_t)(img0 + im) * C + c] = sigmoid1(sacc);
+        }
+    }
+    __syncthreads();
+}
+
 // The products of one 16x16x32 block, smallest terms first; ONE definition shared by pw6 and pw7 so that every
 // tile of either kernel accumulates each output in the same order (bit-identical results across tiles).
 //   fp32 activations (NXS = 3 terms) x 3 weight planes: the six products with i + j <= 2
@@ -200,7 +282,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && 2 * KS * NT * 16 * S6_ROWB <= 
                                                      const XT* __restrict__ R,
                                                      XT* __restrict__ Y, int M, int K, int N,
                                                      int HW, int act, int mblocks, int nblocks,
-                                                     ConvGeom cg, int res_first, unsigned xbytes, unsigned gbytes) {
+                                                     ConvGeom cg, int res_first, unsigned xbytes, unsigned gbytes, SeFuse se) {
     constexpr int BK = S6_BK;
     constexpr int BN = NT * 16, BM = NW * MT * 16, NTHR = NW * 64;
     constexpr bool PIPE = false;
@@ -222,6 +304,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && 2 * KS * NT * 16 * S6_ROWB <= 
 #ifdef S6_TRACE
     int tp = 0;
 #endif
+    if constexpr (GATE && !CONV) {
+        if (se.P) s6_se_gate<NTHR>(se, const_cast<float*>(gate), K, HW, M, mblk * BM, BM, reinterpret_cast<float*>(&ws[0][0][0]));
+    }
 
     int m[MT];
     size_t gbase[MT];
@@ -483,7 +568,7 @@ __global__ __launch_bounds__(256, (2 * (WM * MT + WN * NT) * 16 * S6_ROWB <= 80 
                                                      const XT* __restrict__ R,
                                                      XT* __restrict__ Y, int M, int K, int N,
                                                      int HW, int act, int mblocks, int nblocks,
-                                                     ConvGeom cg, int res_first, unsigned xbytes, unsigned gbytes) {
+                                                     ConvGeom cg, int res_first, unsigned xbytes, unsigned gbytes, SeFuse se) {
     static_assert(WM * WN == 4, "four waves per block");
     constexpr int BK = S6_BK;
     constexpr int BM = WM * MT * 16, BN = WN * NT * 16;
@@ -502,6 +587,9 @@ __global__ __launch_bounds__(256, (2 * (WM * MT + WN * NT) * 16 * S6_ROWB <= 80 
     const int j = lane & 15, q = lane >> 4;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = mblk * BM, n0 = nblk * BN;
+    if constexpr (GATE && !CONV) {
+        if (se.P) s6_se_gate<256>(se, const_cast<float*>(gate), K, HW, M, m0, BM, reinterpret_cast<float*>(&ws[0][0]));
+    }
 
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W3), 0, 6 * plane, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<XT*>(X), 0, xbytes, 0x00020000);
@@ -710,7 +798,7 @@ inline S6Tile make_tile6(int M, int N, int mt, int nt, int ks = 1) { return make
 template <bool CONV, bool GATE, typename XT, int NP>
 void s6_dispatch(const S6Tile& t, const XT* X, const unsigned short* W3, const float* bias,
                  const float* gate, const XT* R, XT* Y, int M, int K, int N, int HW, int act,
-                 const ConvGeom& g, int res_first, hipStream_t s) {
+                 const ConvGeom& g, int res_first, hipStream_t s, const SeFuse& se) {
     const int grid = ((t.mblocks + 7) / 8) * 8 * t.nblocks;
     const int Kp = (K + S6_KPAD - 1) / S6_KPAD * S6_KPAD, plane = s6_np(N) * Kp;
     const unsigned xbytes = CONV ? (unsigned)((size_t)(M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin * sizeof(XT))
@@ -720,7 +808,7 @@ void s6_dispatch(const S6Tile& t, const XT* X, const unsigned short* W3, const f
 #define DFD_S7_CASE(WMV, WNV, MTV, NTV)                                                                              \
     if (t.wm == WMV && t.wn == WNV && t.mt == MTV && t.nt == NTV) {                                                  \
         hipLaunchKernelGGL((pw7_kernel<WMV, WNV, MTV, NTV, CONV, GATE, XT, NP>), dim3(grid), dim3(256), 0, s, X, W3, plane,  \
-                           Kp, bias, gate, R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes); \
+                           Kp, bias, gate, R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes, se); \
         return;                                                                                                      \
     }
         DFD_S7_CONFIGS(DFD_S7_CASE)
@@ -729,10 +817,10 @@ void s6_dispatch(const S6Tile& t, const XT* X, const unsigned short* W3, const f
     }
 #define DFD_S6_LAUNCH(NTV, MTV, KSV)                                                                                 \
     hipLaunchKernelGGL((pw6_kernel<NTV, CONV, MTV, GATE, KSV, 4, XT, NP>), dim3(grid), dim3(256), 0, s, X, W3, plane, Kp, bias, gate, \
-                       R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes)
+                       R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes, se)
 #define DFD_S6_LAUNCH8(NTV, KSV)                                                                                     \
     hipLaunchKernelGGL((pw6_kernel<NTV, CONV, 1, GATE, KSV, 8, XT, NP>), dim3(grid), dim3(512), 0, s, X, W3, plane, Kp, bias, \
-                       gate, R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes)
+                       gate, R, Y, M, K, N, HW, act, t.mblocks, t.nblocks, g, res_first, xbytes, gbytes, se)
 #define DFD_S6_CASE(NTV)                                        \
     case NTV:                                                   \
         if (t.wm == 8 && t.ks == 2) DFD_S6_LAUNCH8(NTV, 2);     \
@@ -754,16 +842,16 @@ void s6_dispatch(const S6Tile& t, const XT* X, const unsigned short* W3, const f
 template <typename XT, int NP>
 void s6_dispatch_any(bool conv, bool gated, const S6Tile& t, const XT* X, const unsigned short* W3, const float* bias,
                      const float* gate, const XT* R, XT* Y, int M, int K, int N, int HW, int act, const ConvGeom& g,
-                     int res_first, hipStream_t s);
+                     int res_first, hipStream_t s, const SeFuse& se);
 
 #define DFD_S6_INSTANTIATE(XT, NP)                                                                                      \
     template <>                                                                                                         \
     void s6_dispatch_any<XT, NP>(bool conv, bool gated, const S6Tile& t, const XT* X, const unsigned short* W3,         \
                                  const float* bias, const float* gate, const XT* R, XT* Y, int M, int K, int N, int HW, \
-                                 int act, const ConvGeom& g, int res_first, hipStream_t s) {                            \
-        if (conv) s6_dispatch<true, false, XT, NP>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);      \
-        else if (gated) s6_dispatch<false, true, XT, NP>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s); \
-        else s6_dispatch<false, false, XT, NP>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s);          \
+                                 int act, const ConvGeom& g, int res_first, hipStream_t s, const SeFuse& se) {          \
+        if (conv) s6_dispatch<true, false, XT, NP>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se);  \
+        else if (gated) s6_dispatch<false, true, XT, NP>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se); \
+        else s6_dispatch<false, false, XT, NP>(t, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se);      \
     }
 
 }  // namespace dfd

@@ -98,6 +98,34 @@ def test_late_blocks_in_one_launch_match_oracle(b0_handle, ref):
         xd.free()
 
 
+def test_gate_from_the_projection_gemm_equals_se_kernel(b0_handle, ref):
+    """Option "se_in_proj" (default off: measured slower): for the blocks whose depthwise launch leaves final per-image pool sums the
+    projection GEMM's blocks evaluate the squeeze-excite gate themselves.  The arithmetic is se_kernel's operation by
+    operation: gates, block outputs and logits are BIT-identical to the separate-launch path, at batch 3 (one block
+    spans several 7 x 7 images), batch 1 and batch 5, and the gates hold the oracle bar."""
+    x, want, taps = ref
+    n = x.shape[0]
+    xd = b0_handle.alloc(x.nbytes).upload(x)
+    try:
+        got = {}
+        for flag in (1, 0):
+            b0_handle.set_option("se_in_proj", flag)
+            cur = {"logits": b0_handle.classify(x), "l1": b0_handle.classify(x[:1])}
+            for i in range(6, 16):
+                for kind, cnt in (("gate", n * taps[f"b{i}.gate"].numel() // n), ("out", taps[f"b{i}.out"].numel())):
+                    cur[f"b{i}.{kind}"] = b0_handle.tap(xd.ptr, n, f"b{i}.{kind}", cnt).copy()
+            got[flag] = cur
+        for k in got[1]:
+            assert np.array_equal(got[1][k], got[0][k]), k
+        for i in range(6, 16):
+            w = _nhwc(taps[f"b{i}.gate"]).reshape(-1)
+            assert np.abs(got[1][f"b{i}.gate"] - w).max() <= LOGIT_TOL, i
+        assert np.abs(got[1]["logits"] - want).max() <= LOGIT_TOL
+    finally:
+        b0_handle.set_option("se_in_proj", 0)
+        xd.free()
+
+
 def test_fused_and_unfused_logits_agree(b0_handle, ref):
     x, want, _ = ref
     b0_handle.set_option("fuse_expand", 0)
