@@ -79,7 +79,8 @@ static S6Tile pick_tile6(int M, int N) {
 
 // Every instance the library can launch for a shape, in a fixed order (what the tuner measures and what
 // dfd_set_option(h, "gemm_tile", i) indexes): pw6 with 4 waves (KS x MT x NT), pw6 with 8 waves (KS x NT), pw7.
-static std::vector<S6Tile> s6_candidates(int M, int K, int N) {
+// thin: the shape and call may also run pw8 (all of N per wave, weights resident in LDS; s6_thin below) - appended last
+static std::vector<S6Tile> s6_candidates(int M, int K, int N, bool thin = false) {
     const int tiles = (N + 15) / 16;
     std::vector<S6Tile> raw, out;
     for (int ks = 1; ks <= (K > 32 ? 2 : 1); ++ks)
@@ -97,6 +98,8 @@ static std::vector<S6Tile> s6_candidates(int M, int K, int N) {
         out.push_back(t);
     }
     if (out.empty()) out.push_back(make_tile6(M, N, 1, 1));
+    if (thin)
+        for (int bpc : {2, 3, 4, 6, 8, 12, 16, 24}) out.push_back(make_tile(M, N, 2, s8_waves(K), 1, 1, tiles, bpc));      // ks = blocks per CU (grid: dispatcher)
     return out;
 }
 
@@ -154,7 +157,7 @@ int s6_table_import(S6Table* t, const char* text, size_t len) {
                    &v[6], &v[7], &v[8], &v[9]) == 10) {
             // accept only tiles the dispatcher can launch for this shape
             bool known = false;
-            for (const S6Tile& c : s6_candidates(v[0], v[1], v[2]))
+            for (const S6Tile& c : s6_candidates(v[0], v[1], v[2], (v[3] & 128) != 0))
                 known |= c.kind == v[4] && c.wm == v[5] && c.wn == v[6] && c.mt == v[7] && c.nt == v[8] && c.ks == v[9];
             if (known) {
                 S6Tile tile = make_tile(v[0], v[2], v[4], v[5], v[6], v[7], v[8], v[9]);
@@ -221,9 +224,14 @@ static void s6_run_one(S6Table* tab, bool conv, bool gated, const XT* X, const u
                        const float* gate, const XT* R, XT* Y, int M, int K, int N, int HW, int act, const ConvGeom& g,
                        int res_first, hipStream_t s, const SeFuse& se) {
     static const bool tune_env = !(getenv("DFD_S6_TUNE") && atoi(getenv("DFD_S6_TUNE")) == 0);
+    static const bool thin_env = !(getenv("DFD_S6_THIN") && atoi(getenv("DFD_S6_THIN")) == 0);
+    // pw8 takes the call when the whole weight matrix fits its LDS image, a 16-row tile never straddles two images (the
+    // gate row is block-uniform) and nothing but bias / activation / residual happens in the epilogue
+    const bool thin = thin_env && !conv && s8_supports(K, N) && (!gated || (HW % 16 == 0 && M % HW == 0)) && !se.P && act != ACT_PRELU &&
+                      !(R && res_first);
     S6Tile tile;
     if (tab && tab->force >= 0) {
-        const std::vector<S6Tile> cands = s6_candidates(M, K, N);
+        const std::vector<S6Tile> cands = s6_candidates(M, K, N, thin);
         tile = cands[(size_t)tab->force % cands.size()];
     } else {
         // M in 8 buckets per octave: data-dependent row counts (the MTCNN candidate windows) share an entry
@@ -234,14 +242,14 @@ static void s6_run_one(S6Table* tab, bool conv, bool gated, const XT* X, const u
             mkey = ((M + (1 << sh) - 1) >> sh) << sh;
         }
         const S6Key key{mkey, K, N, (conv ? 1 : 0) | (gated ? 2 : 0) | (sizeof(XT) == 2 ? 4 : 0) | (NP == 1 ? 8 : 0) |
-                                        (se.P ? 16 : 0) | (conv ? (g.ksize << 8) | (g.stride << 4) : 0)};
+                                        (se.P ? 16 : 0) | (thin ? 128 : 0) | (conv ? (g.ksize << 8) | (g.stride << 4) : 0)};
         const bool tuning = tab && tab->tuning && tune_env;
         auto it = tab ? tab->tiles.find(key) : std::map<S6Key, S6Tile>::iterator();
         if (tab && it != tab->tiles.end() && (it->second.measured || !tuning)) {
             tile = it->second;
         } else {
             tile = pick_tile6(M, N);
-            if (tuning) s6_measure<XT, NP>(conv, gated, s6_candidates(M, K, N), &tile, key, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se);
+            if (tuning) s6_measure<XT, NP>(conv, gated, s6_candidates(M, K, N, thin), &tile, key, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se);
             if (tab) tab->tiles[key] = tile;
         }
         tile = make_tile(M, N, tile.kind, tile.wm, tile.wn, tile.mt, tile.nt, tile.ks);      // block counts for this call's M

@@ -46,6 +46,9 @@ __device__ long long g_s6_trace[1024];
 #define S6_TP(id) do { } while (0)
 #endif
 
+#ifndef S6_ROW_STORES
+#define S6_ROW_STORES 0                   // 1: pw6 / pw7 epilogues store in row order through LDS (s6_epilogue_rows) - measured, no gain (below)
+#endif
 constexpr int S6_BK = 32;                 // K of one MFMA = one K-step
 constexpr int S6_KPAD = 64;               // weight planes are zero-padded in K to two K-steps (pw6 with KS = 2)
 #ifndef S6_XD
@@ -263,6 +266,68 @@ __device__ __forceinline__ void s6_epilogue(const v4f (&acc)[MT][NT], const int 
     }
 }
 
+// The same epilogue with ROW-ORDER stores (round 4).  An MFMA accumulator leaves lanes 0-15 with 16 different rows, so
+// a store instruction of s6_epilogue writes 16 bytes per lane at a row stride; measured on the narrow projections those
+// stores cost 2.3-4.1 TB/s-equivalent next to loads that stream at 6 TB/s (pw8_kernel below).  Here a wave turns each of
+// its 16-row tiles through `stage` (its own 16 x NT*16 floats of LDS: the block's operand buffers, free after the K
+// loop) and every instruction stores - and reads the residual as - runs of NT*64 contiguous bytes per row with
+// consecutive lanes on consecutive 16 bytes.  Bias, residual and activation are applied on that side with the
+// operations of s6_epilogue in its order: identical bits.  N % 4 == 0 only (callers keep s6_epilogue otherwise).
+// MEASURED (batch 256, all tile / oracle tests green): the projections of blocks 4-15 and the head within +-1 us, block
+// 11's expand (135 MB out) 69 -> 76 us.  In pw6 / pw7 a store instruction already covers 64 contiguous bytes per row and
+// the stores sit behind a K loop that is the launch's time; compiled out (S6_ROW_STORES 0).  pw8 keeps its own form of
+// it: there the stores are a third of the bytes of a launch that is nothing but a stream (-5 %).
+template <int MT, int NT, typename XT>
+__device__ __forceinline__ void s6_epilogue_rows(const v4f (&acc)[MT][NT], float* __restrict__ stage, int mrow0, int nbase0,
+                                                 int lane, const float* __restrict__ bias, const XT* __restrict__ R,
+                                                 XT* __restrict__ Y, int M, int N, int act, int res_first) {
+    constexpr int UPR = 4 * NT;                           // 4-channel units per row of the wave's tile
+    const int j = lane & 15, q = lane >> 4;
+    int row[NT], n[NT];
+    v4f bv[NT], sv[NT];
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+        const int u = 64 * p + lane;
+        row[p] = u / UPR;
+        n[p] = nbase0 + 4 * (u - row[p] * UPR);
+        const int nc = n[p] < N ? n[p] : 0;
+        bv[p] = ldg4(bias + nc);
+        sv[p] = act == ACT_PRELU ? ldg4(bias + N + nc) : (v4f){0.f, 0.f, 0.f, 0.f};      // slopes follow the bias
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        v4f rv[NT];
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            const int m = mrow0 + mt * 16 + row[p], mc = m < M ? m : M - 1, nc = n[p] < N ? n[p] : 0;
+            rv[p] = R ? ld4(R + (size_t)mc * N + nc) : (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) stg4(stage + j * (NT * 16) + nt * 16 + 4 * q, acc[mt][nt]);
+        // LDS operations of one wave execute in issue order; the compiler only has to keep the two groups apart
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            const int m = mrow0 + mt * 16 + row[p];
+            v4f v = ldg4(stage + 4 * (64 * p + lane)) + bv[p];
+            if (res_first) v += rv[p];
+            if (act == ACT_SWISH) v = swish4(v);
+            else if (act == ACT_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            } else if (act == ACT_PRELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * sv[p][r];
+            }
+            if (!res_first) v += rv[p];
+            if (n[p] < N && m < M) st4(Y + (size_t)m * N + n[p], v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // KS = K-steps (MFMA K = 32 each) per LDS stage and barrier: 1, or 2 for half as many handoffs per K
 // PIPE (KS = 1 only): the split of the NEXT K-step's activations is issued between the MFMAs of the current one
 // (sched_group_barrier pattern 1 MFMA : 2 VALU) instead of in front of them.  The s_memtime trace of the plain
@@ -292,7 +357,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && 2 * KS * NT * 16 * S6_ROWB <= 
     static_assert(NP == 3 || (NP == 1 && ESZ == 2), "weight planes: 3 (fp32-exact), or 1 with bf16 activations");
     constexpr int CHUNKS = BN * 4 * NP * KS;              // 16-byte chunks per stage: row x plane x k-octet
     constexpr int WLOADS = (CHUNKS + NTHR - 1) / NTHR;
-    __shared__ __attribute__((aligned(16))) unsigned char ws[2][KS][BN * S6_ROWB];
+    // (the row-order epilogue turns a 16-row tile per wave through this storage: NW x 16 x BN floats)
+    constexpr int WS_STAGE = BN * S6_ROWB, WS_MIN = (NW * 16 * BN * 4 + 2 * KS - 1) / (2 * KS);
+    __shared__ __attribute__((aligned(16))) unsigned char ws[2][KS][WS_STAGE > WS_MIN ? WS_STAGE : (WS_MIN + 15) / 16 * 16];
 
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int mblk = (idx / nblocks) * 8 + xcd, nblk = idx % nblocks;
@@ -543,7 +610,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && 2 * KS * NT * 16 * S6_ROWB <= 
     }
 
     S6_TP(8);
-    s6_epilogue<MT, NT, XT>(acc, m, n0 + 4 * q, bias, R, Y, M, N, act, res_first);
+    if (S6_ROW_STORES && (N & 3) == 0) {                  // every layer of B0 and of the detectors
+        // (the last stage ended with a barrier: no wave still reads the weight buffers)
+        float* stage = reinterpret_cast<float*>(&ws[0][0][0]) + wave * (16 * BN);
+        s6_epilogue_rows<MT, NT, XT>(acc, stage, mblk * BM + wave * (MT * 16), n0, lane, bias, R, Y, M, N, act, res_first);
+    } else {
+        s6_epilogue<MT, NT, XT>(acc, m, n0 + 4 * q, bias, R, Y, M, N, act, res_first);
+    }
     S6_TP(9);
 #ifdef S6_TRACE
     if (K == S6_TRACE_K && N == S6_TRACE_N && blockIdx.x == 8 && threadIdx.x == 0) g_s6_trace[1023] = tp;
@@ -772,13 +845,230 @@ __global__ __launch_bounds__(256, (2 * (WM * MT + WN * NT) * 16 * S6_ROWB <= 80 
     }
     if (kt < nk) step(std::integral_constant<int, 0>{}, kt);
 
-    int m[MT];
+    if (S6_ROW_STORES && (N & 3) == 0) {
+        // (the last step ended with a barrier: the operand tiles are free; a wave needs 16 x NT*16 floats, the weight
+        // buffers hold 2 x WN*NT*16 rows of 192 bytes)
+        float* stage = reinterpret_cast<float*>(&ws[0][0]) + wave * (16 * NT * 16);
+        s6_epilogue_rows<MT, NT, XT>(acc, stage, m0 + wm * MT * 16, n0 + wn * NT * 16, lane, bias, R, Y, M, N, act, res_first);
+    } else {
+        int m[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) m[mt] = m0 + (wm * MT + mt) * 16 + j;
-    s6_epilogue<MT, NT, XT>(acc, m, n0 + wn * NT * 16 + 4 * q, bias, R, Y, M, N, act, res_first);
+        for (int mt = 0; mt < MT; ++mt) m[mt] = m0 + (wm * MT + mt) * 16 + j;
+        s6_epilogue<MT, NT, XT>(acc, m, n0 + wn * NT * 16 + 4 * q, bias, R, Y, M, N, act, res_first);
+    }
 }
 
-// kind 0: pw6 (block = NW waves x MT*16 rows, NT*16 columns; wm = NW); kind 1: pw7 (WM x WN waves of MT x NT tiles)
+// ------------------------------------------------------------------------------------------------------
+// pw8_kernel (round 4): the narrow projections of the large maps (blocks 0-3: K = 32 .. 144, N = 16 .. 40, 0.2 - 3.2 M
+// rows).  These layers are streams - 385-616 MB in and out per 256 crops against 60 MFMAs per 16 rows - and pw6 runs
+// them at 0.45-0.55 of the HBM rate: a block of 64-128 rows pulls the whole weight matrix through L2 -> LDS again,
+// crosses a barrier per K-step for it, keeps one K-step of activations in flight per wave and ends.  Here the weight
+// matrix (all K-steps, three planes, pw6's rotated row image) and the image's squeeze-excite gate are staged in LDS
+// ONCE per block; a wave then walks its 16-row tiles with NO barrier: the whole next tile (every K-step of its rows
+// and its residual fragment) is requested before the current tile is split and multiplied, so a wave has 2-9 KB in
+// flight all the time.  Products, their order and the epilogue arithmetic are pw6's (s6_products, the operations of
+// s6_epilogue): the output bits equal those of every other tile (tests/test_gemm_tiles_gpu.py walks it as a candidate).
+// STORES: an MFMA accumulator leaves lanes 0-15 with 16 different rows, so a store instruction of the plain epilogue
+// writes 16 B per lane at a row stride - measured, those stores ran at 2.3-4.1 TB/s-equivalent while the loads of the
+// same kernel stream at 6 TB/s (no-store build: 92 vs 125 us for K = 144, N = 24).  Here the finished tile goes through a
+// per-wave LDS image of the output rows and leaves as whole 1-KB pieces, 16 consecutive bytes per consecutive lane; the
+// residual is read the same way and added on that side (the last operation of the epilogue either way).
+//   A block takes `tpb` consecutive 16-row tiles of the whole matrix (equal shares: the grid is a small multiple of the
+//   resident blocks, not a function of the image size), wave w the tiles w, w + NW, ... of them (neighbouring waves
+//   stream neighbouring rows).  GATE: HW % 16 == 0, so a tile never straddles two images and its gate row is
+//   wave-uniform; tpb <= tiles per image (tpg), so a block meets at most two images and stages both gate rows.
+template <int NT, int NK, bool GATE, int NW, typename XT, int NP>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : NT * NK <= 10 ? 3 : 2)) void pw8_kernel(const XT* __restrict__ X, const unsigned short* __restrict__ W3, int plane,
+                                                      int Kp, const float* __restrict__ bias, const float* __restrict__ gate,
+                                                      const XT* __restrict__ R, XT* __restrict__ Y, int M, int K, int N,
+                                                      int tpg, int tpb, int act, int res_first, unsigned xbytes) {
+    constexpr int BK = S6_BK, BN = NT * 16, NTHR = NW * 64;
+    constexpr int ESZ = (int)sizeof(XT), XL = ESZ == 4 ? 2 : 1, NXS = ESZ == 4 ? 3 : 1;
+    static_assert(NP == 3 || (NP == 1 && ESZ == 2), "weight planes: 3 (fp32-exact), or 1 with bf16 activations");
+    constexpr int CHUNKS = NK * BN * 4 * NP, WLOADS = (CHUNKS + NTHR - 1) / NTHR;
+    __shared__ __attribute__((aligned(16))) unsigned char ws[NK][BN * S6_ROWB];
+    __shared__ __attribute__((aligned(16))) float gs[2][NK * BK];
+    __shared__ __attribute__((aligned(16))) float os[NW][16 * BN];           // the wave's output tile (fp32), rows N elements apart
+
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int ttot = (M + 15) >> 4;
+    const int t0 = blockIdx.x * tpb, t1 = t0 + tpb < ttot ? t0 + tpb : ttot; // this block's tiles
+    const int img0 = GATE ? t0 / tpg : 0;                                    // first image the block meets
+    const int tsplit = GATE ? (img0 + 1) * tpg : 1 << 30;                    // first tile of the block's second image
+    const int rows_end = M;
+    const int cnt = t0 + wave < t1 ? (t1 - t0 - wave + NW - 1) / NW : 0;     // tiles of this wave
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<XT*>(X), 0, xbytes, 0x00020000);
+    auto ld = [&](int vo, int so) { return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, so, 0)); };
+    // in the last K-step of a K that is not a multiple of 32, lanes past the row end re-read its last 8 values (zero weights)
+    const int over = (NK - 1) * BK + 8 * q - (K - 8);
+    const int koff = ESZ * 8 * q, koff_last = koff - ESZ * (over > 0 ? over : 0);
+    const int nq = 4 * q;
+    auto tile_row = [&](int i) {                                             // row of this lane in the wave's i-th tile (clamped)
+        const int ii = i < cnt ? i : (cnt > 0 ? cnt - 1 : 0);
+        return (t0 + wave + ii * NW) * 16 + j;
+    };
+    // output side: piece p of a tile = its 4-channel units 64 p + lane (row-major over 16 rows x N / 4 units)
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (unsigned)((size_t)M * N * ESZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<XT*>(R ? R : X), 0, R ? (unsigned)((size_t)M * N * ESZ) : 0u, 0x00020000);
+    auto ld_unit = [&](const __amdgpu_buffer_rsrc_t& rs, int vo, int so) {
+        if constexpr (ESZ == 4) return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+        else return bf4_to_f4(__builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0)));
+    };
+    v4f xr[2][NK][XL], rr[2][NT];
+    auto load_tile = [&](int i, v4f (&x)[NK][XL], v4f (&r)[NT]) {
+        const int m = tile_row(i), mc = m < rows_end ? m : rows_end - 1;
+        const int vb = ESZ * mc * K;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int vo = vb + (ks == NK - 1 ? koff_last : koff);
+            x[ks][0] = ld(vo, ESZ * BK * ks);
+            if constexpr (XL == 2) x[ks][1] = ld(vo + 16, ESZ * BK * ks);
+        }
+        const int ob = ESZ * (m - j) * N;                                     // byte offset of the tile's output rows (wave-uniform)
+#pragma unroll
+        for (int p = 0; p < NT; ++p)                                         // rows past M: the buffer bound returns zeros
+            r[p] = R ? ld_unit(rres, 4 * ESZ * (64 * p + lane), ob) : (v4f){0.f, 0.f, 0.f, 0.f};
+    };
+    if (cnt > 0) load_tile(0, xr[0], rr[0]);
+    // the weight matrix and the gate row -> LDS (threads past the last chunk repeat it: same value, same address)
+    {
+        u4 wv[WLOADS];
+#pragma unroll
+        for (int t = 0; t < WLOADS; ++t) {
+            const int e = tid + t * NTHR < CHUNKS ? tid + t * NTHR : CHUNKS - 1;
+            const int ks = e / (BN * 4 * NP), e2 = e - ks * (BN * 4 * NP);
+            const int row = e2 / (4 * NP), rem = e2 - row * (4 * NP), pl = rem >> 2, c = rem & 3;
+            wv[t] = *reinterpret_cast<const u4*>(W3 + (size_t)pl * plane + (size_t)row * Kp + ks * BK + 8 * c);
+        }
+        constexpr int GL = (2 * NK * BK + NTHR - 1) / NTHR;
+        const int img_last = GATE ? (M - 1) / (tpg * 16) : 0;
+        float gv[GL];
+#pragma unroll
+        for (int t = 0; t < GL; ++t) {
+            const int e = tid + t * NTHR, im = e >= NK * BK ? 1 : 0, k = e - im * NK * BK;
+            const int img = img0 + im < img_last ? img0 + im : img_last;
+            gv[t] = GATE ? gate[(size_t)img * K + (k < K ? k : 0)] : 1.f;
+        }
+#pragma unroll
+        for (int t = 0; t < WLOADS; ++t) {
+            const int e = tid + t * NTHR < CHUNKS ? tid + t * NTHR : CHUNKS - 1;
+            const int ks = e / (BN * 4 * NP), e2 = e - ks * (BN * 4 * NP);
+            const int row = e2 / (4 * NP), rem = e2 - row * (4 * NP), pl = rem >> 2, c = rem & 3;
+            *reinterpret_cast<u4*>(&ws[ks][row * S6_ROWB + s6_chunk_pos(row, pl * 4 + c) * 16]) = wv[t];
+        }
+#pragma unroll
+        for (int t = 0; t < GL; ++t) {
+            const int e = tid + t * NTHR, im = e >= NK * BK ? 1 : 0, k = e - im * NK * BK;
+            if (e < 2 * NK * BK) gs[im][k] = k < K ? gv[t] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (cnt == 0) return;
+
+    v4f bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + nq;
+        bv[nt] = ldg4(bias + (n < N ? n : 0));
+    }
+    const int rd0 = s6_chunk_pos(j, q) * 16, rd1 = s6_chunk_pos(j, 4 + q) * 16, rd2 = s6_chunk_pos(j, 8 + q) * 16;
+    auto read_w = [&](int ks, int nt, bf8 (&f)[NP]) {
+        const unsigned char* wp = &ws[ks][(nt * 16 + j) * S6_ROWB];
+        f[0] = *reinterpret_cast<const bf8*>(wp + rd0);
+        if constexpr (NP == 3) {
+            f[1] = *reinterpret_cast<const bf8*>(wp + rd1);
+            f[2] = *reinterpret_cast<const bf8*>(wp + rd2);
+        }
+    };
+    auto tile = [&](auto bc, int i) {
+        constexpr int b = decltype(bc)::value;
+        load_tile(i + 1, xr[b ^ 1], rr[b ^ 1]);                              // the whole next tile (clamped: the repeat is never used)
+        __builtin_amdgcn_sched_barrier(0);
+        v4f acc[1][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[0][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        const float* gw = gs[GATE && t0 + wave + i * NW >= tsplit ? 1 : 0];            // wave-uniform
+        bf8 wf[2][NP];
+        read_w(0, 0, wf[0]);
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            bf8 xs[1][NXS];
+            if constexpr (ESZ == 4) {
+                v4f lo = xr[b][ks][0], hi = xr[b][ks][XL - 1];
+                if constexpr (GATE) {
+                    lo *= *reinterpret_cast<const v4f*>(&gw[ks * BK + 8 * q]);
+                    hi *= *reinterpret_cast<const v4f*>(&gw[ks * BK + 8 * q + 4]);
+                }
+                split8(lo, hi, xs[0][0], xs[0][NXS > 1 ? 1 : 0], xs[0][NXS > 2 ? 2 : 0]);
+            } else {
+                const v4f g0 = GATE ? *reinterpret_cast<const v4f*>(&gw[ks * BK + 8 * q]) : (v4f){1.f, 1.f, 1.f, 1.f};
+                const v4f g1 = GATE ? *reinterpret_cast<const v4f*>(&gw[ks * BK + 8 * q + 4]) : (v4f){1.f, 1.f, 1.f, 1.f};
+                xs[0][0] = bf16x8_gate<GATE>(xr[b][ks][0], g0, g1);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int nx = ks * NT + nt + 1;                             // next (K-step, tile) fragment in flight during these MFMAs
+                if (nx < NK * NT) read_w(nx / NT, nx % NT, wf[nx & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                s6_products<1, NXS, NP, NT>(acc, xs, wf[(ks * NT + nt) & 1], nt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // epilogue: the operations of s6_epilogue (N % 4 == 0; bias, activation, then the residual - the host sends no
+        // residual-before-activation call here), the tile turned into row order through the wave's LDS image on the way
+        float* ow = os[wave];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 16 + nq;
+            v4f v = acc[0][nt] + bv[nt];
+            if (act == ACT_SWISH) v = swish4(v);
+            else if (act == ACT_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (n < N) stg4(ow + j * N + n, v);
+        }
+        // LDS operations of one wave execute in issue order; the compiler only has to keep the two groups apart
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int ob = ESZ * (tile_row(i) - j) * N;
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+            const int u = 64 * p + lane;                                     // 4-channel unit of the tile
+            if (u < 4 * N) {
+                v4f v = ldg4(ow + 4 * u) + rr[b][p];
+                if constexpr (ESZ == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), ry, 16 * u, ob, 0);
+                else {
+                    const bf4v h = __builtin_convertvector(v, bf4v);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, h), ry, 8 * u, ob, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    int i = 0;
+    for (; i + 2 <= cnt; i += 2) {
+        tile(std::integral_constant<int, 0>{}, i);
+        tile(std::integral_constant<int, 1>{}, i + 1);
+    }
+    if (i < cnt) tile(std::integral_constant<int, 0>{}, i);
+}
+
+// shapes pw8 is instantiated for: all of N in NT 16-column tiles (N <= 48, N % 4 == 0), K in NK K-steps exactly
+// (NK, waves per block): K = 240 (block 4) keeps two tiles of 8 K-steps in registers and 74 KB of weights in LDS - one
+// block of eight waves per CU
+#define DFD_S8_NK_CASES(OP) OP(1, 4) OP(3, 4) OP(5, 4) OP(8, 8)
+inline int s8_waves(int K) { return (K + S6_BK - 1) / S6_BK == 8 ? 8 : 4; }
+inline bool s8_supports(int K, int N) {
+    const int nk = (K + S6_BK - 1) / S6_BK;
+    return N % 4 == 0 && N <= 48 && K % 8 == 0 && (nk == 1 || nk == 3 || nk == 5 || nk == 8);
+}
+
+// kind 0: pw6 (block = NW waves x MT*16 rows, NT*16 columns; wm = NW); kind 1: pw7 (WM x WN waves of MT x NT tiles);
+// kind 2: pw8 (wm = waves per block, ks = tiles per wave, nt = all of N; mblocks = groups x parts)
 struct S6Tile { int kind, wm, wn, mt, nt, ks, mblocks, nblocks; bool measured; };      // ks: K-steps per stage (pw6)
 inline S6Tile make_tile(int M, int N, int kind, int wm, int wn, int mt, int nt, int ks = 1) {
     const int bm = wm * mt * 16, bn = wn * nt * 16;
@@ -804,6 +1094,29 @@ void s6_dispatch(const S6Tile& t, const XT* X, const unsigned short* W3, const f
     const unsigned xbytes = CONV ? (unsigned)((size_t)(M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin * sizeof(XT))
                                  : (unsigned)((size_t)M * K * sizeof(XT));
     const unsigned gbytes = GATE ? (unsigned)((size_t)((M + HW - 1) / HW) * K * 4) : 0u;
+    if (t.kind == 2) {
+        if constexpr (!CONV) {
+            // t.ks = blocks per CU the grid aims at; equal shares of the matrix' tiles, at most one image's worth (a block
+            // stages two gate rows) and at least one tile per wave
+            const int tpg = GATE ? HW / 16 : 1 << 30, ttot = (M + 15) / 16, nk = (K + S6_BK - 1) / S6_BK;
+            int tpb = (ttot + 256 * t.ks - 1) / (256 * t.ks);
+            tpb = tpb > tpg ? tpg : tpb < t.wm ? t.wm : tpb;
+            const int nblk = (ttot + tpb - 1) / tpb;
+#define DFD_S8_LAUNCH(NTV, NKV, NWV)                                                                                 \
+    hipLaunchKernelGGL((pw8_kernel<NTV, NKV, GATE, NWV, XT, NP>), dim3(nblk), dim3(NWV * 64), 0, s, X, W3, plane, Kp, bias, \
+                       gate, R, Y, M, K, N, tpg, tpb, act, res_first, xbytes)
+#define DFD_S8_CASE(NKV, NWV)                            \
+    if (nk == NKV) {                                     \
+        if (t.nt == 1) DFD_S8_LAUNCH(1, NKV, NWV);       \
+        else if (t.nt == 2) DFD_S8_LAUNCH(2, NKV, NWV);  \
+        else DFD_S8_LAUNCH(3, NKV, NWV);                 \
+    }
+            DFD_S8_NK_CASES(DFD_S8_CASE)
+#undef DFD_S8_CASE
+#undef DFD_S8_LAUNCH
+        }
+        return;
+    }
     if (t.kind == 1) {
 #define DFD_S7_CASE(WMV, WNV, MTV, NTV)                                                                              \
     if (t.wm == WMV && t.wn == WNV && t.mt == MTV && t.nt == NTV) {                                                  \
