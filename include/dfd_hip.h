@@ -294,6 +294,27 @@ int dfd_analyze_frame(dfd_handle* h, int stream_id, const uint8_t* bgr, int heig
 int dfd_jpeg_coefficients(const uint8_t* jpeg, size_t len, int* info, uint16_t* qtables_out, int16_t* coef_out,
                           size_t capacity, size_t* count);
 int dfd_decode_jpeg(dfd_handle* h, const uint8_t* jpeg, size_t len, uint8_t* bgr_out, size_t capacity, int* height, int* width);
+/* n JPEGs of ONE size -> n packed BGR frames [n][H][W][3] (bgr_out may be NULL: the frames stay on the device).  Round 4:
+ * in a batch the scans of restart-less files are entropy-decoded ON THE DEVICE (csrc/jpeg_gpu_entropy.h: a lane per
+ * 512-byte chunk of the de-stuffed scan, the host decoder's speculative-chunk scheme as a fixed-point iteration) - the
+ * JPEG bytes cross PCIe instead of 6.2 MB of coefficients per 1080p frame.  Restart-interval files, files of differing
+ * sampling, and any frame the device decoder's own checks do not vouch for go through the host decoder; the result is
+ * the same bits either way (tests pin both to libjpeg).  Options: "jpeg_device_entropy" (default 2: batches of at least
+ * that many frames; 0 = never), "jpeg_chunk_bytes" (default 512).  dfd_jpeg_decode_counts: frames of batch calls decoded
+ * on the device / by the host decoder since dfd_create. */
+int dfd_decode_jpeg_batch(dfd_handle* h, int n, const uint8_t* const* jpegs, const size_t* lens, uint8_t* bgr_out, size_t capacity,
+                          int* height, int* width);
+int dfd_jpeg_decode_counts(const dfd_handle* h, unsigned long long* on_device, unsigned long long* on_host);
+/* dfd_analyze_frames_host with JPEG files instead of raw frames: n_total files of one size and sampling (jpegs[i], lens[i]; host
+ * memory, from dfd_host_alloc for full speed) are analysed `batch` at a time - the scans of chunk k + 1 cross PCIe on the
+ * copy stream while chunk k is entropy-decoded on the device, turned into frames (IDCT, upsampling, colour) and run
+ * through dfd_analyze_batch_device.  0.3 - 1.2 MB per 1080p frame over the link instead of 6.2 MB: the path that is not
+ * bound by the raw upload.  DFD_ERR_UNSUPPORTED for files only the host decoder takes (restart intervals, mixed layouts).
+ * Results as dfd_analyze_batch_device; height_out / width_out (may be NULL) receive the frame size. */
+int dfd_analyze_jpegs_host(dfd_handle* h, const uint8_t* const* jpegs, const size_t* lens, int n_total, int batch,
+                           const int32_t* forced_xywh, int forced_k, float conf_thr, int max_faces, int apply_clahe, int with_forensics,
+                           int32_t* xywh_out, int* n_faces_out, float* logits_out, double* forensic_prob_out, int* height_out,
+                           int* width_out);
 int dfd_analyze_jpeg(dfd_handle* h, int stream_id, const uint8_t* jpeg, size_t len, int full_forensics, float conf_thr,
                      int max_faces, int apply_clahe, double* scores_out, double* forensic_prob_out, int32_t* xywh_out,
                      int* n_faces_out, float* logits_out, int* height_out, int* width_out);

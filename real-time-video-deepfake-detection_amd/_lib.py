@@ -82,6 +82,9 @@ SIGNATURES = {
                                         C.POINTER(C.c_size_t)]),
     "dfd_decode_jpeg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
                                   C.POINTER(C.c_int)]),
+    "dfd_decode_jpeg_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int)]),
+    "dfd_jpeg_decode_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "dfd_analyze_jpeg": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int),
                                    C.POINTER(C.c_int)]),
@@ -101,6 +104,9 @@ SIGNATURES = {
     "dfd_analyze_frames_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                           C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    "dfd_analyze_jpegs_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float,
+                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dfd_forensic_signals_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                               C.c_void_p, C.c_void_p]),
     "dfd_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -453,6 +459,24 @@ class Handle:
         self._check(self._lib.dfd_memcpy_d2h(self._p, _ptr(out), self.frame_ptr(), out.nbytes))
         return out
 
+    def decode_jpeg_batch(self, datas) -> np.ndarray:
+        """n JPEGs of one size -> (n,H,W,3) uint8 BGR through the batch path (device entropy decoding where it applies)"""
+        n = len(datas)
+        bufs = [(C.c_char * len(d)).from_buffer_copy(d) for d in datas]
+        ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+        lens = (C.c_size_t * n)(*[len(d) for d in datas])
+        hh, ww = C.c_int(), C.c_int()
+        self._check(self._lib.dfd_decode_jpeg_batch(self._p, n, ptrs, lens, None, 0, C.byref(hh), C.byref(ww)))
+        out = np.empty((n, hh.value, ww.value, 3), np.uint8)
+        self._check(self._lib.dfd_memcpy_d2h(self._p, _ptr(out), self.frame_ptr(), out.nbytes))
+        return out
+
+    def jpeg_decode_counts(self):
+        """(frames of batch calls entropy-decoded on the device, frames decoded by the host decoder)"""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        self._check(self._lib.dfd_jpeg_decode_counts(self._p, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def frame_ptr(self) -> int:
         """device address of the last uploaded / decoded frame"""
         return self._lib.dfd_frame_ptr(self._p)
@@ -551,6 +575,47 @@ class Handle:
             _ptr(xy), _ptr(nf), _ptr(lg), _ptr(fp)))
         boxes = [[tuple(int(v) for v in xy[f, i]) for i in range(nf[f])] for f in range(n)]
         return boxes, [lg[f, : nf[f]].copy() for f in range(n)], (fp if with_forensics else None)
+
+    def pack_jpegs(self, datas):
+        """the files back to back (64-byte aligned) in ONE pinned buffer -> (buffer, offsets, lengths); release the buffer
+        with host_free.  What analyze_jpegs_host takes for full speed: DMA straight from the caller's memory."""
+        offs, total = [], 0
+        for d in datas:
+            offs.append(total)
+            total += (len(d) + 63) // 64 * 64
+        buf = self.host_alloc((max(total, 64),))
+        for o, d in zip(offs, datas):
+            buf[o:o + len(d)] = np.frombuffer(d, np.uint8)
+        return buf, offs, [len(d) for d in datas]
+
+    def analyze_jpegs_host(self, datas, batch: int, forced_boxes=None, confidence_threshold: float = 0.5, max_faces: int = 4,
+                           apply_clahe: bool = True, with_forensics: bool = False, packed=None):
+        """JPEG files of one size (bytes objects, or packed = pack_jpegs(...) for pinned input) -> as analyze_batch_device:
+        the files' bytes cross PCIe and are entropy-decoded on the device (dfd_analyze_jpegs_host)."""
+        n = len(datas) if packed is None else len(packed[1])
+        if packed is None:
+            keep = [(C.c_char * len(d)).from_buffer_copy(d) for d in datas]
+            ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in keep])
+            lens = (C.c_size_t * n)(*[len(d) for d in datas])
+        else:
+            buf, offs, ls = packed
+            ptrs = (C.c_void_p * n)(*[buf.ctypes.data + o for o in offs])
+            lens = (C.c_size_t * n)(*ls)
+        forced, forced_k = None, 0
+        if forced_boxes is not None:
+            forced = np.ascontiguousarray(np.asarray(forced_boxes, np.int32).reshape(n, -1, 4))
+            forced_k = forced.shape[1]
+        xy = np.zeros((n, max_faces, 4), np.int32)
+        nf = np.zeros(n, np.int32)
+        lg = np.zeros((n, max_faces), np.float32)
+        fp = np.zeros(n, np.float64)
+        hh, ww = C.c_int(), C.c_int()
+        self._check(self._lib.dfd_analyze_jpegs_host(
+            self._p, ptrs, lens, n, int(batch), _ptr(forced) if forced is not None else None, forced_k, float(confidence_threshold),
+            int(max_faces), int(bool(apply_clahe)), int(bool(with_forensics)), _ptr(xy), _ptr(nf), _ptr(lg), _ptr(fp),
+            C.byref(hh), C.byref(ww)))
+        boxes = [[tuple(int(v) for v in xy[f, i]) for i in range(nf[f])] for f in range(n)]
+        return boxes, [lg[f, : nf[f]].copy() for f in range(n)], (fp if with_forensics else None), (hh.value, ww.value)
 
     def classifier_crop_count(self) -> int:
         """crops the classifier has run on since the handle was created (a crop the MTCNN stage rejects is not one)"""

@@ -175,6 +175,13 @@ int dfd_set_option(dfd_handle* h, const char* name, int value) {
         return DFD_OK;
     }
     if (strcmp(name, "gemm_tile") == 0) { s6_table_set_force(h->gemm, value); return DFD_OK; }
+    if (strcmp(name, "jpeg_device_entropy") == 0) { h->jpeg_device_entropy = value < 0 ? 0 : value; return DFD_OK; }
+    if (strcmp(name, "jpeg_rounds") == 0) { h->jpeg_rounds = value; return DFD_OK; }
+    if (strcmp(name, "jpeg_chunk_bytes") == 0) {
+        if (value < 256 || value > (1 << 20) || (value & (value - 1))) return fail(h, DFD_ERR_ARG, "jpeg_chunk_bytes: a power of two in 256 .. 2^20");
+        h->jpeg_chunk_bytes = value;
+        return DFD_OK;
+    }
     if (strcmp(name, "profile_stride") == 0) { h->prof_stride = value > 0 ? value : 1; return DFD_OK; }
     return fail(h, DFD_ERR_ARG, "unknown option '%s'", name);
 }
@@ -201,6 +208,13 @@ int dfd_warmup(dfd_handle* h, int n_crops, int n_frames) {
 int dfd_classifier_crop_count(const dfd_handle* h, unsigned long long* total) {
     if (!h || !total) return DFD_ERR_ARG;
     *total = h->classifier_crops;
+    return DFD_OK;
+}
+
+int dfd_jpeg_decode_counts(const dfd_handle* h, unsigned long long* on_device, unsigned long long* on_host) {
+    if (!h || !on_device || !on_host) return DFD_ERR_ARG;
+    *on_device = h->jpeg_frames_device;
+    *on_host = h->jpeg_frames_host;
     return DFD_OK;
 }
 

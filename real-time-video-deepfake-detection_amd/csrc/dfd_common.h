@@ -131,8 +131,14 @@ struct dfd_handle {
     bool act_bf16 = false;               // classifier activations stored as bf16 (fp32 arithmetic): configs[3]
     int bf16_planes = 3;                 // weight planes the bf16-activation GEMMs use: 3 = fp32-exact weights, 1 = bf16 weights
     dfd::DevBuf jpeg_work;               // dfd_decode_jpeg: coefficients, component planes, quantisation tables
+    dfd::DevBuf jpeg_raw[2];             // dfd_analyze_jpegs_host: the scans of the chunk being decoded / being uploaded
     void* jpeg_host = nullptr;           // pinned host buffer the entropy decoder writes the coefficients into
     size_t jpeg_host_cap = 0;
+    int jpeg_device_entropy = 2;         // batches of at least this many restart-less JPEGs are entropy-decoded on the device
+                                         // (jpeg_gpu_entropy.h); 0 = never (option "jpeg_device_entropy")
+    int jpeg_rounds = 16;                // rounds of that decoder's fixed-point iteration (option "jpeg_rounds", 2 .. 32; converged rounds cost ~nothing)
+    int jpeg_chunk_bytes = 512;          // bytes of de-stuffed scan per lane of that decoder (option "jpeg_chunk_bytes", >= 256, % 4)
+    unsigned long long jpeg_frames_device = 0, jpeg_frames_host = 0;   // frames of batch calls decoded there / by the host decoder
     dfd::DevBuf tap_buf;                 // fp32 staging for taps of bf16 buffers
     std::map<const float*, unsigned short*> wsplit;   // fp32 weight tensor -> its three-plane bf16 split
     dfd::S6Table* gemm = nullptr;        // split-GEMM tile per shape (measured by dfd_warmup, heuristic otherwise)

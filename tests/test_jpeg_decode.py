@@ -180,3 +180,109 @@ def test_analyze_jpeg_equals_analyze_frame(pkg, b0_handle):
     with pytest.raises(pkg._lib.DfdError) as e:
         h.decode_jpeg(_jpeg(_img(40, 40, 1), progressive=True))
     assert e.value.code == h.UNSUPPORTED
+
+
+# ---- entropy decoding on the device (round 4, csrc/jpeg_gpu_entropy.h): the batch path -------------------------------
+def _noise(h, w, seed):
+    return np.random.default_rng(seed).integers(50, 200, (h, w, 3), dtype=np.uint8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,kw", CASES + [(1080, 1920, dict(quality=85)), (200, 333, dict(quality=92, optimize=True, subsampling=0))])
+def test_device_entropy_batch_equals_libjpeg(b0_handle, h, w, kw):
+    """three different files of one size per batch: every frame == Pillow's decode, and the device decoder did them"""
+    datas = [_jpeg(_img(h, w, h * 1000 + w + i), **kw) for i in range(3)]
+    d0, h0 = b0_handle.jpeg_decode_counts()
+    got = b0_handle.decode_jpeg_batch(datas)
+    d1, h1 = b0_handle.jpeg_decode_counts()
+    for i, data in enumerate(datas):
+        assert np.array_equal(got[i], _pil_bgr(data)), i
+    # (the size query decodes nothing; the second call decodes the three frames)
+    assert (d1 - d0, h1 - h0) == (3, 0)
+
+
+@pytest.mark.gpu
+def test_device_entropy_worst_case_texture_and_gray(b0_handle):
+    """random texture at 1080p (1.2 MB of entropy-coded data per frame, 2,400 lanes each), gray files, and a batch whose
+    frames carry their own optimised tables"""
+    datas = [_jpeg(_noise(1080, 1920, 70 + i), quality=85) for i in range(4)]
+    got = b0_handle.decode_jpeg_batch(datas)
+    for i, data in enumerate(datas):
+        assert np.array_equal(got[i], _pil_bgr(data)), i
+    gray = [_jpeg(_img(200, 333, 32 + i)[..., 0], quality=80) for i in range(2)]
+    got = b0_handle.decode_jpeg_batch(gray)
+    for i, data in enumerate(gray):
+        assert np.array_equal(got[i], _pil_bgr(data)), i
+    opt = [_jpeg(_noise(240, 320, 5 + i) // (i + 1), quality=70 + 5 * i, optimize=True) for i in range(5)]
+    got = b0_handle.decode_jpeg_batch(opt)
+    for i, data in enumerate(opt):
+        assert np.array_equal(got[i], _pil_bgr(data)), i
+
+
+@pytest.mark.gpu
+def test_device_entropy_result_does_not_depend_on_the_chunk_size(b0_handle):
+    datas = [_jpeg(_img(480, 640, 90 + i), quality=85) for i in range(2)] + [_jpeg(_noise(480, 640, 3), quality=95)]
+    want = [_pil_bgr(d) for d in datas]
+    try:
+        for chunk in (256, 512, 1024, 4096, 65536):
+            b0_handle.set_option("jpeg_chunk_bytes", chunk)
+            got = b0_handle.decode_jpeg_batch(datas)
+            assert all(np.array_equal(g, w) for g, w in zip(got, want)), chunk
+    finally:
+        b0_handle.set_option("jpeg_chunk_bytes", 512)
+
+
+@pytest.mark.gpu
+def test_device_entropy_leaves_what_it_cannot_vouch_for_to_the_host_decoder(pkg, b0_handle):
+    """restart-interval files and batches of mixed sampling take the host path (same bits); a truncated scan is an error
+    from whichever decoder meets it; the option switches the device decoder off"""
+    h = b0_handle
+    rst = [_jpeg(_img(64, 96, 5 + i), quality=80, restart_marker_blocks=3) for i in range(2)]
+    d0, h0 = h.jpeg_decode_counts()
+    got = h.decode_jpeg_batch(rst)
+    d1, h1 = h.jpeg_decode_counts()
+    assert all(np.array_equal(got[i], _pil_bgr(rst[i])) for i in range(2)) and (d1 - d0, h1 - h0) == (0, 2)
+    mixed = [_jpeg(_img(64, 96, 1), quality=80), _jpeg(_img(64, 96, 2), quality=80, subsampling=0)]
+    got = h.decode_jpeg_batch(mixed)
+    assert all(np.array_equal(got[i], _pil_bgr(mixed[i])) for i in range(2))
+    good = _jpeg(_img(128, 128, 33), quality=90)
+    cut = good[: len(good) // 2] + b"\xff\xd9"
+    with pytest.raises(pkg._lib.DfdError):
+        h.decode_jpeg_batch([good, cut])
+    try:
+        h.set_option("jpeg_device_entropy", 0)
+        d0, h0 = h.jpeg_decode_counts()
+        datas = [_jpeg(_img(120, 160, 7 + i), quality=85) for i in range(2)]
+        got = h.decode_jpeg_batch(datas)
+        d1, h1 = h.jpeg_decode_counts()
+        assert all(np.array_equal(got[i], _pil_bgr(datas[i])) for i in range(2)) and (d1 - d0, h1 - h0) == (0, 2)
+    finally:
+        h.set_option("jpeg_device_entropy", 2)
+
+
+@pytest.mark.gpu
+def test_analyze_jpegs_host_equals_decoding_first(pkg, seeded_sd):
+    """dfd_analyze_jpegs_host (scans uploaded chunk by chunk, decoded on the device, analysed) == Pillow decode of the same
+    files + dfd_analyze_batch_device: boxes, logits, forensic probabilities; pinned and pageable input; a ragged last chunk"""
+    W = pkg.weights
+    h = pkg._lib.Handle(W.pack_all(seeded_sd, W.seeded_ssd_state_dict(0)), device=0, max_batch=16)
+    try:
+        frames = [F.natural_like(270, 480, seed=60 + i) for i in range(5)] + [F.face_frame(480, 270, 3)] + [_noise(270, 480, 9)]
+        datas = [_jpeg(f, quality=85) for f in frames]
+        decoded = np.stack([_pil_bgr(d) for d in datas])
+        boxes = [[(40, 30, 120, 140), (250, 60, 160, 180)]] * len(datas)
+        fd = h.alloc(decoded.nbytes).upload(decoded)
+        want = h.analyze_batch_device(fd.ptr, len(datas), 270, 480, forced_boxes=boxes, max_faces=2, with_forensics=True)
+        fd.free()
+        packed = h.pack_jpegs(datas)
+        for kw in (dict(packed=packed), dict()):
+            got = h.analyze_jpegs_host(datas, 3, forced_boxes=boxes, max_faces=2, with_forensics=True, **kw)
+            assert got[3] == (270, 480) and got[0] == want[0]
+            assert all(np.array_equal(a, b) for a, b in zip(got[1], want[1]))
+            assert np.array_equal(got[2], want[2])
+        h.host_free(packed[0])
+        with pytest.raises(pkg._lib.DfdError) as e:
+            h.analyze_jpegs_host([_jpeg(frames[0], quality=85, restart_marker_blocks=2)] * 2, 2, forced_boxes=boxes[:2], max_faces=2)
+        assert e.value.code == h.UNSUPPORTED
+    finally:
+        h.close()
