@@ -113,6 +113,11 @@ void destroy_impl(dfd_handle* h) {
         if (h->slot_free[i]) hipEventDestroy(h->slot_free[i]);
     }
     if (h->copy_stream) hipStreamDestroy(h->copy_stream);
+    for (int i = 0; i < 2; ++i) {
+        if (h->jpeg_done[i]) hipEventDestroy(h->jpeg_done[i]);
+        if (h->frames_free[i]) hipEventDestroy(h->frames_free[i]);
+    }
+    if (h->jpeg_stream) hipStreamDestroy(h->jpeg_stream);
     if (h->aux_stream) {
         hipStreamSynchronize(h->aux_stream);
         hipStreamDestroy(h->aux_stream);

@@ -132,6 +132,9 @@ struct dfd_handle {
     int bf16_planes = 3;                 // weight planes the bf16-activation GEMMs use: 3 = fp32-exact weights, 1 = bf16 weights
     dfd::DevBuf jpeg_work;               // dfd_decode_jpeg: coefficients, component planes, quantisation tables
     dfd::DevBuf jpeg_raw[2];             // dfd_analyze_jpegs_host: the scans of the chunk being decoded / being uploaded
+    dfd::DevBuf jpeg_work2[2];           // ... and the decoder's scratch of the chunk being decoded / the one before
+    hipStream_t jpeg_stream = nullptr;   // ... whose decode runs beside the analysis of the previous chunk
+    hipEvent_t jpeg_done[2] = {nullptr, nullptr}, frames_free[2] = {nullptr, nullptr};
     void* jpeg_host = nullptr;           // pinned host buffer the entropy decoder writes the coefficients into
     size_t jpeg_host_cap = 0;
     int jpeg_device_entropy = 2;         // batches of at least this many restart-less JPEGs are entropy-decoded on the device

@@ -190,6 +190,84 @@ __global__ __launch_bounds__(256) void jpeg_color4_kernel(JpegPlanes J, int mode
     }
 }
 
+// 4:2:0 (h2v2), width % 8 == 0: a thread owns 8 x 2 output pixels - the pixel rows 2 i and 2 i + 1 that share chroma row i.
+// Per plane it loads chroma rows i - 1, i, i + 1 (clamped) at columns c0 - 1 .. c0 + 4 (one dword + two bytes per row) and
+// blends vertically once per column; clamping the neighbour indices reproduces fancy_h2v2's edge rules exactly (at the
+// first / last column 3 * cur + cur = 4 * cur).  22 loads and 12 dword stores for 16 pixels; the four-pixel kernel issues
+// 36 byte loads per 4 pixels.
+__global__ __launch_bounds__(256) void jpeg_color420_kernel(JpegPlanes J, int width, int height, uint8_t* __restrict__ out, int out_stride,
+                                                            size_t plane_stride, size_t out_frame_stride) {
+    const int x0 = 8 * (blockIdx.x * 256 + threadIdx.x), i = blockIdx.y;
+    if (x0 >= width) return;
+    const uint8_t* py = J.plane[0] + blockIdx.z * plane_stride;
+    out += blockIdx.z * out_frame_stride;
+    const int ys = J.bw[0] * 8, cs = J.bw[1] * 8;
+    const int cw = (width + 1) >> 1, ch = (height + 1) >> 1;
+    const int c0 = x0 >> 1;
+    const int iu = i > 0 ? i - 1 : 0, id = i + 1 < ch ? i + 1 : ch - 1;
+    const int cl = c0 > 0 ? c0 - 1 : 0, cr4 = c0 + 4 < cw ? c0 + 4 : cw - 1;
+    int ve[2][6], vo[2][6];                                         // [plane][column c0 - 1 + k]: vertical blends for rows 2 i / 2 i + 1
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        const uint8_t* p = J.plane[1 + pl] + blockIdx.z * plane_stride;
+        int r[3][6];
+        const int rows[3] = {iu, i, id};
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const uint8_t* q = p + (size_t)rows[rr] * cs;
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(q + c0);      // c0 % 4 == 0; columns past cw - 1 are MCU padding (unused: clamped below)
+            r[rr][0] = q[cl];
+            r[rr][5] = q[cr4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[rr][1 + k] = (int)((w >> (8 * k)) & 255u);
+        }
+#pragma unroll
+        for (int k = 1; k <= 4; ++k) {                               // a column past the plane's last real sample takes the last one
+            const int c = c0 + k - 1;
+            if (c > cw - 1) {
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) r[rr][k] = r[rr][5];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            ve[pl][k] = 3 * r[1][k] + r[0][k];
+            vo[pl][k] = 3 * r[1][k] + r[2][k];
+        }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int y = 2 * i + half;
+        if (y >= height) break;
+        const uint2 yw = *reinterpret_cast<const uint2*>(py + (size_t)y * ys + x0);
+        uint8_t px[24];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int Yv = (int)(((k < 4 ? yw.x : yw.y) >> (8 * (k & 3))) & 255u);
+            const int c = 1 + (k >> 1);                              // index of column x >> 1 in the six
+            int cbv, crv;
+            if (half == 0) {
+                cbv = (k & 1) ? (3 * ve[0][c] + ve[0][c + 1] + 7) >> 4 : (3 * ve[0][c] + ve[0][c - 1] + 8) >> 4;
+                crv = (k & 1) ? (3 * ve[1][c] + ve[1][c + 1] + 7) >> 4 : (3 * ve[1][c] + ve[1][c - 1] + 8) >> 4;
+            } else {
+                cbv = (k & 1) ? (3 * vo[0][c] + vo[0][c + 1] + 7) >> 4 : (3 * vo[0][c] + vo[0][c - 1] + 8) >> 4;
+                crv = (k & 1) ? (3 * vo[1][c] + vo[1][c + 1] + 7) >> 4 : (3 * vo[1][c] + vo[1][c - 1] + 8) >> 4;
+            }
+            cbv -= 128;
+            crv -= 128;
+            px[3 * k + 2] = (uint8_t)clampu8(Yv + ((JFIX(1.40200) * crv + 32768) >> 16));
+            px[3 * k + 1] = (uint8_t)clampu8(Yv + ((-JFIX(0.34414) * cbv + 32768 - JFIX(0.71414) * crv) >> 16));
+            px[3 * k] = (uint8_t)clampu8(Yv + ((JFIX(1.77200) * cbv + 32768) >> 16));
+        }
+        uint2 w[3];
+        memcpy(w, px, 24);
+        uint2* o = reinterpret_cast<uint2*>(out + (size_t)y * out_stride + 3 * x0);      // 24 x0 / 8: 8-byte aligned
+        o[0] = w[0];
+        o[1] = w[1];
+        o[2] = w[2];
+    }
+}
+
 }  // namespace
 
 namespace dfd {
@@ -340,151 +418,212 @@ static size_t jpeg_gpu_stage_bytes(const JpegGpuLayout& W, int n) {
            al256((size_t)n * 192 * 2) + al256(4 * JG_MAX_ROUNDS);
 }
 
-static int jpeg_gpu_decode(dfd_handle* h, std::vector<Parsed>& P, const std::vector<ScanLayout>& L, const uint8_t* raw_dev,
-                           const uint32_t* raw_off, const uint32_t* raw_len, int n, uint8_t* work, const JpegGpuLayout& W, char* stage,
-                           uint8_t* frames_dev, int chunk_bytes, int* host_decoded_out) {
-    hipStream_t s = h->stream;
-    // ---- descriptors
-    JgFrame* Fh = reinterpret_cast<JgFrame*>(stage);
-    char* sp = stage + al256(sizeof(JgFrame) * (size_t)n);
-    JgFrame* Fback = reinterpret_cast<JgFrame*>(sp);
-    sp += al256(sizeof(JgFrame) * (size_t)n);
-    JgTableSet* Th = reinterpret_cast<JgTableSet*>(sp);
-    sp += al256(sizeof(JgTableSet) * (size_t)n);
-    uint16_t* bm = reinterpret_cast<uint16_t*>(sp);
-    sp += al256(2 * W.ndsblk);
-    uint16_t* cm = reinterpret_cast<uint16_t*>(sp);
-    sp += al256(2 * W.ncblk);
-    uint16_t* qh = reinterpret_cast<uint16_t*>(sp);
-    sp += al256((size_t)n * 192 * 2);
-    uint32_t* redone_h = reinterpret_cast<uint32_t*>(sp);
-    int nsets = 0;
-    size_t ds = 0, chunks = 0, dsblk = 0, cblk = 0;
-    std::vector<char> on_host(n, 0);
-    for (int i = 0; i < n; ++i) {
-        JgFrame& F = Fh[i];
-        memset(&F, 0, sizeof F);
-        F.raw_off = raw_off[i];
-        F.raw_len = raw_len[i];
-        F.ds_off = (uint32_t)ds;
-        const size_t nc = ((size_t)raw_len[i] + chunk_bytes - 1) / chunk_bytes;
-        ds += ((nc + JG_CB - 1) / JG_CB * JG_CB + 64) * (size_t)chunk_bytes;
-        F.chunk0 = (uint32_t)chunks; F.nchunks = (uint32_t)nc; F.cblk0 = (uint32_t)cblk;
-        for (size_t b = 0; b < (nc + JG_CB - 1) / JG_CB; ++b) cm[cblk++] = (uint16_t)i;
-        chunks += (nc + JG_CB - 1) / JG_CB * JG_CB;
-        F.dsblk0 = (uint32_t)dsblk;
-        F.ndsblk = (uint32_t)(((size_t)raw_len[i] + JG_DS_BLOCK - 1) / JG_DS_BLOCK);
-        for (uint32_t b = 0; b < F.ndsblk; ++b) bm[dsblk++] = (uint16_t)i;
-        F.coef_off = (uint32_t)((size_t)i * W.coef_stride);
-        F.bpm = L[i].bpm; F.total_blocks = (int32_t)L[i].total; F.mcux = L[i].mcux; F.chunk_bytes = chunk_bytes;
-        F.cw_shift = 0;
-        while ((4 << F.cw_shift) < chunk_bytes) ++F.cw_shift;
-        for (int k = 0; k < L[i].bpm; ++k) {
-            F.slot_comp[k] = (uint8_t)L[i].slot_comp[k]; F.slot_bx[k] = (uint8_t)L[i].slot_bx[k]; F.slot_by[k] = (uint8_t)L[i].slot_by[k];
-        }
-        for (int c = 0; c < P[i].ncomp; ++c) {
-            F.comp_h[c] = P[i].comp[c].h; F.comp_v[c] = P[i].comp[c].v; F.comp_bw[c] = L[i].bw[c]; F.comp_off[c] = (uint32_t)L[i].comp_off[c];
-        }
-        F.marker_pos = 0xffffffffu;
-        JgTableSet* ts = &Th[nsets];
-        if (!jg_build_tables(P[i], ts, F.slot_dc, F.slot_ac, L[i])) { on_host[i] = 1; F.raw_len = 0; F.nchunks = 0; F.ndsblk = 0; }
-        else if (nsets > 0 && memcmp(ts, &Th[nsets - 1], sizeof *ts) == 0) F.tabset = (uint32_t)(nsets - 1);
-        else F.tabset = (uint32_t)nsets++;
-        for (int c = 0; c < 3; ++c) memcpy(qh + (size_t)i * 192 + 64 * c, P[i].q[P[i].comp[c < P[i].ncomp ? c : 0].tq], 128);
+// do two parsed files use the same Huffman tables in every MCU slot? (then the second shares the first's device image)
+static bool jpeg_same_tables(const Parsed& A, const ScanLayout& LA, const Parsed& B, const ScanLayout& LB) {
+    if (LA.bpm != LB.bpm) return false;
+    for (int s = 0; s < LA.bpm; ++s) {
+        if (LA.slot_comp[s] != LB.slot_comp[s]) return false;
+        const Component &ca = A.comp[LA.slot_comp[s]], &cb = B.comp[LB.slot_comp[s]];
+        if (ca.td != cb.td || ca.ta != cb.ta) return false;
+        if (memcmp(&A.dc[ca.td], &B.dc[cb.td], sizeof(HuffTable)) || memcmp(&A.ac[ca.ta], &B.ac[cb.ta], sizeof(HuffTable))) return false;
     }
-    JgFrame* Fd = reinterpret_cast<JgFrame*>(work + W.frames);
-    JgTableSet* Td = reinterpret_cast<JgTableSet*>(work + W.tabs);
-    uint16_t* bmd = reinterpret_cast<uint16_t*>(work + W.blkmap);
-    uint16_t* cmd = reinterpret_cast<uint16_t*>(work + W.cblkmap);
-    uint16_t* qd = reinterpret_cast<uint16_t*>(work + W.q);
-    DFD_HIP_TRY(h, hipMemcpyAsync(Fd, Fh, sizeof(JgFrame) * (size_t)n, hipMemcpyHostToDevice, s));
-    if (nsets) DFD_HIP_TRY(h, hipMemcpyAsync(Td, Th, sizeof(JgTableSet) * (size_t)nsets, hipMemcpyHostToDevice, s));
-    if (dsblk) DFD_HIP_TRY(h, hipMemcpyAsync(bmd, bm, 2 * dsblk, hipMemcpyHostToDevice, s));
-    if (cblk) DFD_HIP_TRY(h, hipMemcpyAsync(cmd, cm, 2 * cblk, hipMemcpyHostToDevice, s));
-    DFD_HIP_TRY(h, hipMemcpyAsync(qd, qh, (size_t)n * 192 * 2, hipMemcpyHostToDevice, s));
-    int16_t* coef = reinterpret_cast<int16_t*>(work + W.coef);
-    DFD_HIP_TRY(h, hipMemsetAsync(coef, 0, W.coef_stride * 2 * (size_t)n, s));
-    JgChunks S;
-    S.st = reinterpret_cast<uint2*>(work + W.st);
-    S.en[0] = reinterpret_cast<uint2*>(work + W.en0);
-    S.en[1] = reinterpret_cast<uint2*>(work + W.en1);
-    S.cnt = reinterpret_cast<uint32_t*>(work + W.cnt);
-    S.dcs = reinterpret_cast<int32_t*>(work + W.dcs);
-    S.gfirst = reinterpret_cast<uint32_t*>(work + W.gfirst);
-    S.dcb = reinterpret_cast<int32_t*>(work + W.dcb);
-    S.err = work + W.err;
-    S.redone = reinterpret_cast<uint32_t*>(work + W.redone);
-    DFD_HIP_TRY(h, hipMemsetAsync(S.redone, 0, 4 * JG_MAX_ROUNDS, s));
-    const int rounds = h->jpeg_rounds < 2 ? 2 : (h->jpeg_rounds > JG_MAX_ROUNDS ? JG_MAX_ROUNDS : h->jpeg_rounds);
-    uint8_t* dsd = work + W.ds;
-    uint32_t* removed = reinterpret_cast<uint32_t*>(work + W.removed);
-    if (dsblk) {
-        hipLaunchKernelGGL(jg_count_kernel, dim3((unsigned)dsblk), dim3(JG_DS_THREADS), 0, s, raw_dev, Fd, bmd, removed);
-        hipLaunchKernelGGL(jg_compact_kernel, dim3((unsigned)dsblk), dim3(JG_DS_THREADS), 0, s, raw_dev, dsd, Fd, bmd, removed);
-    }
-    if (cblk) {
-        for (int r = 0; r < rounds; ++r)
-            hipLaunchKernelGGL(jg_round_kernel, dim3((unsigned)cblk), dim3(JG_CB), 0, s, dsd, Fd, Td, cmd, S, r);
-        hipLaunchKernelGGL(jg_scan_kernel, dim3(n), dim3(1024), 0, s, Fd, S, rounds - 1);
-        hipLaunchKernelGGL(jg_emit_kernel, dim3((unsigned)cblk), dim3(JG_CB), 0, s, dsd, Fd, Td, cmd, S, coef);
-    }
-    DFD_HIP_TRY(h, hipMemcpyAsync(Fback, Fd, sizeof(JgFrame) * (size_t)n, hipMemcpyDeviceToHost, s));
-    DFD_HIP_TRY(h, hipMemcpyAsync(redone_h, S.redone, 4 * JG_MAX_ROUNDS, hipMemcpyDeviceToHost, s));
-    DFD_HIP_TRY(h, hipGetLastError());
-    DFD_HIP_TRY(h, stream_sync(h));
-    if (getenv("DFD_JPEG_VERBOSE")) {
-        fprintf(stderr, "[dfd] jpeg device entropy: %d frames, %zu chunks of %d bytes, lanes decoding per round:", n, chunks, chunk_bytes);
-        for (int r = 0; r < rounds; ++r) fprintf(stderr, " %u", redone_h[r]);
-        fprintf(stderr, "\n");
-    }
-    // ---- frames the device decoder does not vouch for: the host decoder says what they are
-    int host_decoded = 0;
-    for (int i = 0; i < n; ++i) {
-        if (!on_host[i] && Fback[i].status == JG_OK) continue;
-        if (getenv("DFD_JPEG_VERBOSE"))
-            fprintf(stderr, "[dfd] jpeg device entropy: frame %d status %d (%u of %d blocks, %u payload bits) -> host decoder\n", i,
-                    on_host[i] ? -1 : Fback[i].status, Fback[i].blocks_found, Fh[i].total_blocks, Fback[i].nbits);
-        std::vector<int16_t> tmp;
-        try {
-            tmp.resize(L[i].total * 64);
-        } catch (const std::bad_alloc&) { return fail(h, DFD_ERR_CAPACITY, "decode_jpeg: out of host memory"); }
-        const int rc = entropy_decode(h, &P[i], tmp.data(), L[i], true);
-        if (rc) return rc;
-        DFD_HIP_TRY(h, hipMemcpy(coef + (size_t)i * W.coef_stride, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
-        ++host_decoded;
-    }
-    if (host_decoded_out) *host_decoded_out = host_decoded;
-    // ---- IDCT + upsampling + colour of all frames: two launches
-    JpegPlanes J{};
-    int nb[3] = {0, 0, 0};
-    size_t plane_off = 0;
-    for (int c = 0; c < 3; ++c) {
-        const int cc = c < P[0].ncomp ? c : 0;
-        if (c < P[0].ncomp) {
-            J.plane[c] = work + W.planes + plane_off;
-            plane_off += al256((size_t)P[0].comp[c].bw * 8 * P[0].comp[c].bh * 8);
-            nb[c] = P[0].comp[c].bw * P[0].comp[c].bh;
-        } else {
-            J.plane[c] = J.plane[0];
-        }
-        J.coef[c] = coef + L[0].comp_off[cc];
-        J.bw[c] = P[0].comp[cc].bw;
-        J.bh[c] = P[0].comp[cc].bh;
-        J.qoff[c] = 64 * c;
-    }
-    const int total_blocks = nb[0] + nb[1] + nb[2];
-    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((total_blocks + 63) / 64, n), dim3(64), 0, s, J, qd, nb[0], nb[1], nb[2], W.coef_stride,
-                       W.plane_stride);
-    const int mode = P[0].ncomp == 1 ? 0 : (P[0].hmax == 1 ? 1 : (P[0].vmax == 1 ? 2 : 3));
-    if ((P[0].width * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(frames_dev) & 3) == 0)
-        hipLaunchKernelGGL(jpeg_color4_kernel, dim3((P[0].width + 1023) / 1024, P[0].height, n), dim3(256), 0, s, J, mode, P[0].width,
-                           P[0].height, frames_dev, P[0].width * 3, W.plane_stride, (size_t)P[0].height * P[0].width * 3);
-    else
-        hipLaunchKernelGGL(jpeg_color_kernel, dim3((P[0].width + 255) / 256, P[0].height, n), dim3(256), 0, s, J, mode, P[0].width,
-                           P[0].height, frames_dev, P[0].width * 3, W.plane_stride, (size_t)P[0].height * P[0].width * 3);
-    DFD_HIP_TRY(h, hipGetLastError());
-    return DFD_OK;
+    return true;
 }
+
+// One batch on the device decoder, in two halves so that the caller decides where the wait goes:
+//   enqueue()  descriptors up, de-stuffing, rounds, scan, emit, IDCT, colour, verdicts down - nothing waits;
+//   finish()   AFTER the stream has been waited for: reads the verdicts; frames the device decoder does not vouch for
+//              go through the host decoder, their coefficients are uploaded and IDCT / colour run again (then it waits).
+struct JpegGpuJob {
+    dfd_handle* h = nullptr;
+    hipStream_t s = nullptr;                     // the stream everything is queued on (null: the handle's)
+    std::vector<Parsed>* P = nullptr;
+    const std::vector<ScanLayout>* L = nullptr;
+    int n = 0, chunk_bytes = 512, rounds = 16;
+    uint8_t* work = nullptr;
+    JpegGpuLayout W{};
+    char* stage = nullptr;
+    uint8_t* frames_dev = nullptr;
+    JgFrame *Fh = nullptr, *Fback = nullptr;
+    uint32_t* redone_h = nullptr;
+    uint16_t* qd = nullptr;
+    int16_t* coef = nullptr;
+    size_t chunks = 0;
+    std::vector<char> on_host;
+
+    int idct_colour() {
+        const Parsed& P0 = (*P)[0];
+        const ScanLayout& L0 = (*L)[0];
+        hipStream_t s = this->s ? this->s : h->stream;
+        JpegPlanes J{};
+        int nb[3] = {0, 0, 0};
+        size_t plane_off = 0;
+        for (int c = 0; c < 3; ++c) {
+            const int cc = c < P0.ncomp ? c : 0;
+            if (c < P0.ncomp) {
+                J.plane[c] = work + W.planes + plane_off;
+                plane_off += al256((size_t)P0.comp[c].bw * 8 * P0.comp[c].bh * 8);
+                nb[c] = P0.comp[c].bw * P0.comp[c].bh;
+            } else {
+                J.plane[c] = J.plane[0];
+            }
+            J.coef[c] = coef + L0.comp_off[cc];
+            J.bw[c] = P0.comp[cc].bw;
+            J.bh[c] = P0.comp[cc].bh;
+            J.qoff[c] = 64 * c;
+        }
+        const int total_blocks = nb[0] + nb[1] + nb[2];
+        hipLaunchKernelGGL(jpeg_idct_kernel, dim3((total_blocks + 63) / 64, n), dim3(64), 0, s, J, qd, nb[0], nb[1], nb[2], W.coef_stride,
+                           W.plane_stride);
+        const int mode = P0.ncomp == 1 ? 0 : (P0.hmax == 1 ? 1 : (P0.vmax == 1 ? 2 : 3));
+        const size_t fstride = (size_t)P0.height * P0.width * 3;
+        const bool aligned = (P0.width * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(frames_dev) & 7) == 0;
+        if (aligned && mode == 3 && P0.width % 8 == 0)
+            hipLaunchKernelGGL(jpeg_color420_kernel, dim3((P0.width / 8 + 255) / 256, (P0.height + 1) / 2, n), dim3(256), 0, s, J, P0.width,
+                               P0.height, frames_dev, P0.width * 3, W.plane_stride, fstride);
+        else if (aligned)
+            hipLaunchKernelGGL(jpeg_color4_kernel, dim3((P0.width + 1023) / 1024, P0.height, n), dim3(256), 0, s, J, mode, P0.width,
+                               P0.height, frames_dev, P0.width * 3, W.plane_stride, fstride);
+        else
+            hipLaunchKernelGGL(jpeg_color_kernel, dim3((P0.width + 255) / 256, P0.height, n), dim3(256), 0, s, J, mode, P0.width,
+                               P0.height, frames_dev, P0.width * 3, W.plane_stride, fstride);
+        DFD_HIP_TRY(h, hipGetLastError());
+        return DFD_OK;
+    }
+
+    int enqueue(const uint8_t* raw_dev, const uint32_t* raw_off, const uint32_t* raw_len) {
+        hipStream_t s = this->s ? this->s : h->stream;
+        const std::vector<Parsed>& PP = *P;
+        const std::vector<ScanLayout>& LL = *L;
+        Fh = reinterpret_cast<JgFrame*>(stage);
+        char* sp = stage + al256(sizeof(JgFrame) * (size_t)n);
+        Fback = reinterpret_cast<JgFrame*>(sp);
+        sp += al256(sizeof(JgFrame) * (size_t)n);
+        JgTableSet* Th = reinterpret_cast<JgTableSet*>(sp);
+        sp += al256(sizeof(JgTableSet) * (size_t)n);
+        uint16_t* bm = reinterpret_cast<uint16_t*>(sp);
+        sp += al256(2 * W.ndsblk);
+        uint16_t* cm = reinterpret_cast<uint16_t*>(sp);
+        sp += al256(2 * W.ncblk);
+        uint16_t* qh = reinterpret_cast<uint16_t*>(sp);
+        sp += al256((size_t)n * 192 * 2);
+        redone_h = reinterpret_cast<uint32_t*>(sp);
+        int nsets = 0;
+        size_t ds = 0, dsblk = 0, cblk = 0;
+        chunks = 0;
+        on_host.assign(n, 0);
+        for (int i = 0; i < n; ++i) {
+            JgFrame& F = Fh[i];
+            memset(&F, 0, sizeof F);
+            F.raw_off = raw_off[i];
+            F.raw_len = raw_len[i];
+            F.ds_off = (uint32_t)ds;
+            const size_t nc = ((size_t)raw_len[i] + chunk_bytes - 1) / chunk_bytes;
+            ds += ((nc + JG_CB - 1) / JG_CB * JG_CB + 64) * (size_t)chunk_bytes;
+            F.chunk0 = (uint32_t)chunks; F.nchunks = (uint32_t)nc; F.cblk0 = (uint32_t)cblk;
+            F.dsblk0 = (uint32_t)dsblk;
+            F.ndsblk = (uint32_t)(((size_t)raw_len[i] + JG_DS_BLOCK - 1) / JG_DS_BLOCK);
+            F.coef_off = (uint32_t)((size_t)i * W.coef_stride);
+            F.bpm = LL[i].bpm; F.total_blocks = (int32_t)LL[i].total; F.mcux = LL[i].mcux; F.chunk_bytes = chunk_bytes;
+            F.cw_shift = 0;
+            while ((4 << F.cw_shift) < chunk_bytes) ++F.cw_shift;
+            for (int k = 0; k < LL[i].bpm; ++k) {
+                F.slot_comp[k] = (uint8_t)LL[i].slot_comp[k]; F.slot_bx[k] = (uint8_t)LL[i].slot_bx[k]; F.slot_by[k] = (uint8_t)LL[i].slot_by[k];
+            }
+            for (int c = 0; c < PP[i].ncomp; ++c) {
+                F.comp_h[c] = PP[i].comp[c].h; F.comp_v[c] = PP[i].comp[c].v; F.comp_bw[c] = LL[i].bw[c]; F.comp_off[c] = (uint32_t)LL[i].comp_off[c];
+            }
+            F.marker_pos = 0xffffffffu;
+            // the device image of the tables is built once per run of frames that share them (a stream's frames usually do)
+            if (i > 0 && !on_host[i - 1] && jpeg_same_tables(PP[i], LL[i], PP[i - 1], LL[i - 1])) {
+                F.tabset = Fh[i - 1].tabset;
+                memcpy(F.slot_dc, Fh[i - 1].slot_dc, 8);
+                memcpy(F.slot_ac, Fh[i - 1].slot_ac, 8);
+            } else if (jg_build_tables(PP[i], &Th[nsets], F.slot_dc, F.slot_ac, LL[i])) {
+                F.tabset = (uint32_t)nsets++;
+            } else {
+                on_host[i] = 1;                                      // more distinct tables than the device image holds
+                F.raw_len = 0; F.nchunks = 0; F.ndsblk = 0;
+            }
+            for (size_t b = 0; b < (F.nchunks + JG_CB - 1) / JG_CB; ++b) cm[cblk++] = (uint16_t)i;
+            chunks += ((size_t)F.nchunks + JG_CB - 1) / JG_CB * JG_CB;
+            for (uint32_t b = 0; b < F.ndsblk; ++b) bm[dsblk++] = (uint16_t)i;
+            for (int c = 0; c < 3; ++c) memcpy(qh + (size_t)i * 192 + 64 * c, PP[i].q[PP[i].comp[c < PP[i].ncomp ? c : 0].tq], 128);
+        }
+        JgFrame* Fd = reinterpret_cast<JgFrame*>(work + W.frames);
+        JgTableSet* Td = reinterpret_cast<JgTableSet*>(work + W.tabs);
+        uint16_t* bmd = reinterpret_cast<uint16_t*>(work + W.blkmap);
+        uint16_t* cmd = reinterpret_cast<uint16_t*>(work + W.cblkmap);
+        qd = reinterpret_cast<uint16_t*>(work + W.q);
+        DFD_HIP_TRY(h, hipMemcpyAsync(Fd, Fh, sizeof(JgFrame) * (size_t)n, hipMemcpyHostToDevice, s));
+        if (nsets) DFD_HIP_TRY(h, hipMemcpyAsync(Td, Th, sizeof(JgTableSet) * (size_t)nsets, hipMemcpyHostToDevice, s));
+        if (dsblk) DFD_HIP_TRY(h, hipMemcpyAsync(bmd, bm, 2 * dsblk, hipMemcpyHostToDevice, s));
+        if (cblk) DFD_HIP_TRY(h, hipMemcpyAsync(cmd, cm, 2 * cblk, hipMemcpyHostToDevice, s));
+        DFD_HIP_TRY(h, hipMemcpyAsync(qd, qh, (size_t)n * 192 * 2, hipMemcpyHostToDevice, s));
+        coef = reinterpret_cast<int16_t*>(work + W.coef);
+        DFD_HIP_TRY(h, hipMemsetAsync(coef, 0, W.coef_stride * 2 * (size_t)n, s));
+        JgChunks S;
+        S.st = reinterpret_cast<uint2*>(work + W.st);
+        S.en[0] = reinterpret_cast<uint2*>(work + W.en0);
+        S.en[1] = reinterpret_cast<uint2*>(work + W.en1);
+        S.cnt = reinterpret_cast<uint32_t*>(work + W.cnt);
+        S.dcs = reinterpret_cast<int32_t*>(work + W.dcs);
+        S.gfirst = reinterpret_cast<uint32_t*>(work + W.gfirst);
+        S.dcb = reinterpret_cast<int32_t*>(work + W.dcb);
+        S.err = work + W.err;
+        S.redone = reinterpret_cast<uint32_t*>(work + W.redone);
+        DFD_HIP_TRY(h, hipMemsetAsync(S.redone, 0, 4 * JG_MAX_ROUNDS, s));
+        rounds = h->jpeg_rounds < 2 ? 2 : (h->jpeg_rounds > JG_MAX_ROUNDS ? JG_MAX_ROUNDS : h->jpeg_rounds);
+        uint8_t* dsd = work + W.ds;
+        uint32_t* removed = reinterpret_cast<uint32_t*>(work + W.removed);
+        if (dsblk) {
+            hipLaunchKernelGGL(jg_count_kernel, dim3((unsigned)dsblk), dim3(JG_DS_THREADS), 0, s, raw_dev, Fd, bmd, removed);
+            hipLaunchKernelGGL(jg_compact_kernel, dim3((unsigned)dsblk), dim3(JG_DS_THREADS), 0, s, raw_dev, dsd, Fd, bmd, removed);
+        }
+        if (cblk) {
+            for (int r = 0; r < rounds; ++r)
+                hipLaunchKernelGGL(jg_round_kernel, dim3((unsigned)cblk), dim3(JG_CB), 0, s, dsd, Fd, Td, cmd, S, r);
+            hipLaunchKernelGGL(jg_scan_kernel, dim3(n), dim3(1024), 0, s, Fd, S, rounds - 1);
+            hipLaunchKernelGGL(jg_emit_kernel, dim3((unsigned)cblk), dim3(JG_CB), 0, s, dsd, Fd, Td, cmd, S, coef);
+        }
+        DFD_HIP_TRY(h, hipMemcpyAsync(Fback, Fd, sizeof(JgFrame) * (size_t)n, hipMemcpyDeviceToHost, s));
+        DFD_HIP_TRY(h, hipMemcpyAsync(redone_h, S.redone, 4 * JG_MAX_ROUNDS, hipMemcpyDeviceToHost, s));
+        DFD_HIP_TRY(h, hipGetLastError());
+        return idct_colour();
+    }
+
+    int finish(int* host_decoded_out) {
+        std::vector<Parsed>& PP = *P;
+        const std::vector<ScanLayout>& LL = *L;
+        if (getenv("DFD_JPEG_VERBOSE")) {
+            fprintf(stderr, "[dfd] jpeg device entropy: %d frames, %zu chunks of %d bytes, lanes decoding per round:", n, chunks, chunk_bytes);
+            for (int r = 0; r < rounds; ++r) fprintf(stderr, " %u", redone_h[r]);
+            fprintf(stderr, "\n");
+        }
+        int host_decoded = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!on_host[i] && Fback[i].status == JG_OK) continue;
+            if (getenv("DFD_JPEG_VERBOSE"))
+                fprintf(stderr, "[dfd] jpeg device entropy: frame %d status %d (%u of %d blocks, %u payload bits) -> host decoder\n", i,
+                        on_host[i] ? -1 : Fback[i].status, Fback[i].blocks_found, Fh[i].total_blocks, Fback[i].nbits);
+            std::vector<int16_t> tmp;
+            try {
+                tmp.resize(LL[i].total * 64);
+            } catch (const std::bad_alloc&) { return fail(h, DFD_ERR_CAPACITY, "decode_jpeg: out of host memory"); }
+            const int rc = entropy_decode(h, &PP[i], tmp.data(), LL[i], true);
+            if (rc) return rc;
+            DFD_HIP_TRY(h, hipMemcpy(coef + (size_t)i * W.coef_stride, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+            ++host_decoded;
+        }
+        if (host_decoded_out) *host_decoded_out = host_decoded;
+        if (host_decoded) {
+            const int rc = idct_colour();
+            if (rc) return rc;
+            DFD_HIP_TRY(h, hipStreamSynchronize(this->s ? this->s : h->stream));
+        }
+        return DFD_OK;
+    }
+};
 
 // n JPEGs of ONE size -> frames [n][H][W][3] at frames_dev (null: only parse, report the size).  The scans are entropy-
 // decoded one per pool thread (each sequentially), the device halves are queued frame by frame.
@@ -526,12 +665,14 @@ int jpeg_decode_batch_to(dfd_handle* h, const uint8_t* const* jpegs, const size_
         uint8_t* raw_dev = static_cast<uint8_t*>(h->jpeg_work.p);
         DFD_HIP_TRY(h, hipMemcpyAsync(raw_dev, pinned, up, hipMemcpyHostToDevice, h->stream));
         int on_host = 0;
-        if ((rc = jpeg_gpu_decode(h, P, L, raw_dev, roff.data(), rlen.data(), n, raw_dev + al256(up), W, pinned + up, frames_dev, chunk_bytes,
-                                  &on_host)))
-            return rc;
+        JpegGpuJob job;
+        job.h = h; job.P = &P; job.L = &L; job.n = n; job.chunk_bytes = chunk_bytes; job.work = raw_dev + al256(up); job.W = W;
+        job.stage = pinned + up; job.frames_dev = frames_dev;
+        if ((rc = job.enqueue(raw_dev, roff.data(), rlen.data()))) return rc;
+        DFD_HIP_TRY(h, stream_sync(h));                              // verdicts are in; the pinned bytes are reused by the next call
+        if ((rc = job.finish(&on_host))) return rc;
         h->jpeg_frames_device += (unsigned long long)(n - on_host);
         h->jpeg_frames_host += (unsigned long long)on_host;
-        DFD_HIP_TRY(h, stream_sync(h));                              // the pinned bytes are reused by the next call
         return DFD_OK;
     }
     h->jpeg_frames_host += (unsigned long long)n;
@@ -621,89 +762,112 @@ int dfd_analyze_jpegs_host(dfd_handle* h, const uint8_t* const* jpegs, const siz
             DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->slot_free[i], hipEventDisableTiming));
         }
     }
+    if (!h->jpeg_stream) {
+        // lowest priority: the decode has a whole analysis period to finish in; its workgroups take what the analysis leaves idle
+        int least = 0, greatest = 0;
+        DFD_HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        DFD_HIP_TRY(h, hipStreamCreateWithPriority(&h->jpeg_stream, hipStreamNonBlocking, least));
+        for (int i = 0; i < 2; ++i) {
+            DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->jpeg_done[i], hipEventDisableTiming));
+            DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->frames_free[i], hipEventDisableTiming));
+        }
+    }
+    // ---- every chunk's headers first (host only, microseconds per file): sizes of all buffers are known before anything runs
     struct Chunk {
-        int first, cnt;
+        int first = 0, cnt = 0;
         std::vector<Parsed> P;
         std::vector<ScanLayout> L;
         std::vector<uint32_t> roff, rlen;
         size_t up = 0;
+        JpegGpuLayout W{};
     };
     std::vector<Chunk> chunks;
-    for (int first = 0; first < n_total; first += batch) {
-        Chunk c;
-        c.first = first;
-        c.cnt = std::min(batch, n_total - first);
-        chunks.push_back(std::move(c));
-    }
     const int chunk_bytes = h->jpeg_chunk_bytes;
     int hh = 0, ww = 0;
-    auto prepare = [&](Chunk& c) -> int {                           // headers + layout of a chunk (host only)
+    size_t max_up = 0, max_work = 0, max_stage = 0;
+    for (int first = 0; first < n_total; first += batch) {
+        chunks.emplace_back();
+        Chunk& c = chunks.back();
+        c.first = first;
+        c.cnt = std::min(batch, n_total - first);
         c.P.resize(c.cnt);
         c.L.resize(c.cnt);
         c.roff.resize(c.cnt);
         c.rlen.resize(c.cnt);
         for (int i = 0; i < c.cnt; ++i) {
-            if ((rc = parse_headers(h, jpegs[c.first + i], lens[c.first + i], &c.P[i]))) return rc;
+            if ((rc = parse_headers(h, jpegs[first + i], lens[first + i], &c.P[i]))) return rc;
             scan_layout(&c.P[i], &c.L[i]);
             if (hh == 0) { hh = c.P[i].height; ww = c.P[i].width; }
             if (c.P[i].height != hh || c.P[i].width != ww)
-                return fail(h, DFD_ERR_ARG, "analyze_jpegs_host: file %d is %d x %d, file 0 is %d x %d", c.first + i, c.P[i].width,
+                return fail(h, DFD_ERR_ARG, "analyze_jpegs_host: file %d is %d x %d, file 0 is %d x %d", first + i, c.P[i].width,
                             c.P[i].height, ww, hh);
             c.roff[i] = (uint32_t)c.up;
             c.rlen[i] = (uint32_t)(c.P[i].end - c.P[i].scan);
             c.up += al256((size_t)c.rlen[i] + 16);
         }
         if (!jpeg_gpu_batch_ok(h, c.P, c.L, c.cnt))
-            return fail(h, DFD_ERR_UNSUPPORTED, "analyze_jpegs_host: files %d.. need the host decoder (restart intervals or mixed layouts)", c.first);
-        return DFD_OK;
-    };
-    auto upload = [&](int k) -> int {                               // chunk k's scans -> raw slot k & 1, on the copy stream
-        Chunk& c = chunks[k];
-        const int slot = k & 1;
-        if ((rc = prepare(c))) return rc;
-        if (k >= 2) DFD_HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->slot_free[slot], 0));
-        if (c.up > h->jpeg_raw[slot].cap) {
-            // (growing a slot another chunk may still read would be a race: chunk k - 2 has finished only on the device)
-            if (k >= 2) DFD_HIP_TRY(h, hipEventSynchronize(h->slot_free[slot]));
-            if ((rc = ensure(h, &h->jpeg_raw[slot], c.up + (c.up >> 2)))) return rc;
-        }
-        uint8_t* dst = static_cast<uint8_t*>(h->jpeg_raw[slot].p);
-        for (int i = 0; i < c.cnt; ++i)
-            DFD_HIP_TRY(h, hipMemcpyAsync(dst + c.roff[i], c.P[i].scan, c.rlen[i], hipMemcpyHostToDevice, h->copy_stream));
-        DFD_HIP_TRY(h, hipEventRecord(h->copy_done[slot], h->copy_stream));
-        return DFD_OK;
-    };
-    const int nb = (int)chunks.size();
-    if ((rc = upload(0))) return rc;
+            return fail(h, DFD_ERR_UNSUPPORTED, "analyze_jpegs_host: files %d.. need the host decoder (restart intervals or mixed layouts)", first);
+        c.W = jpeg_gpu_layout(c.P, c.L, c.rlen.data(), c.cnt, chunk_bytes);
+        max_up = std::max(max_up, c.up);
+        max_work = std::max(max_work, c.W.total);
+        max_stage = std::max(max_stage, al256(jpeg_gpu_stage_bytes(c.W, c.cnt)));
+    }
     if (height_out) *height_out = hh;
     if (width_out) *width_out = ww;
     const size_t frame_bytes = (size_t)hh * ww * 3;
     if ((size_t)batch * (size_t)hh * (size_t)ww > kMaxBatchPixels)
         return fail(h, DFD_ERR_UNSUPPORTED, "analyze_jpegs_host: %d frames of %d x %d per chunk exceed the %zu-pixel budget", batch, ww, hh,
                     kMaxBatchPixels);
-    if ((rc = ensure(h, &h->stage[0], (size_t)batch * frame_bytes))) return rc;
+    // two of everything a chunk touches: chunk k + 1 is uploaded and DECODED (third stream) while chunk k is analysed - the decode
+    // kernels are latency-bound at one or two waves per SIMD and run in the shadow of the analysis
+    if ((rc = jpeg_pinned(h, 2 * max_stage))) return rc;
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = ensure(h, &h->jpeg_raw[i], max_up))) return rc;
+        if ((rc = ensure(h, &h->jpeg_work2[i], max_work))) return rc;
+        if ((rc = ensure(h, &h->stage[i], (size_t)batch * frame_bytes))) return rc;
+    }
+    const int nb = (int)chunks.size();
+    std::vector<JpegGpuJob> jobs(nb);
+    auto start = [&](int k) -> int {                                // chunk k: scans up (copy stream), decode queued (jpeg stream)
+        Chunk& c = chunks[k];
+        const int slot = k & 1;
+        if (k >= 2) DFD_HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->slot_free[slot], 0));      // decode k - 2 has read its scans
+        uint8_t* dst = static_cast<uint8_t*>(h->jpeg_raw[slot].p);
+        for (int i = 0; i < c.cnt; ++i)
+            DFD_HIP_TRY(h, hipMemcpyAsync(dst + c.roff[i], c.P[i].scan, c.rlen[i], hipMemcpyHostToDevice, h->copy_stream));
+        DFD_HIP_TRY(h, hipEventRecord(h->copy_done[slot], h->copy_stream));
+        DFD_HIP_TRY(h, hipStreamWaitEvent(h->jpeg_stream, h->copy_done[slot], 0));
+        if (k >= 2) DFD_HIP_TRY(h, hipStreamWaitEvent(h->jpeg_stream, h->frames_free[slot], 0));    // analysis k - 2 has read its frames
+        JpegGpuJob& job = jobs[k];
+        job.h = h; job.s = h->jpeg_stream; job.P = &c.P; job.L = &c.L; job.n = c.cnt; job.chunk_bytes = chunk_bytes;
+        job.work = static_cast<uint8_t*>(h->jpeg_work2[slot].p); job.W = c.W;
+        job.stage = static_cast<char*>(h->jpeg_host) + (size_t)slot * max_stage;
+        job.frames_dev = static_cast<uint8_t*>(h->stage[slot].p);
+        if ((rc = job.enqueue(dst, c.roff.data(), c.rlen.data()))) return rc;
+        DFD_HIP_TRY(h, hipEventRecord(h->slot_free[slot], h->jpeg_stream));
+        DFD_HIP_TRY(h, hipEventRecord(h->jpeg_done[slot], h->jpeg_stream));
+        return DFD_OK;
+    };
+    struct Drain {                                                   // no exit leaves work behind on the side streams
+        dfd_handle* h;
+        ~Drain() { hipStreamSynchronize(h->copy_stream); hipStreamSynchronize(h->jpeg_stream); }
+    } drain{h};
+    if ((rc = start(0))) return rc;
     for (int k = 0; k < nb; ++k) {
         Chunk& c = chunks[k];
         const int slot = k & 1;
-        if (k + 1 < nb && (rc = upload(k + 1))) return rc;          // in flight while chunk k is decoded and analysed
-        const JpegGpuLayout W = jpeg_gpu_layout(c.P, c.L, c.rlen.data(), c.cnt, chunk_bytes);
-        if ((rc = jpeg_pinned(h, jpeg_gpu_stage_bytes(W, c.cnt)))) return rc;
-        if ((rc = ensure(h, &h->jpeg_work, W.total))) return rc;
-        DFD_HIP_TRY(h, hipStreamWaitEvent(h->stream, h->copy_done[slot], 0));
+        if (k + 1 < nb && (rc = start(k + 1))) return rc;
+        DFD_HIP_TRY(h, hipEventSynchronize(h->jpeg_done[slot]));      // chunk k is decoded: its verdicts are on the host
         int on_host = 0;
-        if ((rc = jpeg_gpu_decode(h, c.P, c.L, static_cast<const uint8_t*>(h->jpeg_raw[slot].p), c.roff.data(), c.rlen.data(), c.cnt,
-                                  static_cast<uint8_t*>(h->jpeg_work.p), W, static_cast<char*>(h->jpeg_host),
-                                  static_cast<uint8_t*>(h->stage[0].p), chunk_bytes, &on_host)))
-            return rc;
-        DFD_HIP_TRY(h, hipEventRecord(h->slot_free[slot], h->stream));   // the scans have been read (the decoder waited for its verdicts)
+        if ((rc = jobs[k].finish(&on_host))) return rc;              // (a frame the device decoder did not vouch for: host decoder, rare)
         h->jpeg_frames_device += (unsigned long long)(c.cnt - on_host);
         h->jpeg_frames_host += (unsigned long long)on_host;
-        rc = dfd_analyze_batch_device(h, static_cast<const uint8_t*>(h->stage[0].p), c.cnt, hh, ww,
+        rc = dfd_analyze_batch_device(h, static_cast<const uint8_t*>(h->stage[slot].p), c.cnt, hh, ww,
                                       forced_xywh ? forced_xywh + (size_t)c.first * forced_k * 4 : nullptr, forced_k, conf_thr, max_faces,
                                       apply_clahe, with_forensics, xywh_out + (size_t)c.first * max_faces * 4, n_faces_out + c.first,
                                       logits_out + (size_t)c.first * max_faces, forensic_prob_out ? forensic_prob_out + c.first : nullptr);
         if (rc) return rc;
-        c.P.clear(); c.L.clear();
+        DFD_HIP_TRY(h, hipEventRecord(h->frames_free[slot], h->stream));
     }
     DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;
