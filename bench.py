@@ -178,6 +178,61 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, w
                     "ms_per_frame": round(dt / (frames_per_step * steps) * 1e3, 3),
                     "repeats_frames_per_s": [round(frames_per_step * steps * world / d, 1) for d in dts]}
     h.set_option("bf16_activations", 0)
+    # JPEG BYTES across PCIe instead of raw frames (VERDICT r3 item 7; reference backend_server.py:139-145 receives JPEG):
+    # dfd_analyze_jpegs_host - the scans of chunk k + 1 are uploaded while chunk k is entropy-decoded ON THE DEVICE
+    # (csrc/jpeg_gpu_entropy.h), turned into frames and analysed.  Two kinds of quality-85 4:2:0 frames, byte sizes stated:
+    # a natural-texture frame (smooth shading + texture + sensor noise) and the random-texture frames of the rows above
+    # (the worst case for entropy coding: 4 x the bytes of a natural frame).
+    if world == 1:
+        import io
+
+        from PIL import Image
+
+        def encode(fr):
+            buf = io.BytesIO()
+            Image.fromarray(np.ascontiguousarray(fr[..., ::-1])).save(buf, format="JPEG", quality=85)
+            return buf.getvalue()
+
+        def natural_texture(seed):
+            r = np.random.default_rng(seed)
+            yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+            img = np.zeros((H, W, 3), np.float32)
+            for c in range(3):
+                img[..., c] = 120 + 60 * np.sin(xx / (190.0 + 23 * c) + c) * np.cos(yy / (140.0 - 11 * c)) + 25 * np.sin((xx + 2 * yy) / 37.0)
+            low = r.normal(0, 1, (H // 8 + 1, W // 8 + 1, 3)).astype(np.float32)
+            img += 14 * np.kron(low, np.ones((8, 8, 1), np.float32))[:H, :W]      # blocky mid-frequency texture
+            img += r.normal(0, 3.0, img.shape)                                    # sensor noise
+            return np.clip(img, 0, 255).astype(np.uint8)
+
+        reps = 8
+        rows = {}
+        for kind, src in (("natural_texture", [natural_texture(40 + i) for i in range(8)]), ("random_texture", [frames[i] for i in range(8)])):
+            files = [encode(f) for f in src]
+            datas = [files[i % len(files)] for i in range(reps * frames_per_step)]
+            packed = h.pack_jpegs(datas)
+            hb = boxes * reps
+            best = None
+            for chunk in (64, 32):
+                for _ in range(3):                                  # untimed: buffers, clocks (the files were just encoded on the host)
+                    h.analyze_jpegs_host(datas, chunk, forced_boxes=hb, max_faces=K, packed=packed)
+                dts = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    h.analyze_jpegs_host(datas, chunk, forced_boxes=hb, max_faces=K, packed=packed)
+                    dts.append(time.perf_counter() - t0)
+                dt = sorted(dts)[2]
+                if best is None or dt < best[1]:
+                    best = (chunk, dt)
+            on_dev, on_host = h.jpeg_decode_counts()
+            rows[kind] = {"frames_per_s": round(len(datas) / best[1], 1), "ms_per_frame": round(best[1] / len(datas) * 1e3, 3),
+                          "frames_per_chunk": best[0], "jpeg_bytes_per_frame": int(np.mean([len(f) for f in files])),
+                          "MB_per_s_over_pcie": round(sum(len(d) for d in datas) / best[1] / 1e6, 1)}
+            h.host_free(packed[0])
+        rows["frames_entropy_decoded_on_device_vs_host_decoder"] = list(h.jpeg_decode_counts())
+        rows["note"] = (f"{reps * frames_per_step} x 1080p quality-85 4:2:0 JPEG files from pinned host memory per call, SSD detect + {K} "
+                        "forced boxes -> CLAHE -> 224 -> B0 fp32 as the rows above; decoded frames equal Pillow's bit for bit "
+                        "(tests/test_jpeg_decode.py); the raw-frame path of the row above is bound by its 6.2 MB per frame")
+        res["detect_classify_jpeg_h2d"] = rows
     # PCIe-inclusive: the same frames from pinned host memory, 8 x 64 frames per call in batches of 64, the upload
     # of batch k + 1 overlapped with the compute of batch k (dfd_analyze_frames_host)
     if world == 1:
@@ -220,6 +275,8 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, w
                     "move through a pinned mailbox with copy kernels so that they do not queue behind the frame upload on the "
                     "SDMA engine; 6.22 MB per frame over PCIe Gen5 x16 (63 GB/s spec)"}
         h.host_free(pinned)
+        if "detect_classify_jpeg_h2d" in res:
+            res["detect_classify_jpeg_h2d"]["raw_upload_bound_frames_per_s"] = res["detect_classify_h2d"]["upload_only_frames_per_s"]
         # the same with a four times longer call: the un-overlapped ends of a call (first upload, last chunk's compute) are
         # a fixed cost, so the rate of a long call is the one a continuously fed service sees
         long_reps = 4 * reps
@@ -241,61 +298,6 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, w
                                                        "frames_per_s": round(long_reps * frames_per_step / min(dts), 1),
                                                        "frames_per_chunk": best_chunk}
             h.host_free(pinned)
-    # JPEG BYTES across PCIe instead of raw frames (VERDICT r3 item 7; reference backend_server.py:139-145 receives JPEG):
-    # dfd_analyze_jpegs_host - the scans of chunk k + 1 are uploaded while chunk k is entropy-decoded ON THE DEVICE
-    # (csrc/jpeg_gpu_entropy.h), turned into frames and analysed.  Two kinds of quality-85 4:2:0 frames, byte sizes stated:
-    # a natural-texture frame (smooth shading + texture + sensor noise) and the random-texture frames of the rows above
-    # (the worst case for entropy coding: 4 x the bytes of a natural frame).
-    if world == 1:
-        import io
-
-        from PIL import Image
-
-        def encode(fr):
-            buf = io.BytesIO()
-            Image.fromarray(np.ascontiguousarray(fr[..., ::-1])).save(buf, format="JPEG", quality=85)
-            return buf.getvalue()
-
-        def natural_texture(seed):
-            r = np.random.default_rng(seed)
-            yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
-            img = np.zeros((H, W, 3), np.float32)
-            for c in range(3):
-                img[..., c] = 120 + 60 * np.sin(xx / (190.0 + 23 * c) + c) * np.cos(yy / (140.0 - 11 * c)) + 25 * np.sin((xx + 2 * yy) / 37.0)
-            low = r.normal(0, 1, (H // 8 + 1, W // 8 + 1, 3)).astype(np.float32)
-            img += 14 * np.kron(low, np.ones((8, 8, 1), np.float32))[:H, :W]      # blocky mid-frequency texture
-            img += r.normal(0, 3.0, img.shape)                                    # sensor noise
-            return np.clip(img, 0, 255).astype(np.uint8)
-
-        reps = 8
-        rows = {}
-        for kind, src in (("natural_texture", [natural_texture(40 + i) for i in range(8)]), ("random_texture", [frames[i] for i in range(8)])):
-            files = [encode(f) for f in src]
-            datas = [files[i % len(files)] for i in range(reps * frames_per_step)]
-            packed = h.pack_jpegs(datas)
-            hb = boxes * reps
-            best = None
-            for chunk in (64, 32):
-                h.analyze_jpegs_host(datas, chunk, forced_boxes=hb, max_faces=K, packed=packed)
-                dts = []
-                for _ in range(3):
-                    t0 = time.perf_counter()
-                    h.analyze_jpegs_host(datas, chunk, forced_boxes=hb, max_faces=K, packed=packed)
-                    dts.append(time.perf_counter() - t0)
-                dt = sorted(dts)[1]
-                if best is None or dt < best[1]:
-                    best = (chunk, dt)
-            on_dev, on_host = h.jpeg_decode_counts()
-            rows[kind] = {"frames_per_s": round(len(datas) / best[1], 1), "ms_per_frame": round(best[1] / len(datas) * 1e3, 3),
-                          "frames_per_chunk": best[0], "jpeg_bytes_per_frame": int(np.mean([len(f) for f in files])),
-                          "MB_per_s_over_pcie": round(sum(len(d) for d in datas) / best[1] / 1e6, 1)}
-            h.host_free(packed[0])
-        rows["frames_entropy_decoded_on_device_vs_host_decoder"] = list(h.jpeg_decode_counts())
-        rows["raw_upload_bound_frames_per_s"] = res["detect_classify_h2d"]["upload_only_frames_per_s"]
-        rows["note"] = (f"{reps * frames_per_step} x 1080p quality-85 4:2:0 JPEG files from pinned host memory per call, SSD detect + {K} "
-                        "forced boxes -> CLAHE -> 224 -> B0 fp32 as the rows above; decoded frames equal Pillow's bit for bit "
-                        "(tests/test_jpeg_decode.py); the raw-frame path of the row above is bound by its 6.2 MB per frame")
-        res["detect_classify_jpeg_h2d"] = rows
     # per-request latency of the server flow from JPEG bytes: entropy decode on the host + IDCT / colour on
     # the device (dfd_analyze_jpeg) against host decode (Pillow) + raw upload (dfd_analyze_frame)
     if world == 1:

@@ -4,6 +4,10 @@ import io, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
+if os.environ.get("JP_TORCH"):
+    import torch
+    if os.environ["JP_TORCH"] == "2":
+        torch.manual_seed(0); _ = torch.randn(256, 3, 224, 224) @ torch.randn(224, 224)
 from PIL import Image
 import rtdfd_amd
 import frames as F
@@ -36,6 +40,19 @@ n = int(os.environ.get("JP_N", "256"))
 datas = [files[i % 8] for i in range(n)]
 boxes = [[(200, 150, 320, 400), (900, 300, 256, 256), (1400, 500, 400, 480), (600, 700, 224, 224)]] * n
 packed = h.pack_jpegs(datas)
+if os.environ.get("JP_BURN"):
+    # sustained-clock comparison: the resident analysis of the same decoded frames, timed in this process after a burn-in
+    dec = h.decode_jpeg_batch(datas[:64])
+    fd = h.alloc(dec.nbytes).upload(dec)
+    t_end = time.perf_counter() + float(os.environ["JP_BURN"])
+    while time.perf_counter() < t_end:
+        h.analyze_batch_device(fd.ptr, 64, 1080, 1920, forced_boxes=boxes[:64], max_faces=K)
+    t0 = time.perf_counter()
+    for _ in range(8):
+        h.analyze_batch_device(fd.ptr, 64, 1080, 1920, forced_boxes=boxes[:64], max_faces=K)
+    dt = (time.perf_counter() - t0) / 8
+    print("resident analysis of 64 decoded frames: %.2f ms = %.0f frames/s" % (dt * 1e3, 64 / dt), flush=True)
+    fd.free()
 for _ in range(2):
     h.analyze_jpegs_host(datas, 64, forced_boxes=boxes, max_faces=K, packed=packed)
 ts = []

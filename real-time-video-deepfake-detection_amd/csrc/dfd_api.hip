@@ -117,7 +117,7 @@ void destroy_impl(dfd_handle* h) {
         if (h->jpeg_done[i]) hipEventDestroy(h->jpeg_done[i]);
         if (h->frames_free[i]) hipEventDestroy(h->frames_free[i]);
     }
-    if (h->jpeg_stream) hipStreamDestroy(h->jpeg_stream);
+    h->jpeg_stream = nullptr;                     // (the handle's second compute stream: destroyed below)
     if (h->aux_stream) {
         hipStreamSynchronize(h->aux_stream);
         hipStreamDestroy(h->aux_stream);

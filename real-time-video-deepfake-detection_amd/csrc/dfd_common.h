@@ -133,7 +133,7 @@ struct dfd_handle {
     dfd::DevBuf jpeg_work;               // dfd_decode_jpeg: coefficients, component planes, quantisation tables
     dfd::DevBuf jpeg_raw[2];             // dfd_analyze_jpegs_host: the scans of the chunk being decoded / being uploaded
     dfd::DevBuf jpeg_work2[2];           // ... and the decoder's scratch of the chunk being decoded / the one before
-    hipStream_t jpeg_stream = nullptr;   // ... whose decode runs beside the analysis of the previous chunk
+    hipStream_t jpeg_stream = nullptr;   // ... whose decode runs beside the analysis of the previous chunk (= aux_stream)
     hipEvent_t jpeg_done[2] = {nullptr, nullptr}, frames_free[2] = {nullptr, nullptr};
     void* jpeg_host = nullptr;           // pinned host buffer the entropy decoder writes the coefficients into
     size_t jpeg_host_cap = 0;

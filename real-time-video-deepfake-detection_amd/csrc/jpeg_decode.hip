@@ -375,7 +375,7 @@ static JpegGpuLayout jpeg_gpu_layout(const std::vector<Parsed>& P, const std::ve
         ds += ((nc + JG_CB - 1) / JG_CB * JG_CB + 64) * (size_t)chunk_bytes;      // chunk-interleaved image: whole groups of 64 chunks + one
         cblk += (nc + JG_CB - 1) / JG_CB;
         chunks += (nc + JG_CB - 1) / JG_CB * JG_CB;
-        dsblk += ((size_t)raw_len[i] + JG_DS_BLOCK - 1) / JG_DS_BLOCK;
+        dsblk += ((size_t)raw_len[i] + 15 + JG_DS_BLOCK - 1) / JG_DS_BLOCK;      // (+ up to 15 bytes in front of an unaligned scan)
     }
     W.ds_bytes = ds; W.nchunks = chunks; W.ndsblk = dsblk; W.ncblk = cblk;
     size_t plane_total = 0;
@@ -522,7 +522,7 @@ struct JpegGpuJob {
             ds += ((nc + JG_CB - 1) / JG_CB * JG_CB + 64) * (size_t)chunk_bytes;
             F.chunk0 = (uint32_t)chunks; F.nchunks = (uint32_t)nc; F.cblk0 = (uint32_t)cblk;
             F.dsblk0 = (uint32_t)dsblk;
-            F.ndsblk = (uint32_t)(((size_t)raw_len[i] + JG_DS_BLOCK - 1) / JG_DS_BLOCK);
+            F.ndsblk = (uint32_t)(((size_t)raw_len[i] + (raw_off[i] & 15u) + JG_DS_BLOCK - 1) / JG_DS_BLOCK);
             F.coef_off = (uint32_t)((size_t)i * W.coef_stride);
             F.bpm = LL[i].bpm; F.total_blocks = (int32_t)LL[i].total; F.mcux = LL[i].mcux; F.chunk_bytes = chunk_bytes;
             F.cw_shift = 0;
@@ -762,11 +762,21 @@ int dfd_analyze_jpegs_host(dfd_handle* h, const uint8_t* const* jpegs, const siz
             DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->slot_free[i], hipEventDisableTiming));
         }
     }
-    if (!h->jpeg_stream) {
-        // lowest priority: the decode has a whole analysis period to finish in; its workgroups take what the analysis leaves idle
+    if (!h->aux_stream) {
+        // The decode runs on the handle's SECOND compute stream (the one the forensic launch set of a batch call uses):
+        // lowest priority - it has a whole analysis period to finish in and takes what the analysis leaves idle.  One side
+        // stream, not one per purpose: a process gets a handful of hardware queues, and with main / forensics / copy /
+        // decode streams two of them shared a queue - the decode then ran IN LINE with the analysis it was meant to
+        // run beside (8.7 k frames/s inside the long bench process against 10.2 k in a process that had made no forensic
+        // call).  Forensics of chunk k and the decode of chunk k + 1 share the stream in order; both are fill-in work.
         int least = 0, greatest = 0;
         DFD_HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        DFD_HIP_TRY(h, hipStreamCreateWithPriority(&h->jpeg_stream, hipStreamNonBlocking, least));
+        DFD_HIP_TRY(h, hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, least));
+        DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->aux_go, hipEventDisableTiming));
+        DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->aux_done, hipEventDisableTiming));
+    }
+    if (!h->jpeg_done[0]) {
+        h->jpeg_stream = h->aux_stream;
         for (int i = 0; i < 2; ++i) {
             DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->jpeg_done[i], hipEventDisableTiming));
             DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->frames_free[i], hipEventDisableTiming));
@@ -779,6 +789,9 @@ int dfd_analyze_jpegs_host(dfd_handle* h, const uint8_t* const* jpegs, const siz
         std::vector<ScanLayout> L;
         std::vector<uint32_t> roff, rlen;
         size_t up = 0;
+        bool one_copy = false;                   // the files lie back to back in host memory: ONE DMA for the chunk
+        const uint8_t* span = nullptr;
+        size_t span_bytes = 0;
         JpegGpuLayout W{};
     };
     std::vector<Chunk> chunks;
@@ -794,6 +807,8 @@ int dfd_analyze_jpegs_host(dfd_handle* h, const uint8_t* const* jpegs, const siz
         c.L.resize(c.cnt);
         c.roff.resize(c.cnt);
         c.rlen.resize(c.cnt);
+        size_t sum_len = 0;
+        bool ascending = true;
         for (int i = 0; i < c.cnt; ++i) {
             if ((rc = parse_headers(h, jpegs[first + i], lens[first + i], &c.P[i]))) return rc;
             scan_layout(&c.P[i], &c.L[i]);
@@ -804,6 +819,18 @@ int dfd_analyze_jpegs_host(dfd_handle* h, const uint8_t* const* jpegs, const siz
             c.roff[i] = (uint32_t)c.up;
             c.rlen[i] = (uint32_t)(c.P[i].end - c.P[i].scan);
             c.up += al256((size_t)c.rlen[i] + 16);
+            sum_len += lens[first + i];
+            if (i > 0 && jpegs[first + i] < jpegs[first + i - 1] + lens[first + i - 1]) ascending = false;
+        }
+        // files packed into one (pinned) buffer - Handle.pack_jpegs, a receive buffer - go up as ONE transfer: 64 small DMAs per
+        // chunk cost the host ~10 us each on the path that feeds the decoder (the de-stuffing kernels take any alignment)
+        const size_t span = (size_t)(jpegs[first + c.cnt - 1] + lens[first + c.cnt - 1] - jpegs[first]);
+        if (ascending && span <= sum_len + sum_len / 4 + 4096 && span < ((size_t)1 << 31)) {
+            c.one_copy = true;
+            c.span = jpegs[first];
+            c.span_bytes = span;
+            for (int i = 0; i < c.cnt; ++i) c.roff[i] = (uint32_t)(c.P[i].scan - c.span);
+            c.up = al256(span + 32);
         }
         if (!jpeg_gpu_batch_ok(h, c.P, c.L, c.cnt))
             return fail(h, DFD_ERR_UNSUPPORTED, "analyze_jpegs_host: files %d.. need the host decoder (restart intervals or mixed layouts)", first);
@@ -833,8 +860,12 @@ int dfd_analyze_jpegs_host(dfd_handle* h, const uint8_t* const* jpegs, const siz
         const int slot = k & 1;
         if (k >= 2) DFD_HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->slot_free[slot], 0));      // decode k - 2 has read its scans
         uint8_t* dst = static_cast<uint8_t*>(h->jpeg_raw[slot].p);
-        for (int i = 0; i < c.cnt; ++i)
-            DFD_HIP_TRY(h, hipMemcpyAsync(dst + c.roff[i], c.P[i].scan, c.rlen[i], hipMemcpyHostToDevice, h->copy_stream));
+        if (c.one_copy) {
+            DFD_HIP_TRY(h, hipMemcpyAsync(dst, c.span, c.span_bytes, hipMemcpyHostToDevice, h->copy_stream));
+        } else {
+            for (int i = 0; i < c.cnt; ++i)
+                DFD_HIP_TRY(h, hipMemcpyAsync(dst + c.roff[i], c.P[i].scan, c.rlen[i], hipMemcpyHostToDevice, h->copy_stream));
+        }
         DFD_HIP_TRY(h, hipEventRecord(h->copy_done[slot], h->copy_stream));
         DFD_HIP_TRY(h, hipStreamWaitEvent(h->jpeg_stream, h->copy_done[slot], 0));
         if (k >= 2) DFD_HIP_TRY(h, hipStreamWaitEvent(h->jpeg_stream, h->frames_free[slot], 0));    // analysis k - 2 has read its frames
@@ -843,7 +874,8 @@ int dfd_analyze_jpegs_host(dfd_handle* h, const uint8_t* const* jpegs, const siz
         job.work = static_cast<uint8_t*>(h->jpeg_work2[slot].p); job.W = c.W;
         job.stage = static_cast<char*>(h->jpeg_host) + (size_t)slot * max_stage;
         job.frames_dev = static_cast<uint8_t*>(h->stage[slot].p);
-        if ((rc = job.enqueue(dst, c.roff.data(), c.rlen.data()))) return rc;
+        const int erc = job.enqueue(dst, c.roff.data(), c.rlen.data());   // (no shared scratch: start() also runs on the producer thread)
+        if (erc) return erc;
         DFD_HIP_TRY(h, hipEventRecord(h->slot_free[slot], h->jpeg_stream));
         DFD_HIP_TRY(h, hipEventRecord(h->jpeg_done[slot], h->jpeg_stream));
         return DFD_OK;
@@ -852,11 +884,44 @@ int dfd_analyze_jpegs_host(dfd_handle* h, const uint8_t* const* jpegs, const siz
         dfd_handle* h;
         ~Drain() { hipStreamSynchronize(h->copy_stream); hipStreamSynchronize(h->jpeg_stream); }
     } drain{h};
+    // The host side of start(k + 1) - one or a few dozen transfers, the descriptors, ~25 launches - runs on a second thread
+    // while this one sits in the (blocking) analysis of chunk k: done in line it kept the main stream idle for that long
+    // in front of every chunk.  The producer starts chunk k only after the analysis of chunk k - 2 has been queued (its
+    // frames_free event recorded: a stream wait picks up the LAST record of an event, so the record must exist first).
+    std::mutex mu;
+    std::condition_variable cv;
+    int started = 0, analysed = -1, prod_rc = DFD_OK;                // chunks started / chunks whose analysis is queued
+    bool stop = false;
     if ((rc = start(0))) return rc;
+    std::thread producer([&] {
+        hipSetDevice(h->device);
+        for (int k = 1; k < nb; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || analysed >= k - 2; });
+                if (stop) return;
+            }
+            const int r = start(k);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (r) prod_rc = r; else started = k;
+            }
+            cv.notify_all();
+            if (r) return;
+        }
+    });
+    struct Join {
+        std::thread& t; std::mutex& mu; std::condition_variable& cv; bool& stop;
+        ~Join() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); }
+    } join{producer, mu, cv, stop};
     for (int k = 0; k < nb; ++k) {
         Chunk& c = chunks[k];
         const int slot = k & 1;
-        if (k + 1 < nb && (rc = start(k + 1))) return rc;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return started >= k || prod_rc != DFD_OK; });
+            if (prod_rc != DFD_OK) return prod_rc;
+        }
         DFD_HIP_TRY(h, hipEventSynchronize(h->jpeg_done[slot]));      // chunk k is decoded: its verdicts are on the host
         int on_host = 0;
         if ((rc = jobs[k].finish(&on_host))) return rc;              // (a frame the device decoder did not vouch for: host decoder, rare)
@@ -868,6 +933,11 @@ int dfd_analyze_jpegs_host(dfd_handle* h, const uint8_t* const* jpegs, const siz
                                       logits_out + (size_t)c.first * max_faces, forensic_prob_out ? forensic_prob_out + c.first : nullptr);
         if (rc) return rc;
         DFD_HIP_TRY(h, hipEventRecord(h->frames_free[slot], h->stream));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            analysed = k;
+        }
+        cv.notify_all();
     }
     DFD_HIP_TRY(h, stream_sync(h));
     return DFD_OK;

@@ -45,7 +45,8 @@ struct JgTableSet {                              // device image of one frame's 
 };
 
 struct JgFrame {
-    uint32_t raw_off, raw_len;                   // the scan's bytes in the uploaded buffer (raw_off % 16 == 0)
+    uint32_t raw_off, raw_len;                   // the scan's bytes in the uploaded buffer (any alignment: the de-stuffing kernels
+                                                 // read whole 16-byte pieces from raw_off & ~15 and skip the bytes in front)
     uint32_t ds_off;                             // its de-stuffed bytes (% 16 == 0, capacity raw_len + 64)
     uint32_t chunk0, nchunks, cblk0;             // chunk range, first chunk block
     uint32_t dsblk0, ndsblk;                     // de-stuffing blocks
@@ -86,7 +87,8 @@ __host__ __device__ __forceinline__ uint32_t jg_dword_at(uint32_t g, int cw_shif
 
 // ---------------------------------------------------------------------------------------------- de-stuffing
 // piece q of a block = its bytes [16 q, 16 q + 16): thread t takes the pieces t, t + 256, ... (coalesced 16-byte loads)
-__device__ __forceinline__ void jg_piece_scan(const uint8_t* scan, uint32_t raw_len, uint32_t pos0, const uint8_t (&b)[16], uint8_t prev,
+// (positions in [lead, raw_len) are the scan; a piece may start in front of it)
+__device__ __forceinline__ void jg_piece_scan(uint32_t lead, uint32_t raw_len, uint32_t pos0, const uint8_t (&b)[16], uint8_t prev,
                                               int* removed, uint32_t* marker) {
     int rem = 0;
     uint32_t mk = 0xffffffffu;
@@ -94,7 +96,8 @@ __device__ __forceinline__ void jg_piece_scan(const uint8_t* scan, uint32_t raw_
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const uint32_t pos = pos0 + i;
-        if (pos < raw_len) {
+        if (pos == lead) p = 0;                                    // nothing in front of the first byte
+        if (pos >= lead && pos < raw_len) {
             if (p == 0xFF) {
                 if (b[i] == 0) ++rem;
                 else if (mk == 0xffffffffu) mk = pos - 1;
@@ -111,9 +114,10 @@ __global__ __launch_bounds__(JG_DS_THREADS) void jg_count_kernel(const uint8_t* 
                                                                  const uint16_t* __restrict__ blk_frame, uint32_t* __restrict__ blk_removed) {
     __shared__ int red[JG_DS_THREADS / 64];
     const int f = blk_frame[blockIdx.x], tid = threadIdx.x;
-    const uint32_t raw_off = F[f].raw_off, raw_len = F[f].raw_len;
+    // positions count from the 16-byte boundary in front of the scan: its bytes are [lead, lead + raw_len)
+    const uint32_t lead = F[f].raw_off & 15u, raw_len = F[f].raw_len + lead;
     const uint32_t base = (blockIdx.x - F[f].dsblk0) * (uint32_t)JG_DS_BLOCK;
-    const uint8_t* scan = raw + raw_off;
+    const uint8_t* scan = raw + (F[f].raw_off - lead);
     int total = 0;
     uint32_t mk = 0xffffffffu;
 #pragma unroll
@@ -122,10 +126,10 @@ __global__ __launch_bounds__(JG_DS_THREADS) void jg_count_kernel(const uint8_t* 
         uint8_t b[16];
         const uint4 v = pos0 < raw_len ? *reinterpret_cast<const uint4*>(scan + pos0) : make_uint4(0, 0, 0, 0);   // (capacity is padded)
         memcpy(b, &v, 16);
-        const uint8_t prev = pos0 > 0 && pos0 <= raw_len ? scan[pos0 - 1] : 0;
+        const uint8_t prev = pos0 > lead && pos0 <= raw_len ? scan[pos0 - 1] : 0;
         int rem;
         uint32_t m;
-        jg_piece_scan(scan, raw_len, pos0, b, prev, &rem, &m);
+        jg_piece_scan(lead, raw_len, pos0, b, prev, &rem, &m);
         total += rem;
         mk = m < mk ? m : mk;
     }
@@ -154,9 +158,9 @@ __global__ __launch_bounds__(JG_DS_THREADS) void jg_compact_kernel(const uint8_t
     __shared__ int wsum[JG_DS_THREADS / 64 + 1];
     __shared__ int before;
     const int f = blk_frame[blockIdx.x], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t raw_off = F[f].raw_off, raw_len = F[f].raw_len, b0 = F[f].dsblk0;
+    const uint32_t lead = F[f].raw_off & 15u, raw_len = F[f].raw_len + lead, b0 = F[f].dsblk0;
     const uint32_t base = (blockIdx.x - b0) * (uint32_t)JG_DS_BLOCK;
-    const uint8_t* scan = raw + raw_off;
+    const uint8_t* scan = raw + (F[f].raw_off - lead);
     uint8_t* out = ds + F[f].ds_off;
     const int cw_shift = F[f].cw_shift;
     // stuffed zeros in the frame's blocks before this one
@@ -181,10 +185,10 @@ __global__ __launch_bounds__(JG_DS_THREADS) void jg_compact_kernel(const uint8_t
         const uint32_t pos0 = base + (uint32_t)(i * JG_DS_THREADS + tid) * 16;
         const uint4 v = pos0 < raw_len ? *reinterpret_cast<const uint4*>(scan + pos0) : make_uint4(0, 0, 0, 0);
         memcpy(b[i], &v, 16);
-        prev[i] = pos0 > 0 && pos0 <= raw_len ? scan[pos0 - 1] : 0;
+        prev[i] = pos0 > lead && pos0 <= raw_len ? scan[pos0 - 1] : 0;
         int rem;
         uint32_t m;
-        jg_piece_scan(scan, raw_len, pos0, b[i], prev[i], &rem, &m);
+        jg_piece_scan(lead, raw_len, pos0, b[i], prev[i], &rem, &m);
         cnt[i * JG_DS_THREADS + tid] = rem;
     }
     __syncthreads();
@@ -212,12 +216,14 @@ __global__ __launch_bounds__(JG_DS_THREADS) void jg_compact_kernel(const uint8_t
         const int q = i * JG_DS_THREADS + tid;
         const uint32_t pos0 = base + (uint32_t)q * 16;
         if (pos0 >= raw_len) continue;
-        uint32_t o = pos0 - (uint32_t)before - (uint32_t)cnt[q];
+        // output index of the piece's first scan byte: scan bytes in front of it minus the stuffed zeros among them
+        uint32_t o = (pos0 > lead ? pos0 - lead : 0u) - (uint32_t)before - (uint32_t)cnt[q];
         uint8_t p = prev[i];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const uint32_t pos = pos0 + k;
-            if (pos < raw_len) {
+            if (pos == lead) p = 0;
+            if (pos >= lead && pos < raw_len) {
                 const bool stuffed = p == 0xFF && b[i][k] == 0;
                 if (!stuffed) { out[4u * jg_dword_at(o >> 2, cw_shift) + (o & 3u)] = b[i][k]; ++o; }
                 if (pos + 1 == end) F[f].nbits = 8u * o;              // (end == 0: set by the host to 0 beforehand)
