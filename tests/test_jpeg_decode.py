@@ -286,3 +286,29 @@ def test_analyze_jpegs_host_equals_decoding_first(pkg, seeded_sd):
         assert e.value.code == h.UNSUPPORTED
     finally:
         h.close()
+
+
+@pytest.mark.gpu
+def test_analyze_jpegs_host_fails_loudly_and_leaves_the_handle_usable(pkg, seeded_sd):
+    """a truncated scan in the THIRD chunk (the producer thread is two chunks ahead by then): the call reports the host
+    decoder's error, nothing hangs, and the next call on the same handle gives the right answer; a file of another size
+    is refused before anything is queued"""
+    W = pkg.weights
+    h = pkg._lib.Handle(W.pack_all(seeded_sd, W.seeded_ssd_state_dict(0)), device=0, max_batch=16)
+    try:
+        good = [_jpeg(F.natural_like(270, 480, seed=80 + i), quality=85) for i in range(4)]
+        boxes = [[(40, 30, 120, 140)]] * 8
+        datas = [good[i % 4] for i in range(8)]
+        want = h.analyze_jpegs_host(datas, 2, forced_boxes=boxes, max_faces=1)
+        bad = list(datas)
+        bad[5] = good[1][: len(good[1]) // 2] + b"\xff\xd9"
+        with pytest.raises(pkg._lib.DfdError):
+            h.analyze_jpegs_host(bad, 2, forced_boxes=boxes, max_faces=1)
+        other = list(datas)
+        other[6] = _jpeg(F.natural_like(240, 320, seed=3), quality=85)
+        with pytest.raises(pkg._lib.DfdError):
+            h.analyze_jpegs_host(other, 2, forced_boxes=boxes, max_faces=1)
+        again = h.analyze_jpegs_host(datas, 2, forced_boxes=boxes, max_faces=1)
+        assert again[0] == want[0] and all(np.array_equal(a, b) for a, b in zip(again[1], want[1]))
+    finally:
+        h.close()
