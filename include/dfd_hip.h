@@ -65,6 +65,8 @@ int dfd_max_batch(const dfd_handle* h);
  *   "se_in_proj" (default 0, env DFD_SE_IN_PROJ; measured slower, kept for the measurement): where a depthwise launch leaves final per-image pool sums (the
  *   whole-image launches of "fuse_late") the projection GEMM's blocks evaluate the squeeze-excite gate themselves
  *   (se_kernel's arithmetic, identical gate bits) instead of a separate launch per block.
+ *   "se_thin" (default 0; measured slower, kept for the measurement): blocks 0-4 - the blocks of the narrow projection
+ *   kernel (pw8_kernel) evaluate the squeeze-excite gate of the images they meet in a prologue, no se_kernel launch.
  *   "fuse_stem" (default 1, env DFD_FUSE_STEM): the stem conv is computed inside block 0's depthwise
  *   kernel (the 112x112x32 stem activation stays in LDS).
  *   "split_gemm" (default 1, env DFD_SPLIT_GEMM): 1x1 convs (N >= 16) and the detector's k x k convs run on

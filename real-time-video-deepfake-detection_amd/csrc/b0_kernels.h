@@ -69,7 +69,12 @@ struct SeFuse {
     const float *w1 = nullptr, *b1 = nullptr, *w2t = nullptr, *b2 = nullptr;
     float inv_hw = 0.f;
     int c_se = 0;
+    int tiles = 1;                   // pool partials per image: P is [n][tiles][C]
+    bool thin = false;               // no se_kernel ran: the call must go to pw8_kernel, whose blocks evaluate the gate of the
+                                     // (at most two) images they meet in a light prologue (C <= 256, c_se <= 16; any `tiles`)
 };
+constexpr int SE_THIN_MAX_C = 256, SE_THIN_MAX_SE = 16;
+inline bool se_thin_supported(int C, int c_se) { return C <= SE_THIN_MAX_C && c_se >= 1 && c_se <= SE_THIN_MAX_SE; }
 constexpr int SE_FUSE_MAX_IMG = 4;   // images one GEMM block (<= 128 rows) can touch when an image has >= 49 rows
 constexpr int SE_FUSE_MAX_SE = 48;
 
@@ -79,6 +84,8 @@ constexpr int SE_FUSE_MAX_SE = 48;
 size_t split_weights_count(int N, int K);
 void launch_split_weights(const float* W, unsigned short* out, int N, int K, hipStream_t s, bool transposed = false);
 bool split_gemm_supports(int K, int N);
+// can a gated 1x1 conv of this shape run on pw8_kernel (weights resident in LDS; images of HW rows, HW % 16 == 0)?
+bool split_gemm_thin_supports(int K, int N, int HW);
 // `tab` is the handle's tile table (null: heuristic tile, nothing remembered).  A shape the table has no
 // measurement for runs the heuristic tile unless the table is in tuning mode (dfd_warmup), where every
 // candidate is timed on the caller's operands - the only place these launchers synchronise.  Calls whose

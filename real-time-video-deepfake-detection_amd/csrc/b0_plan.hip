@@ -280,9 +280,16 @@ static int b0_forward_t(dfd_handle* h, const float* x, int n, float* logits_dev,
         // option "se_in_proj": where the depthwise launch left FINAL per-image pool sums (tiles == 1: the whole-image
         // launches of blocks 6-10 / 12-15) the projection GEMM evaluates the gate itself - no se_kernel launch
         SeFuse sef;
-        const bool se_in_proj = !se_fused && h->se_in_proj && tiles == 1 && se_fuse_supported(b.h_out * b.h_out, b.c_se) &&
-                                pointwise_on_split<XT>(h, b.c_exp, b.c_out);
-        if (se_in_proj) {
+        // option "se_thin" (round 4; measured slower, off by default): the narrow projections of blocks 0-4 run on pw8_kernel,
+        // whose blocks evaluate the gate of the images they meet themselves - no se_kernel launch in front of them
+        const bool se_thin = !se_fused && h->se_thin && pointwise_on_split<XT>(h, b.c_exp, b.c_out) && !h->se_in_proj &&
+                             split_gemm_thin_supports(b.c_exp, b.c_out, b.h_out * b.h_out) && se_thin_supported(b.c_exp, b.c_se);
+        const bool se_in_proj = se_thin || (!se_fused && h->se_in_proj && tiles == 1 && se_fuse_supported(b.h_out * b.h_out, b.c_se) &&
+                                            pointwise_on_split<XT>(h, b.c_exp, b.c_out));
+        if (se_thin) {
+            sef.P = h->pool; sef.w1 = b.se_w1; sef.b1 = b.se_b1; sef.w2t = b.se_w2; sef.b2 = b.se_b2;
+            sef.inv_hw = 1.0f / (float)(b.h_out * b.h_out); sef.c_se = b.c_se; sef.tiles = tiles; sef.thin = true;
+        } else if (se_in_proj) {
             sef.P = h->pool; sef.w1 = b.se_w1; sef.b1 = b.se_b1; sef.w2t = b.se_w2; sef.b2 = b.se_b2;
             sef.inv_hw = 1.0f / (float)(b.h_out * b.h_out); sef.c_se = b.c_se;
         } else if (!se_fused) {

@@ -169,6 +169,7 @@ int dfd_set_option(dfd_handle* h, const char* name, int value) {
     if (strcmp(name, "fuse_se") == 0) { h->fuse_se = value != 0; return DFD_OK; }
     if (strcmp(name, "fuse_late") == 0) { h->fuse_late = value != 0; return DFD_OK; }
     if (strcmp(name, "se_in_proj") == 0) { h->se_in_proj = value != 0; return DFD_OK; }
+    if (strcmp(name, "se_thin") == 0) { h->se_thin = value != 0; return DFD_OK; }
     if (strcmp(name, "fuse_stem") == 0) { h->fuse_stem = value != 0; return DFD_OK; }
     if (strcmp(name, "split_gemm") == 0) { h->split_gemm = value != 0; return DFD_OK; }
     if (strcmp(name, "mtcnn") == 0) { h->use_mtcnn = value != 0; return DFD_OK; }

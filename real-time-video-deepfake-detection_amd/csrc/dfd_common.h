@@ -126,6 +126,9 @@ struct dfd_handle {
     bool se_in_proj = false;             // squeeze-excite gate evaluated by the projection GEMM's blocks where the pool sums are final
                                          // per image (blocks 6-10 / 12-15 with fuse_late): no se_kernel launch there.  Built and
                                          // measured in round 4: gates bit-identical, step SLOWER - off
+    bool se_thin = false;                // blocks 0-4: the gate evaluated by the narrow projection's own blocks (pw8_kernel prologue),
+                                         // no se_kernel launch there.  Built and measured in round 4: the five projections +85 us
+                                         // against 54 us of se_kernel launches saved (3.08 vs 2.99 ms per step) - off (option "se_thin")
     unsigned* se_counter = nullptr;      // [max_batch] arrival counters of that hand-off (zero between launches)
     bool split_gemm = true;              // 1x1 / k x k convs on the bf16x3-split MFMA path (gemm_split.hip)
     bool act_bf16 = false;               // classifier activations stored as bf16 (fp32 arithmetic): configs[3]

@@ -227,11 +227,17 @@ static void s6_run_one(S6Table* tab, bool conv, bool gated, const XT* X, const u
     static const bool thin_env = !(getenv("DFD_S6_THIN") && atoi(getenv("DFD_S6_THIN")) == 0);
     // pw8 takes the call when the whole weight matrix fits its LDS image, a 16-row tile never straddles two images (the
     // gate row is block-uniform) and nothing but bias / activation / residual happens in the epilogue
-    const bool thin = thin_env && !conv && s8_supports(K, N) && (!gated || (HW % 16 == 0 && M % HW == 0)) && !se.P && act != ACT_PRELU &&
-                      !(R && res_first);
+    const bool thin = thin_env && !conv && s8_supports(K, N) && (!gated || (HW % 16 == 0 && M % HW == 0)) && act != ACT_PRELU &&
+                      !(R && res_first) && (!se.P || (se.thin && se_thin_supported(K, se.c_se)));
+    // se.thin: nobody launched se_kernel - only pw8 can take the call (the plan asked split_gemm_thin_supports first)
+    auto candidates = [&]() {
+        std::vector<S6Tile> c = s6_candidates(M, K, N, thin);
+        if (se.P && se.thin) c.erase(std::remove_if(c.begin(), c.end(), [](const S6Tile& t) { return t.kind != 2; }), c.end());
+        return c;
+    };
     S6Tile tile;
     if (tab && tab->force >= 0) {
-        const std::vector<S6Tile> cands = s6_candidates(M, K, N, thin);
+        const std::vector<S6Tile> cands = candidates();
         tile = cands[(size_t)tab->force % cands.size()];
     } else {
         // M in 8 buckets per octave: data-dependent row counts (the MTCNN candidate windows) share an entry
@@ -248,8 +254,8 @@ static void s6_run_one(S6Table* tab, bool conv, bool gated, const XT* X, const u
         if (tab && it != tab->tiles.end() && (it->second.measured || !tuning)) {
             tile = it->second;
         } else {
-            tile = pick_tile6(M, N);
-            if (tuning) s6_measure<XT, NP>(conv, gated, s6_candidates(M, K, N, thin), &tile, key, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se);
+            tile = se.P && se.thin ? candidates()[2] : pick_tile6(M, N);      // (thin-only list: 2, 3, 4 ... blocks per CU)
+            if (tuning) s6_measure<XT, NP>(conv, gated, candidates(), &tile, key, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se);
             if (tab) tab->tiles[key] = tile;
         }
         tile = make_tile(M, N, tile.kind, tile.wm, tile.wn, tile.mt, tile.nt, tile.ks);      // block counts for this call's M
@@ -271,6 +277,10 @@ static void s6_run_np(int planes, S6Table* tab, bool conv, bool gated, const XT*
 }
 
 bool split_gemm_supports(int K, int N) { return K % 8 == 0 && K >= 16 && split_weights_count(N, K) * 6 < (1ull << 31); }
+bool split_gemm_thin_supports(int K, int N, int HW) {
+    static const bool thin_env = !(getenv("DFD_S6_THIN") && atoi(getenv("DFD_S6_THIN")) == 0);
+    return thin_env && split_gemm_supports(K, N) && s8_supports(K, N) && HW > 0 && HW % 16 == 0;
+}
 
 template <typename XT>
 bool launch_pointwise_split(S6Table* tab, const XT* X, const unsigned short* W3, const float* bias, const float* gate,
@@ -279,12 +289,13 @@ bool launch_pointwise_split(S6Table* tab, const XT* X, const unsigned short* W3,
     const ConvGeom none{};
     if (HW <= 0) HW = 1;
     if (se && se->P && (!gate || !se_fuse_supported(HW, se->c_se))) return false;
+    if (se && se->P && se->thin && !(split_gemm_thin_supports(K, N, HW) && se_thin_supported(K, se->c_se) && M % HW == 0)) return false;
     const long long chunk = s6_chunk_rows(M, (long long)K * (long long)sizeof(XT), gate ? HW : 1);
     if (chunk <= 0) return false;
     for (long long m0 = 0; m0 < M; m0 += chunk) {
         const int mc = (int)std::min<long long>(chunk, M - m0);
         SeFuse sec = se ? *se : SeFuse();
-        if (sec.P) sec.P += (size_t)(m0 / HW) * K;               // chunks are whole images
+        if (sec.P) sec.P += (size_t)(m0 / HW) * K * (size_t)sec.tiles;      // chunks are whole images
         s6_run_np<XT>(planes, tab, false, gate != nullptr, X + (size_t)m0 * K, W3, bias,
                       gate ? gate + (size_t)(m0 / HW) * K : nullptr, R ? R + (size_t)m0 * N : nullptr, Y + (size_t)m0 * N,
                       mc, K, N, HW, act, none, 0, s, sec);

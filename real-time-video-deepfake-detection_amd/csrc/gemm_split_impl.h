@@ -881,7 +881,7 @@ template <int NT, int NK, bool GATE, int NW, typename XT, int NP>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : NT * NK <= 10 ? 3 : 2)) void pw8_kernel(const XT* __restrict__ X, const unsigned short* __restrict__ W3, int plane,
                                                       int Kp, const float* __restrict__ bias, const float* __restrict__ gate,
                                                       const XT* __restrict__ R, XT* __restrict__ Y, int M, int K, int N,
-                                                      int tpg, int tpb, int act, int res_first, unsigned xbytes) {
+                                                      int tpg, int tpb, int act, int res_first, unsigned xbytes, SeFuse se) {
     constexpr int BK = S6_BK, BN = NT * 16, NTHR = NW * 64;
     constexpr int ESZ = (int)sizeof(XT), XL = ESZ == 4 ? 2 : 1, NXS = ESZ == 4 ? 3 : 1;
     static_assert(NP == 3 || (NP == 1 && ESZ == 2), "weight planes: 3 (fp32-exact), or 1 with bf16 activations");
@@ -944,12 +944,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : NT * NK <= 10 ? 3 : 2)) voi
         }
         constexpr int GL = (2 * NK * BK + NTHR - 1) / NTHR;
         const int img_last = GATE ? (M - 1) / (tpg * 16) : 0;
+        const bool own_gate = GATE && se.P != nullptr;               // this block evaluates its images' gates itself (below)
         float gv[GL];
 #pragma unroll
         for (int t = 0; t < GL; ++t) {
             const int e = tid + t * NTHR, im = e >= NK * BK ? 1 : 0, k = e - im * NK * BK;
             const int img = img0 + im < img_last ? img0 + im : img_last;
-            gv[t] = GATE ? gate[(size_t)img * K + (k < K ? k : 0)] : 1.f;
+            gv[t] = GATE && !own_gate ? gate[(size_t)img * K + (k < K ? k : 0)] : 1.f;
         }
 #pragma unroll
         for (int t = 0; t < WLOADS; ++t) {
@@ -962,6 +963,60 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : NT * NK <= 10 ? 3 : 2)) voi
         for (int t = 0; t < GL; ++t) {
             const int e = tid + t * NTHR, im = e >= NK * BK ? 1 : 0, k = e - im * NK * BK;
             if (e < 2 * NK * BK) gs[im][k] = k < K ? gv[t] : 0.f;
+        }
+    }
+    if constexpr (GATE) {
+        // Squeeze-excite of the block's (at most two) images by the block itself: on these layers (C <= 256, c_se <= 16) the
+        // gate is ~5 k MACs per image and the separate se_kernel launch 10-13 us of launch + three dependent round trips on an
+        // otherwise idle chip.  MEASURED (option "se_thin", batch 256): the five projections 105 / 69 / 134 / 34 / 58 -> 130 / 82 /
+        // 159 / 41 / 73 us - +85 us for 54 us of se_kernel launches: every block re-reads its images' pool partials (98 x 32
+        // floats per image in block 0) behind two barriers before its first tile, and the tuner answers with fewer, longer
+        // blocks.  Third form of "squeeze-excite inside a neighbouring launch" that loses (fuse_se, se_in_proj): off.  Fixed
+        // summation orders (tile sums as four strided chains folded pairwise, FC1 in 8 lanes per output + xor tree, FC2 as a
+        // chain from the bias): every block that meets an image writes the same gate bits.
+        if (se.P != nullptr) {
+            float* mean_s = reinterpret_cast<float*>(&os[0][0]);     // [2][SE_THIN_MAX_C] (the output image is not in use yet)
+            float* z_s = mean_s + 2 * SE_THIN_MAX_C;                 // [2][SE_THIN_MAX_SE]
+            const int img_last = (M - 1) / (tpg * 16), C = K;
+            for (int e = tid; e < 2 * C; e += NTHR) {
+                const int im = e >= C ? 1 : 0, c = e - im * C;
+                const int img = img0 + im < img_last ? img0 + im : img_last;
+                const float* p = se.P + (size_t)img * se.tiles * C + c;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int t = 0;
+                for (; t + 3 < se.tiles; t += 4) {
+                    s0 += p[(size_t)t * C];
+                    s1 += p[(size_t)(t + 1) * C];
+                    s2 += p[(size_t)(t + 2) * C];
+                    s3 += p[(size_t)(t + 3) * C];
+                }
+                for (; t < se.tiles; ++t) s0 += p[(size_t)t * C];
+                mean_s[im * SE_THIN_MAX_C + c] = ((s0 + s1) + (s2 + s3)) * se.inv_hw;
+            }
+            __syncthreads();
+            for (int e = tid; e < 2 * SE_THIN_MAX_SE * 8; e += NTHR) {      // (image, output, part of 8): 256 work items
+                const int im = e >> 7, o = (e >> 3) & (SE_THIN_MAX_SE - 1), part = e & 7;
+                const int oo = o < se.c_se ? o : se.c_se - 1;
+                float v = 0.f;
+                for (int c = part; c < C; c += 8) v = __builtin_fmaf(mean_s[im * SE_THIN_MAX_C + c], se.w1[(size_t)oo * C + c], v);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 1);
+                if (part == 0 && o < se.c_se) z_s[im * SE_THIN_MAX_SE + o] = swish1(v + se.b1[o]);
+            }
+            __syncthreads();
+            for (int e = tid; e < 2 * NK * BK; e += NTHR) {
+                const int im = e >= NK * BK ? 1 : 0, c = e - im * NK * BK;
+                float g = 0.f;
+                if (c < C) {
+                    float sacc = se.b2[c];
+                    for (int o = 0; o < se.c_se; ++o) sacc = __builtin_fmaf(z_s[im * SE_THIN_MAX_SE + o], se.w2t[(size_t)o * C + c], sacc);
+                    g = sigmoid1(sacc);
+                    const int img = img0 + im < img_last ? img0 + im : img_last;
+                    if (img0 + im <= img_last) const_cast<float*>(gate)[(size_t)img * C + c] = g;      // for taps; every writer agrees
+                }
+                gs[im][c] = g;
+            }
         }
     }
     __syncthreads();
@@ -1104,7 +1159,7 @@ void s6_dispatch(const S6Tile& t, const XT* X, const unsigned short* W3, const f
             const int nblk = (ttot + tpb - 1) / tpb;
 #define DFD_S8_LAUNCH(NTV, NKV, NWV)                                                                                 \
     hipLaunchKernelGGL((pw8_kernel<NTV, NKV, GATE, NWV, XT, NP>), dim3(nblk), dim3(NWV * 64), 0, s, X, W3, plane, Kp, bias, \
-                       gate, R, Y, M, K, N, tpg, tpb, act, res_first, xbytes)
+                       gate, R, Y, M, K, N, tpg, tpb, act, res_first, xbytes, se)
 #define DFD_S8_CASE(NKV, NWV)                            \
     if (nk == NKV) {                                     \
         if (t.nt == 1) DFD_S8_LAUNCH(1, NKV, NWV);       \

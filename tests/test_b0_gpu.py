@@ -258,3 +258,26 @@ def test_fused_squeeze_excite_tail_matches_the_separate_launch(pkg, b0_handle, s
             xd.free()
     finally:
         b0_handle.set_option("fuse_se", 0)
+
+
+@pytest.mark.gpu
+def test_gate_from_the_narrow_projection_blocks_matches_se_kernel(pkg, seeded_sd):
+    """option "se_thin": blocks 0-4 evaluate the squeeze-excite gate in the prologue of the projection kernel's blocks
+    (another summation order than se_kernel: equal within rounding, logits within the oracle bar; measured slower - off)"""
+    rs = np.random.RandomState(5)
+    x = rs.randn(3, 3, 224, 224).astype(np.float32)
+    h = pkg._lib.Handle(pkg.weights.pack_b0(seeded_sd), device=0, max_batch=3)
+    try:
+        xd = h.alloc(x.nbytes).upload(x)
+        base = h.classify(x)
+        g_base = {k: h.tap(xd.ptr, 3, k, 3 * c).copy() for k, c in (("b0.gate", 32), ("b2.gate", 144), ("b4.gate", 240))}
+        h.set_option("se_thin", 1)
+        got = h.classify(x)
+        for k, c in (("b0.gate", 32), ("b2.gate", 144), ("b4.gate", 240)):
+            assert np.abs(h.tap(xd.ptr, 3, k, 3 * c) - g_base[k]).max() <= 1e-6, k
+        xd.free()
+        assert np.abs(got - base).max() <= 1e-4
+        again = h.classify(x)
+        assert np.array_equal(got, again)
+    finally:
+        h.close()
