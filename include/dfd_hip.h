@@ -301,8 +301,8 @@ int dfd_decode_jpeg(dfd_handle* h, const uint8_t* jpeg, size_t len, uint8_t* bgr
  * 512-byte chunk of the de-stuffed scan, the host decoder's speculative-chunk scheme as a fixed-point iteration) - the
  * JPEG bytes cross PCIe instead of 6.2 MB of coefficients per 1080p frame.  Restart-interval files, files of differing
  * sampling, and any frame the device decoder's own checks do not vouch for go through the host decoder; the result is
- * the same bits either way (tests pin both to libjpeg).  Options: "jpeg_device_entropy" (default 2: batches of at least
- * that many frames; 0 = never), "jpeg_chunk_bytes" (default 512).  dfd_jpeg_decode_counts: frames of batch calls decoded
+ * the same bits either way (tests pin both to libjpeg).  Options: "jpeg_device_entropy" (default 2: from 1 MiB of scan data
+ * per call - a small batch is quicker on the host pool; 1 = always; 0 = never), "jpeg_chunk_bytes" (default 512), "jpeg_rounds".  dfd_jpeg_decode_counts: frames of batch calls decoded
  * on the device / by the host decoder since dfd_create. */
 int dfd_decode_jpeg_batch(dfd_handle* h, int n, const uint8_t* const* jpegs, const size_t* lens, uint8_t* bgr_out, size_t capacity,
                           int* height, int* width);

@@ -140,8 +140,8 @@ struct dfd_handle {
     hipEvent_t jpeg_done[2] = {nullptr, nullptr}, frames_free[2] = {nullptr, nullptr};
     void* jpeg_host = nullptr;           // pinned host buffer the entropy decoder writes the coefficients into
     size_t jpeg_host_cap = 0;
-    int jpeg_device_entropy = 2;         // batches of at least this many restart-less JPEGs are entropy-decoded on the device
-                                         // (jpeg_gpu_entropy.h); 0 = never (option "jpeg_device_entropy")
+    int jpeg_device_entropy = 2;         // batch calls: 2 = restart-less JPEGs are entropy-decoded on the device (jpeg_gpu_entropy.h) from
+                                         // 1 MiB of scan data per call (below that the host pool is quicker), 1 = always, 0 = never
     int jpeg_rounds = 16;                // rounds of that decoder's fixed-point iteration (option "jpeg_rounds", 2 .. 32; converged rounds cost ~nothing)
     int jpeg_chunk_bytes = 512;          // bytes of de-stuffed scan per lane of that decoder (option "jpeg_chunk_bytes", >= 256, % 4)
     unsigned long long jpeg_frames_device = 0, jpeg_frames_host = 0;   // frames of batch calls decoded there / by the host decoder

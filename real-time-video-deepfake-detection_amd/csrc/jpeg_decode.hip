@@ -646,7 +646,14 @@ int jpeg_decode_batch_to(dfd_handle* h, const uint8_t* const* jpegs, const size_
         return fail(h, DFD_ERR_UNSUPPORTED, "analyze_stream_batch: %d frames of %d x %d exceed the %zu-pixel budget of one request", n,
                     P[0].width, P[0].height, kMaxBatchPixels);
     if (!frames_dev) return DFD_OK;
-    if (h->jpeg_device_entropy && n >= h->jpeg_device_entropy && jpeg_gpu_batch_ok(h, P, L, n)) {
+    // Which decoder: the device path costs ~1.6 ms whatever the batch holds (three latency-bound passes) + 0.13 ms per MB,
+    // the host pool ~0.45 ms + 1.0-1.5 ms per MB (profiles/jpeg_batch_latency_probe.py: 8 x 480p 0.8 vs 1.7 ms, 8 x 1080p
+    // 4.1 vs 2.4 ms, 32 x 1080p 10.5 vs 2.9 ms): option "jpeg_device_entropy" = 2 (default) takes the device from 1 MiB of
+    // entropy-coded data per call, 1 always, 0 never
+    size_t scan_bytes = 0;
+    for (int i = 0; i < n; ++i) scan_bytes += (size_t)(P[i].end - P[i].scan);
+    const bool want_device = h->jpeg_device_entropy == 1 || (h->jpeg_device_entropy >= 2 && scan_bytes >= ((size_t)1 << 20));
+    if (want_device && jpeg_gpu_batch_ok(h, P, L, n)) {
         // the scans go up as bytes (16-byte aligned starts, 16 bytes of slack each) and are decoded there
         std::vector<uint32_t> roff(n), rlen(n);
         size_t up = 0;

@@ -192,9 +192,13 @@ def _noise(h, w, seed):
 def test_device_entropy_batch_equals_libjpeg(b0_handle, h, w, kw):
     """three different files of one size per batch: every frame == Pillow's decode, and the device decoder did them"""
     datas = [_jpeg(_img(h, w, h * 1000 + w + i), **kw) for i in range(3)]
-    d0, h0 = b0_handle.jpeg_decode_counts()
-    got = b0_handle.decode_jpeg_batch(datas)
-    d1, h1 = b0_handle.jpeg_decode_counts()
+    b0_handle.set_option("jpeg_device_entropy", 1)                  # always (the default sends batches under 1 MiB to the host pool)
+    try:
+        d0, h0 = b0_handle.jpeg_decode_counts()
+        got = b0_handle.decode_jpeg_batch(datas)
+        d1, h1 = b0_handle.jpeg_decode_counts()
+    finally:
+        b0_handle.set_option("jpeg_device_entropy", 2)
     for i, data in enumerate(datas):
         assert np.array_equal(got[i], _pil_bgr(data)), i
     # (the size query decodes nothing; the second call decodes the three frames)
@@ -206,9 +210,12 @@ def test_device_entropy_worst_case_texture_and_gray(b0_handle):
     """random texture at 1080p (1.2 MB of entropy-coded data per frame, 2,400 lanes each), gray files, and a batch whose
     frames carry their own optimised tables"""
     datas = [_jpeg(_noise(1080, 1920, 70 + i), quality=85) for i in range(4)]
-    got = b0_handle.decode_jpeg_batch(datas)
+    d0, h0 = b0_handle.jpeg_decode_counts()
+    got = b0_handle.decode_jpeg_batch(datas)                        # 5 MB of scans: the default picks the device
+    assert b0_handle.jpeg_decode_counts() == (d0 + 4, h0)
     for i, data in enumerate(datas):
         assert np.array_equal(got[i], _pil_bgr(data)), i
+    b0_handle.set_option("jpeg_device_entropy", 1)
     gray = [_jpeg(_img(200, 333, 32 + i)[..., 0], quality=80) for i in range(2)]
     got = b0_handle.decode_jpeg_batch(gray)
     for i, data in enumerate(gray):
@@ -217,12 +224,18 @@ def test_device_entropy_worst_case_texture_and_gray(b0_handle):
     got = b0_handle.decode_jpeg_batch(opt)
     for i, data in enumerate(opt):
         assert np.array_equal(got[i], _pil_bgr(data)), i
+    b0_handle.set_option("jpeg_device_entropy", 2)
+    small = [_jpeg(_img(120, 160, 50 + i), quality=85) for i in range(3)]
+    d0, h0 = b0_handle.jpeg_decode_counts()
+    got = b0_handle.decode_jpeg_batch(small)                        # 30 KB: the default leaves it to the host pool
+    assert b0_handle.jpeg_decode_counts() == (d0, h0 + 3) and all(np.array_equal(got[i], _pil_bgr(small[i])) for i in range(3))
 
 
 @pytest.mark.gpu
 def test_device_entropy_result_does_not_depend_on_the_chunk_size(b0_handle):
     datas = [_jpeg(_img(480, 640, 90 + i), quality=85) for i in range(2)] + [_jpeg(_noise(480, 640, 3), quality=95)]
     want = [_pil_bgr(d) for d in datas]
+    b0_handle.set_option("jpeg_device_entropy", 1)
     try:
         for chunk in (256, 512, 1024, 4096, 65536):
             b0_handle.set_option("jpeg_chunk_bytes", chunk)
@@ -230,6 +243,7 @@ def test_device_entropy_result_does_not_depend_on_the_chunk_size(b0_handle):
             assert all(np.array_equal(g, w) for g, w in zip(got, want)), chunk
     finally:
         b0_handle.set_option("jpeg_chunk_bytes", 512)
+        b0_handle.set_option("jpeg_device_entropy", 2)
 
 
 @pytest.mark.gpu
@@ -237,6 +251,7 @@ def test_device_entropy_leaves_what_it_cannot_vouch_for_to_the_host_decoder(pkg,
     """restart-interval files and batches of mixed sampling take the host path (same bits); a truncated scan is an error
     from whichever decoder meets it; the option switches the device decoder off"""
     h = b0_handle
+    h.set_option("jpeg_device_entropy", 1)
     rst = [_jpeg(_img(64, 96, 5 + i), quality=80, restart_marker_blocks=3) for i in range(2)]
     d0, h0 = h.jpeg_decode_counts()
     got = h.decode_jpeg_batch(rst)
