@@ -403,6 +403,10 @@ static JpegGpuLayout jpeg_gpu_layout(const std::vector<Parsed>& P, const std::ve
 static bool jpeg_gpu_batch_ok(const dfd_handle* h, const std::vector<Parsed>& P, const std::vector<ScanLayout>& L, int n) {
     static const bool off = getenv("DFD_JPEG_DEVICE_ENTROPY") && atoi(getenv("DFD_JPEG_DEVICE_ENTROPY")) == 0;
     if (off || n < 1 || n > 65535) return false;
+    // the device descriptors address scans, the de-stuffed image and coefficients with 32-bit offsets
+    size_t scan_total = 0;
+    for (int i = 0; i < n; ++i) scan_total += (size_t)(P[i].end - P[i].scan) + 65536 + 64 * (size_t)h->jpeg_chunk_bytes;
+    if (scan_total >= ((size_t)1 << 31) || (size_t)n * (L[0].total * 64 + 256) >= ((size_t)1 << 31)) return false;
     for (int i = 0; i < n; ++i) {
         if (!jg_supported(P[i], L[i])) return false;
         if (P[i].ncomp != P[0].ncomp || P[i].hmax != P[0].hmax || P[i].vmax != P[0].vmax || P[i].width != P[0].width ||
@@ -900,15 +904,24 @@ int dfd_analyze_jpegs_host(dfd_handle* h, const uint8_t* const* jpegs, const siz
     int started = 0, analysed = -1, prod_rc = DFD_OK;                // chunks started / chunks whose analysis is queued
     bool stop = false;
     if ((rc = start(0))) return rc;
-    std::thread producer([&] {
-        hipSetDevice(h->device);
+    auto produce = [&] {                                            // (no exception leaves the thread: it would end the process)
+        if (hipSetDevice(h->device) != hipSuccess) {
+            { std::lock_guard<std::mutex> lk(mu); prod_rc = DFD_ERR_HIP; }
+            cv.notify_all();
+            return;
+        }
         for (int k = 1; k < nb; ++k) {
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return stop || analysed >= k - 2; });
                 if (stop) return;
             }
-            const int r = start(k);
+            int r;
+            try {
+                r = start(k);
+            } catch (...) {
+                r = fail(h, DFD_ERR_CAPACITY, "analyze_jpegs_host: out of host memory while starting chunk %d", k);
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (r) prod_rc = r; else started = k;
@@ -916,7 +929,13 @@ int dfd_analyze_jpegs_host(dfd_handle* h, const uint8_t* const* jpegs, const siz
             cv.notify_all();
             if (r) return;
         }
-    });
+    };
+    std::thread producer;
+    try {
+        producer = std::thread(produce);
+    } catch (...) {
+        return fail(h, DFD_ERR_STATE, "analyze_jpegs_host: cannot start the producer thread");
+    }
     struct Join {
         std::thread& t; std::mutex& mu; std::condition_variable& cv; bool& stop;
         ~Join() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); }
