@@ -807,13 +807,14 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      # the contract's fraction prices ALGORITHMIC depthwise bytes (25.11 MB per crop) against the 16 launches'
-                     # time; with the expand convs inside those launches (blocks 1-10, 12-15) their time also holds 302 of the
+                     # time; with the expand convs inside those launches (blocks 1-10, 12-15) their time also holds most of the
                      # net's 385 MMAC per crop, so beside it: the bytes the launches really moved (PMC) over the same time
                      "frac_bytes_moved": round(moved / HBM_PEAK_GBS, 4) if moved else None,
                      "achieved_bytes_moved": round(moved, 1) if moved else None,
                      "kernel": "the 16 depthwise launches per step: dfd::stem_dw_kernel (stem + block 0), dfd::mbconv_kernel / "
-                               "mbconv2_kernel (blocks 1-5: 1x1 expand + depthwise), dfd::mbconv_late_kernel (blocks 6-10, 12-15: "
-                               "expand + depthwise of whole images; option fuse_late, default on), dfd::dw_kernel (block 11)",
+                               "mbconv2_kernel (blocks 1-5: 1x1 expand + depthwise), dfd::mbconv_late_kernel (blocks 6, 7, 10, 12-15: "
+                               "expand + depthwise of whole images; option fuse_late, default on, per block where it measures "
+                               "faster), dfd::dw_kernel / dw_rows7_kernel (blocks 8, 9, 11)",
                      "algorithmic_bytes_per_step": dw_bytes, "ms_per_step": round(dw_ms, 4),
                      "share_of_step": round(dw_ms / all_ms, 4) if all_ms else None,
                      "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "

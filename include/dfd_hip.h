@@ -62,6 +62,8 @@ int dfd_max_batch(const dfd_handle* h);
  *   "fuse_late" (default 1 since round 4, env DFD_FUSE_LATE; needs "fuse_expand"): blocks 6-10 and 12-15 (14 x 14 / 7 x 7
  *   maps) do the same with whole images per thread block - the faster configuration; 0 = expand
  *   GEMM and depthwise kernel as separate launches.
+ *   "fuse_late_skip" (default blocks 8 and 9: bit b set = block b keeps separate launches although "fuse_late" is on; chosen
+ *   per block by measurement at batch 256).
  *   "se_in_proj" (default 0, env DFD_SE_IN_PROJ; measured slower, kept for the measurement): where a depthwise launch leaves final per-image pool sums (the
  *   whole-image launches of "fuse_late") the projection GEMM's blocks evaluate the squeeze-excite gate themselves
  *   (se_kernel's arithmetic, identical gate bits) instead of a separate launch per block.

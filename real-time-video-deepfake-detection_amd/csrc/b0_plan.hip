@@ -250,11 +250,14 @@ static int b0_forward_t(dfd_handle* h, const float* x, int n, float* logits_dev,
         int tiles = 0;
         bool fused = false;
         const unsigned short* we3 = nullptr;
-        if (b.expand != 1 && h->fuse_expand && mbconv_tiles(b.h_in, b.c_exp, b.kernel, b.stride, b.c_in, h->fuse_late) > 0 &&
+        // whole-image launches (blocks 6-15) where they measure faster: per block, batch 256 (section 5, round 4) - blocks 8
+        // and 9 (k5, 480 / 672 channels at 14 x 14) are 2-4 us quicker as expand GEMM + depthwise kernel ("fuse_late_skip")
+        const bool late_here = h->fuse_late && !((h->fuse_late_skip >> bi) & 1u);
+        if (b.expand != 1 && h->fuse_expand && mbconv_tiles(b.h_in, b.c_exp, b.kernel, b.stride, b.c_in, late_here) > 0 &&
             !(we3 = split_weights(h, b.exp_w, b.c_exp, b.c_in))) return DFD_ERR_HIP;
         if (we3 && launch_mbconv_front<XT>(cur, b.c_in, we3, (int)split_weights_count(b.c_exp, b.c_in), (b.c_in + 63) / 64 * 64,
                                            b.exp_w, b.exp_b, b.dw_w, b.dw_b, dwbuf, h->pool, n, b.h_in, b.c_exp,
-                                           b.kernel, b.stride, b.pad_lo, &tiles, s, se_of(b), h->fuse_late)) {
+                                           b.kernel, b.stride, b.pad_lo, &tiles, s, se_of(b), late_here)) {
             fused = true;
             mk.mark(layer_name(bi, "dw"));            // expand + depthwise in one launch
             if (tap && tap->name && q + ".exp" == tap->name)

@@ -39,6 +39,7 @@ int create_impl(dfd_handle* h, int device, const void* blob, size_t blob_len, in
     if (const char* e = getenv("DFD_FUSE_STEM")) h->fuse_stem = atoi(e) != 0;
     if (const char* e = getenv("DFD_FUSE_SE")) h->fuse_se = atoi(e) != 0;
     if (const char* e = getenv("DFD_FUSE_LATE")) h->fuse_late = atoi(e) != 0;
+    if (const char* e = getenv("DFD_FUSE_LATE_SKIP")) h->fuse_late_skip = (unsigned)atoi(e);
     if (const char* e = getenv("DFD_SE_IN_PROJ")) h->se_in_proj = atoi(e) != 0;
     if (const char* e = getenv("DFD_SPLIT_GEMM")) h->split_gemm = atoi(e) != 0;
     if (const char* e = getenv("DFD_BF16_ACTIVATIONS")) h->act_bf16 = atoi(e) != 0;
@@ -168,6 +169,7 @@ int dfd_set_option(dfd_handle* h, const char* name, int value) {
     if (strcmp(name, "fuse_expand") == 0) { h->fuse_expand = value != 0; return DFD_OK; }
     if (strcmp(name, "fuse_se") == 0) { h->fuse_se = value != 0; return DFD_OK; }
     if (strcmp(name, "fuse_late") == 0) { h->fuse_late = value != 0; return DFD_OK; }
+    if (strcmp(name, "fuse_late_skip") == 0) { h->fuse_late_skip = (unsigned)value; return DFD_OK; }
     if (strcmp(name, "se_in_proj") == 0) { h->se_in_proj = value != 0; return DFD_OK; }
     if (strcmp(name, "se_thin") == 0) { h->se_thin = value != 0; return DFD_OK; }
     if (strcmp(name, "fuse_stem") == 0) { h->fuse_stem = value != 0; return DFD_OK; }

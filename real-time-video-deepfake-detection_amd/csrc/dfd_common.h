@@ -121,6 +121,9 @@ struct dfd_handle {
     bool fuse_expand = true;             // MBConv blocks 1-5: expand conv computed inside the depthwise kernel
     bool fuse_late = true;               // blocks 6-10 / 12-15: expand + depthwise of whole images in one launch (mbconv_late_kernel):
                                          // the faster configuration (round 3: +2.2-2.6 % per step, strictly fewer bytes), default since round 4
+    unsigned fuse_late_skip = (1u << 8) | (1u << 9);   // blocks that keep expand GEMM + depthwise kernel although fuse_late is on:
+                                         // measured per block at batch 256 (fused - separate, us): b6 -17.8, b7 -5.5, b8 +2.1, b9 +3.6,
+                                         // b10 -1.4, b12 -9.8, b13 -4.9, b14 -4.7, b15 -2.3 (option "fuse_late_skip", a bit per block)
     bool fuse_se = false;                // squeeze-excite gate computed by the last block of each image inside the depthwise launch
                                          // (measured slower than the separate launch: DESIGN.md section 5, round 3; kept as an option)
     bool se_in_proj = false;             // squeeze-excite gate evaluated by the projection GEMM's blocks where the pool sums are final

@@ -77,6 +77,7 @@ def test_late_blocks_in_one_launch_match_oracle(b0_handle, ref):
     n = x.shape[0]
     xd = b0_handle.alloc(x.nbytes).upload(x)
     b0_handle.set_option("fuse_late", 1)
+    b0_handle.set_option("fuse_late_skip", 0)               # every block the kernel covers (the default leaves 8 and 9 out)
     try:
         for i in range(6, 16):
             for kind in ("dw", "gate", "out"):
@@ -93,8 +94,16 @@ def test_late_blocks_in_one_launch_match_oracle(b0_handle, ref):
         assert np.abs(got - want).max() <= LOGIT_TOL
         for m in (1, 2):                                    # 7 x 7 blocks hold four images: ragged last group
             assert np.abs(b0_handle.classify(x[:m]) - want[:m]).max() <= LOGIT_TOL
+        # the default: blocks 8 and 9 keep expand GEMM + depthwise kernel (measured faster) - their expanded tensor exists
+        b0_handle.set_option("fuse_late_skip", (1 << 8) | (1 << 9))
+        w = _nhwc(taps["b9.exp"])
+        assert np.abs(b0_handle.tap(xd.ptr, n, "b9.exp", w.size).reshape(w.shape) - w).max() <= LOGIT_TOL
+        with pytest.raises(Exception):
+            b0_handle.tap(xd.ptr, n, "b10.exp", 10)
+        assert np.abs(b0_handle.classify(x) - want).max() <= LOGIT_TOL
     finally:
-        b0_handle.set_option("fuse_late", 1)               # the default
+        b0_handle.set_option("fuse_late", 1)               # the defaults
+        b0_handle.set_option("fuse_late_skip", (1 << 8) | (1 << 9))
         xd.free()
 
 
