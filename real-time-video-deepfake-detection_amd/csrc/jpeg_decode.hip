@@ -666,7 +666,9 @@ int jpeg_decode_batch_to(dfd_handle* h, const uint8_t* const* jpegs, const size_
             rlen[i] = (uint32_t)(P[i].end - P[i].scan);
             up += al256((size_t)rlen[i] + 16);
         }
-        const int chunk_bytes = h->jpeg_chunk_bytes;
+        // a pass costs one lane's sequential decode whatever the batch holds: a small batch (few waves anyway) takes half-size
+        // chunks - half the latency per pass; a large one keeps the configured size (fewer lanes, less speculation overhead)
+        const int chunk_bytes = scan_bytes < ((size_t)8 << 20) && h->jpeg_chunk_bytes > 256 ? h->jpeg_chunk_bytes / 2 : h->jpeg_chunk_bytes;
         const JpegGpuLayout W = jpeg_gpu_layout(P, L, rlen.data(), n, chunk_bytes);
         const size_t stage_bytes = jpeg_gpu_stage_bytes(W, n);
         if ((rc = jpeg_pinned(h, up + stage_bytes))) return rc;
