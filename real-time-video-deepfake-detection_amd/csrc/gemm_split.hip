@@ -80,7 +80,8 @@ static S6Tile pick_tile6(int M, int N) {
 // Every instance the library can launch for a shape, in a fixed order (what the tuner measures and what
 // dfd_set_option(h, "gemm_tile", i) indexes): pw6 with 4 waves (KS x MT x NT), pw6 with 8 waves (KS x NT), pw7.
 // thin: the shape and call may also run pw8 (all of N per wave, weights resident in LDS; s6_thin below) - appended last
-static std::vector<S6Tile> s6_candidates(int M, int K, int N, bool thin = false) {
+// wide: the call may run pw9 (activations resident in registers, all column blocks per block; s6_wide in s6_run_one)
+static std::vector<S6Tile> s6_candidates(int M, int K, int N, bool thin = false, bool wide = false) {
     const int tiles = (N + 15) / 16;
     std::vector<S6Tile> raw, out;
     for (int ks = 1; ks <= (K > 32 ? 2 : 1); ++ks)
@@ -98,6 +99,8 @@ static std::vector<S6Tile> s6_candidates(int M, int K, int N, bool thin = false)
         out.push_back(t);
     }
     if (out.empty()) out.push_back(make_tile6(M, N, 1, 1));
+    if (wide)
+        for (int nt : {6, 4}) out.push_back(make_tile(M, N, 3, 4, 1, 2, nt, 1));
     if (thin)
         for (int bpc : {2, 3, 4, 6, 8, 12, 16, 24}) out.push_back(make_tile(M, N, 2, s8_waves(K), 1, 1, tiles, bpc));      // ks = blocks per CU (grid: dispatcher)
     return out;
@@ -157,7 +160,7 @@ int s6_table_import(S6Table* t, const char* text, size_t len) {
                    &v[6], &v[7], &v[8], &v[9]) == 10) {
             // accept only tiles the dispatcher can launch for this shape
             bool known = false;
-            for (const S6Tile& c : s6_candidates(v[0], v[1], v[2], (v[3] & 128) != 0))
+            for (const S6Tile& c : s6_candidates(v[0], v[1], v[2], (v[3] & 128) != 0, (v[3] & 64) != 0))
                 known |= c.kind == v[4] && c.wm == v[5] && c.wn == v[6] && c.mt == v[7] && c.nt == v[8] && c.ks == v[9];
             if (known) {
                 S6Tile tile = make_tile(v[0], v[2], v[4], v[5], v[6], v[7], v[8], v[9]);
@@ -230,8 +233,10 @@ static void s6_run_one(S6Table* tab, bool conv, bool gated, const XT* X, const u
     const bool thin = thin_env && !conv && s8_supports(K, N) && (!gated || (HW % 16 == 0 && M % HW == 0)) && act != ACT_PRELU &&
                       !(R && res_first) && (!se.P || (se.thin && se_thin_supported(K, se.c_se)));
     // se.thin: nobody launched se_kernel - only pw8 can take the call (the plan asked split_gemm_thin_supports first)
+    static const bool wide_env = !(getenv("DFD_S6_WIDE") && atoi(getenv("DFD_S6_WIDE")) == 0);
+    const bool wide = wide_env && !conv && !gated && sizeof(XT) == 4 && NP == 3 && s9_supports(K, N) && act != ACT_PRELU && !se.P && !R;
     auto candidates = [&]() {
-        std::vector<S6Tile> c = s6_candidates(M, K, N, thin);
+        std::vector<S6Tile> c = s6_candidates(M, K, N, thin, wide);
         if (se.P && se.thin) c.erase(std::remove_if(c.begin(), c.end(), [](const S6Tile& t) { return t.kind != 2; }), c.end());
         return c;
     };
@@ -248,7 +253,7 @@ static void s6_run_one(S6Table* tab, bool conv, bool gated, const XT* X, const u
             mkey = ((M + (1 << sh) - 1) >> sh) << sh;
         }
         const S6Key key{mkey, K, N, (conv ? 1 : 0) | (gated ? 2 : 0) | (sizeof(XT) == 2 ? 4 : 0) | (NP == 1 ? 8 : 0) |
-                                        (se.P ? 16 : 0) | (thin ? 128 : 0) | (conv ? (g.ksize << 8) | (g.stride << 4) : 0)};
+                                        (se.P ? 16 : 0) | (thin ? 128 : 0) | (wide ? 64 : 0) | (conv ? (g.ksize << 8) | (g.stride << 4) : 0)};
         const bool tuning = tab && tab->tuning && tune_env;
         auto it = tab ? tab->tiles.find(key) : std::map<S6Key, S6Tile>::iterator();
         if (tab && it != tab->tiles.end() && (it->second.measured || !tuning)) {

@@ -1113,6 +1113,148 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : NT * NK <= 10 ? 3 : 2)) voi
 }
 
 // shapes pw8 is instantiated for: all of N in NT 16-column tiles (N <= 48, N % 4 == 0), K in NK K-steps exactly
+// ------------------------------------------------------------------------------------------------------
+// pw9_kernel (round 4): the wide expansions that still run as their own launch (blocks 8, 9, 11: K = 80 / 112, N = 480 /
+// 672 over 50,176 rows).  With K this short a pw6 block is a prologue, three or four K-steps and an epilogue of twelve
+// tiles, and every one of the N / 96 blocks of a row range loads and splits the same activations again (MFMA busy 0.30 of
+// the launch).  Here a block keeps its 128 rows' split activations IN REGISTERS (MT = 2 row tiles x NKC K-steps x three
+// bf16 planes per wave) and walks ALL column blocks itself: the weight stream (the only thing that changes) runs through
+// the double-buffered LDS stage continuously across column blocks, the split happens once.  Products and epilogue are
+// pw6's (s6_products / s6_epilogue): identical bits, a candidate of the tile tests.  Measured (tuner, batch 256): K = 80,
+// N = 480 40.2 -> 38.7 us, K = 112, N = 672 65.8 -> 60.9 us - the launch writes 96 / 135 MB and that is most of its time
+// (2.2 TB/s; MFMA work 18 us), the redundant splits were the smaller part.
+template <int NT, int NKC, typename XT, int NP>
+__global__ __launch_bounds__(256, 2) void pw9_kernel(const XT* __restrict__ X, const unsigned short* __restrict__ W3, int plane, int Kp,
+                                                     const float* __restrict__ bias, XT* __restrict__ Y, int M, int K, int N, int act,
+                                                     unsigned xbytes) {
+    static_assert(sizeof(XT) == 4 && NP == 3, "fp32 activations, three weight planes");
+    constexpr int BK = S6_BK, MT = 2, BN = NT * 16, BM = 4 * MT * 16;
+    constexpr int CHUNKS = BN * 12, WLOADS = (CHUNKS + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char ws[2][BN * S6_ROWB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * BM, nblocks = (N + BN - 1) / BN;                             // (K + 31) / 32 == NKC (host)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<XT*>(X), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W3), 0, 6 * plane, 0x00020000);
+    int m[MT];
+    // weight chunk t of this thread, as in pw6: (row, plane, k-octet) -> global / LDS offsets
+    int wvo[WLOADS], wlds[WLOADS];
+#pragma unroll
+    for (int t = 0; t < WLOADS; ++t) {
+        const int e = tid + t * 256 < CHUNKS ? tid + t * 256 : CHUNKS - 1;
+        const int row = e / 12, rem = e - row * 12, pl = rem >> 2, c = rem & 3;
+        wvo[t] = 2 * (pl * plane + row * Kp + 8 * c);
+        wlds[t] = row * S6_ROWB + s6_chunk_pos(row, pl * 4 + c) * 16;
+    }
+    u4 wr[WLOADS];
+    auto load_w = [&](int nb, int ks) {                              // stage (nb, ks): rows nb * BN .., k = 32 ks ..
+#pragma unroll
+        for (int t = 0; t < WLOADS; ++t) wr[t] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[t], 2 * (nb * BN * Kp + ks * BK), 0);
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < WLOADS; ++t) *reinterpret_cast<u4*>(&ws[buf][wlds[t]]) = wr[t];
+    };
+    load_w(0, 0);
+    // the block's activations: loaded and split once
+    bf8 xs[NKC][MT][3];
+    {
+        const int over = (NKC - 1) * BK + 8 * q - (K - 8);
+        int vb[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            m[mt] = m0 + wave * (MT * 16) + mt * 16 + j;
+            vb[mt] = 4 * ((m[mt] < M ? m[mt] : M - 1) * K + 8 * q);
+        }
+        // (two K-steps at a time: the raw fragments of all four next to their twelve planes do not fit 256 registers)
+#pragma unroll
+        for (int k0 = 0; k0 < NKC; k0 += 2) {
+            v4f xr[2][MT][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int ks = k0 + kk < NKC ? k0 + kk : NKC - 1;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int vo = vb[mt] - (ks == NKC - 1 && over > 0 ? 4 * over : 0);
+                    xr[kk][mt][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 4 * BK * ks, 0));
+                    xr[kk][mt][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + 16, 4 * BK * ks, 0));
+                }
+            }
+            if (k0 == 0) store_w(0);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                if (k0 + kk < NKC) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        split8(xr[kk][mt][0], xr[kk][mt][1], xs[k0 + kk][mt][0], xs[k0 + kk][mt][1], xs[k0 + kk][mt][2]);
+                }
+        }
+    }
+    __syncthreads();
+    const int rd0 = s6_chunk_pos(j, q) * 16, rd1 = s6_chunk_pos(j, 4 + q) * 16, rd2 = s6_chunk_pos(j, 8 + q) * 16;
+    auto read_w = [&](const unsigned char* wb, int nt, bf8 (&f)[3]) {
+        const unsigned char* wp = wb + (nt * 16 + j) * S6_ROWB;
+        f[0] = *reinterpret_cast<const bf8*>(wp + rd0);
+        f[1] = *reinterpret_cast<const bf8*>(wp + rd1);
+        f[2] = *reinterpret_cast<const bf8*>(wp + rd2);
+    };
+    int stage = 0;
+    for (int nb = 0; nb < nblocks; ++nb) {
+        v4f acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKC; ++ks, ++stage) {
+            // the next stage's weights (next K-step, or the first of the next column block; past the end: a repeat nobody reads)
+            const int nks = ks + 1 < NKC ? ks + 1 : 0, nnb = ks + 1 < NKC ? nb : (nb + 1 < nblocks ? nb + 1 : nb);
+            load_w(nnb, nks);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* wb = ws[stage & 1];
+            bf8 wf[2][3];
+            read_w(wb, 0, wf[0]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (nt + 1 < NT) read_w(wb, nt + 1, wf[(nt + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                s6_products<MT, 3, 3, NT>(acc, xs[ks], wf[nt & 1], nt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            store_w((stage + 1) & 1);
+            __syncthreads();
+        }
+        // s6_epilogue's operations without a residual (the host sends none here): bias, activation, store
+        {
+            v4f bv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nb * BN + nt * 16 + 4 * q;
+                bv[nt] = ldg4(bias + (n < N ? n : 0));
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nb * BN + nt * 16 + 4 * q;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    v4f v = acc[mt][nt] + bv[nt];
+                    if (act == ACT_SWISH) v = swish4(v);
+                    else if (act == ACT_RELU) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    if (n < N && m[mt] < M) st4(Y + (size_t)m[mt] * N + n, v);      // (non-temporal stores: measured, 1-2 us slower)
+                }
+            }
+        }
+    }
+}
+
+// shapes pw9 takes: plain (not gated, not convolved) fp32 1x1 convs with a short K and many column blocks
+#define DFD_S9_NK_CASES(OP) OP(3) OP(4)
+inline bool s9_supports(int K, int N) {
+    const int nk = (K + S6_BK - 1) / S6_BK;
+    return K % 8 == 0 && (nk == 3 || nk == 4) && N >= 192 && N % 4 == 0;
+}
+
 // (NK, waves per block): K = 240 (block 4) keeps two tiles of 8 K-steps in registers and 74 KB of weights in LDS - one
 // block of eight waves per CU
 #define DFD_S8_NK_CASES(OP) OP(1, 4) OP(3, 4) OP(5, 4) OP(8, 8)
@@ -1149,6 +1291,21 @@ void s6_dispatch(const S6Tile& t, const XT* X, const unsigned short* W3, const f
     const unsigned xbytes = CONV ? (unsigned)((size_t)(M / (g.Ho * g.Wo)) * g.H * g.W * g.Cin * sizeof(XT))
                                  : (unsigned)((size_t)M * K * sizeof(XT));
     const unsigned gbytes = GATE ? (unsigned)((size_t)((M + HW - 1) / HW) * K * 4) : 0u;
+    if (t.kind == 3) {
+        if constexpr (!CONV && !GATE && sizeof(XT) == 4 && NP == 3) {
+            const int nk = (K + S6_BK - 1) / S6_BK, mb = (M + 127) / 128;
+#define DFD_S9_CASE(NKV)                                                                                                     \
+    if (nk == NKV) {                                                                                                         \
+        if (t.nt == 6) hipLaunchKernelGGL((pw9_kernel<6, NKV, XT, NP>), dim3(mb), dim3(256), 0, s, X, W3, plane, Kp, bias, Y,    \
+                                          M, K, N, act, xbytes);                                                             \
+        else hipLaunchKernelGGL((pw9_kernel<4, NKV, XT, NP>), dim3(mb), dim3(256), 0, s, X, W3, plane, Kp, bias, Y, M, K, N,     \
+                                act, xbytes);                                                                                \
+    }
+            DFD_S9_NK_CASES(DFD_S9_CASE)
+#undef DFD_S9_CASE
+        }
+        return;
+    }
     if (t.kind == 2) {
         if constexpr (!CONV) {
             // t.ks = blocks per CU the grid aims at; equal shares of the matrix' tiles, at most one image's worth (a block
