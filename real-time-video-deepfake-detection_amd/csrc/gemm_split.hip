@@ -100,7 +100,10 @@ static std::vector<S6Tile> s6_candidates(int M, int K, int N, bool thin = false,
     }
     if (out.empty()) out.push_back(make_tile6(M, N, 1, 1));
     if (wide)
+    {
         for (int nt : {6, 4}) out.push_back(make_tile(M, N, 3, 4, 1, 2, nt, 1));
+        out.push_back(make_tile(M, N, 3, 4, 1, 2, 4, 2));              // ks = 2: the pipelined epilogue (two accumulator sets)
+    }
     if (thin)
         for (int bpc : {2, 3, 4, 6, 8, 12, 16, 24}) out.push_back(make_tile(M, N, 2, s8_waves(K), 1, 1, tiles, bpc));      // ks = blocks per CU (grid: dispatcher)
     return out;

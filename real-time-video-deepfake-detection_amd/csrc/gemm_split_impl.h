@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : NT * NK <= 10 ? 3 : 2)) voi
 // pw6's (s6_products / s6_epilogue): identical bits, a candidate of the tile tests.  Measured (tuner, batch 256): K = 80,
 // N = 480 40.2 -> 38.7 us, K = 112, N = 672 65.8 -> 60.9 us - the launch writes 96 / 135 MB and that is most of its time
 // (2.2 TB/s; MFMA work 18 us), the redundant splits were the smaller part.
-template <int NT, int NKC, typename XT, int NP>
+template <int NT, int NKC, bool PIPE, typename XT, int NP>
 __global__ __launch_bounds__(256, 2) void pw9_kernel(const XT* __restrict__ X, const unsigned short* __restrict__ W3, int plane, int Kp,
                                                      const float* __restrict__ bias, XT* __restrict__ Y, int M, int K, int N, int act,
                                                      unsigned xbytes) {
@@ -1197,54 +1197,119 @@ __global__ __launch_bounds__(256, 2) void pw9_kernel(const XT* __restrict__ X, c
         f[1] = *reinterpret_cast<const bf8*>(wp + rd1);
         f[2] = *reinterpret_cast<const bf8*>(wp + rd2);
     };
+    // finishing one tile of a column block: s6_epilogue's operations without a residual (the host sends none here)
+    auto finish_tile = [&](const v4f& a, const v4f& bv, int mt, int n) {
+        v4f v = a + bv;
+        if (act == ACT_SWISH) v = swish4(v);
+        else if (act == ACT_RELU) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (n < N && m[mt] < M) st4(Y + (size_t)m[mt] * N + n, v);      // (non-temporal stores: measured, 1-2 us slower)
+    };
+    auto load_bias = [&](int nb, v4f (&bv)[NT]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nb * BN + nt * 16 + 4 * q;
+            bv[nt] = ldg4(bias + (n < N ? n : 0));
+        }
+    };
     int stage = 0;
-    for (int nb = 0; nb < nblocks; ++nb) {
-        v4f acc[MT][NT];
+    if constexpr (!PIPE) {
+        for (int nb = 0; nb < nblocks; ++nb) {
+            v4f acc[MT][NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < NKC; ++ks, ++stage) {
-            // the next stage's weights (next K-step, or the first of the next column block; past the end: a repeat nobody reads)
-            const int nks = ks + 1 < NKC ? ks + 1 : 0, nnb = ks + 1 < NKC ? nb : (nb + 1 < nblocks ? nb + 1 : nb);
-            load_w(nnb, nks);
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* wb = ws[stage & 1];
-            bf8 wf[2][3];
-            read_w(wb, 0, wf[0]);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if (nt + 1 < NT) read_w(wb, nt + 1, wf[(nt + 1) & 1]);
+            for (int ks = 0; ks < NKC; ++ks, ++stage) {
+                // the next stage's weights (next K-step, or the first of the next column block; past the end: a repeat nobody reads)
+                const int nks = ks + 1 < NKC ? ks + 1 : 0, nnb = ks + 1 < NKC ? nb : (nb + 1 < nblocks ? nb + 1 : nb);
+                load_w(nnb, nks);
                 __builtin_amdgcn_sched_barrier(0);
-                s6_products<MT, 3, 3, NT>(acc, xs[ks], wf[nt & 1], nt);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            store_w((stage + 1) & 1);
-            __syncthreads();
-        }
-        // s6_epilogue's operations without a residual (the host sends none here): bias, activation, store
-        {
-            v4f bv[NT];
+                const unsigned char* wb = ws[stage & 1];
+                bf8 wf[2][3];
+                read_w(wb, 0, wf[0]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = nb * BN + nt * 16 + 4 * q;
-                bv[nt] = ldg4(bias + (n < N ? n : 0));
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = nb * BN + nt * 16 + 4 * q;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    v4f v = acc[mt][nt] + bv[nt];
-                    if (act == ACT_SWISH) v = swish4(v);
-                    else if (act == ACT_RELU) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
-                    if (n < N && m[mt] < M) st4(Y + (size_t)m[mt] * N + n, v);      // (non-temporal stores: measured, 1-2 us slower)
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (nt + 1 < NT) read_w(wb, nt + 1, wf[(nt + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    s6_products<MT, 3, 3, NT>(acc, xs[ks], wf[nt & 1], nt);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                store_w((stage + 1) & 1);
+                __syncthreads();
             }
+            v4f bv[NT];
+            load_bias(nb, bv);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) finish_tile(acc[mt][nt], bv[nt], mt, nb * BN + nt * 16 + 4 * q);
         }
+    } else {
+        // PIPE: two accumulator sets.  While the MFMAs of column block nb run (the matrix pipe works for 16 cycles per issue),
+        // the wave finishes the tiles of column block nb - 1 between them - bias, swish (~48 VALU instructions per tile) and
+        // the store: the epilogue that followed every K loop as a phase of its own rides inside the next one.  MEASURED (tuner,
+        // batch 256, NT = 4): 40.0 against 40.4 us (K = 80), 62.8 against 61.4 us (K = 112) - nothing: the launch is bound by its
+        // 96 / 135 MB of stores (2.3 TB/s), not by the serial VALU / MFMA phases.  Stays a candidate (never picked so far).
+        constexpr int TILES = MT * NT, TPS = (TILES + NKC - 1) / NKC;      // tiles of the previous block finished per K-step
+        v4f accs[2][MT][NT];
+        v4f bvp[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bvp[nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        auto body = [&](auto cur_c, int nb, bool have_prev) {
+            constexpr int cur = decltype(cur_c)::value;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) accs[cur][mt][nt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKC; ++ks, ++stage) {
+                const int nks = ks + 1 < NKC ? ks + 1 : 0, nnb = ks + 1 < NKC ? nb : (nb + 1 < nblocks ? nb + 1 : nb);
+                load_w(nnb, nks);
+                const unsigned char* wb = ws[stage & 1];
+                bf8 wf[2][3];
+                read_w(wb, 0, wf[0]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (nt + 1 < NT) read_w(wb, nt + 1, wf[(nt + 1) & 1]);
+                    s6_products<MT, 3, 3, NT>(accs[cur], xs[ks], wf[nt & 1], nt);
+                    // tiles ks * TPS .. of the previous block, spread over this K-step's MFMA groups
+#pragma unroll
+                    for (int i = 0; i < TPS; ++i) {
+                        if (((i + 1) * NT + TPS - 1) / TPS - 1 == nt) {
+                            const int e = ks * TPS + i;                // tile index: nt-major, mt inner (s6_epilogue's store order)
+                            if (e < TILES && have_prev) {
+                                const int pn = e / MT, pm = e - pn * MT;
+                                finish_tile(accs[cur ^ 1][pm][pn], bvp[pn], pm, (nb - 1) * BN + pn * 16 + 4 * q);
+                            }
+                        }
+                    }
+                }
+                store_w((stage + 1) & 1);
+                __syncthreads();
+            }
+            load_bias(nb, bvp);                                          // for this block's tiles, finished inside the next one
+        };
+        int nb = 0;
+        for (; nb + 2 <= nblocks; nb += 2) {
+            body(std::integral_constant<int, 0>{}, nb, nb > 0);
+            body(std::integral_constant<int, 1>{}, nb + 1, true);
+        }
+        if (nb < nblocks) {
+            body(std::integral_constant<int, 0>{}, nb, nb > 0);
+            ++nb;
+        }
+        // the last block's tiles
+        const int last = (nblocks - 1) & 1;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (last == 0) finish_tile(accs[0][mt][nt], bvp[nt], mt, (nblocks - 1) * BN + nt * 16 + 4 * q);
+                else finish_tile(accs[1][mt][nt], bvp[nt], mt, (nblocks - 1) * BN + nt * 16 + 4 * q);
+            }
     }
 }
 
@@ -1296,10 +1361,12 @@ void s6_dispatch(const S6Tile& t, const XT* X, const unsigned short* W3, const f
             const int nk = (K + S6_BK - 1) / S6_BK, mb = (M + 127) / 128;
 #define DFD_S9_CASE(NKV)                                                                                                     \
     if (nk == NKV) {                                                                                                         \
-        if (t.nt == 6) hipLaunchKernelGGL((pw9_kernel<6, NKV, XT, NP>), dim3(mb), dim3(256), 0, s, X, W3, plane, Kp, bias, Y,    \
-                                          M, K, N, act, xbytes);                                                             \
-        else hipLaunchKernelGGL((pw9_kernel<4, NKV, XT, NP>), dim3(mb), dim3(256), 0, s, X, W3, plane, Kp, bias, Y, M, K, N,     \
-                                act, xbytes);                                                                                \
+        if (t.nt == 6 && t.ks == 1) hipLaunchKernelGGL((pw9_kernel<6, NKV, false, XT, NP>), dim3(mb), dim3(256), 0, s, X, W3, plane, Kp, \
+                                                       bias, Y, M, K, N, act, xbytes);                                       \
+        else if (t.ks == 1) hipLaunchKernelGGL((pw9_kernel<4, NKV, false, XT, NP>), dim3(mb), dim3(256), 0, s, X, W3, plane, Kp, bias, \
+                                               Y, M, K, N, act, xbytes);                                                     \
+        else hipLaunchKernelGGL((pw9_kernel<4, NKV, true, XT, NP>), dim3(mb), dim3(256), 0, s, X, W3, plane, Kp, bias, Y, M, K, \
+                                N, act, xbytes);                                                                             \
     }
             DFD_S9_NK_CASES(DFD_S9_CASE)
 #undef DFD_S9_CASE
