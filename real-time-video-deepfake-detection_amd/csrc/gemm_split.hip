@@ -262,6 +262,10 @@ static void s6_run_one(S6Table* tab, bool conv, bool gated, const XT* X, const u
         if (tab && it != tab->tiles.end() && (it->second.measured || !tuning)) {
             tile = it->second;
         } else {
+            // A shape nobody warmed up (the classifier at the batch of the faces a step keeps, a request's few crops) keeps the
+            // pw6 heuristic: pw8 / pw9 are picked by MEASUREMENT only - un-warmed at small batches they lose (batch 71 / 16 / 4 / 1:
+            // 1.34 / 0.73 / 0.59 / 0.56 ms per forward against 1.31 / 0.66 / 0.50 / 0.47 with pw6; profiles/unwarmed_batch_probe.py):
+            // their blocks amortise a prologue over many tiles, and a short matrix has few.
             tile = se.P && se.thin ? candidates()[2] : pick_tile6(M, N);      // (thin-only list: 2, 3, 4 ... blocks per CU)
             if (tuning) s6_measure<XT, NP>(conv, gated, candidates(), &tile, key, X, W3, bias, gate, R, Y, M, K, N, HW, act, g, res_first, s, se);
             if (tab) tab->tiles[key] = tile;
