@@ -740,3 +740,54 @@ class Handle:
         self._check(self._lib.dfd_ssd_tap(self._p, _ptr(a), a.shape[0], a.shape[1], a.strides[0], name.encode(),
                                           _ptr(out), out.size, C.byref(cnt)))
         return out[: cnt.value]
+
+
+class ClassifierLanes:
+    """Several classifier forwards in flight on ONE device: `lanes` handles (each with its own stream and workspace,
+    the same weights and the same measured GEMM tiles) take batches in turn, every call asynchronous.
+
+    One batch-256 forward is ~54 dependent launches whose late layers (14 x 14 / 7 x 7 maps) leave CUs idle and whose
+    launch gaps are 4-5 us each; a second forward's kernels fill both (2.97 -> 2.78 ms per
+    batch).  The reference serves one frame at a time (deepfake_detection.py:357-406); a server that has two batches
+    queued is the case this class is for, and the results are the same bits whichever lane computes a batch."""
+
+    def __init__(self, blob: bytes, device: int = 0, max_batch: int = 8, lanes: int = 2, first: "Handle" = None):
+        if lanes < 1:
+            raise ValueError("lanes must be >= 1")
+        self.handles = [first if first is not None else Handle(blob, device=device, max_batch=max_batch)]
+        for _ in range(lanes - 1):
+            self.handles.append(Handle(blob, device=device, max_batch=max_batch))
+        self._owned = self.handles[1:] if first is not None else list(self.handles)
+        self._next = 0
+
+    def __len__(self):
+        return len(self.handles)
+
+    def warmup(self, n_crops: int):
+        """lane 0 measures the tiles, the others take its table (a lane that tuned for itself could pick another of the
+        bit-identical tiles; the table is shared so that every lane launches the same kernels)"""
+        self.handles[0].warmup(n_crops, 0)
+        table = self.handles[0].tiles_export()
+        for h in self.handles[1:]:
+            h.tiles_import(table)
+            h.warmup(n_crops, 0)
+
+    def set_option(self, name: str, value: int):
+        for h in self.handles:
+            h.set_option(name, value)
+
+    def submit(self, x_dev: int, n: int, logits_dev: int) -> int:
+        """queue one forward on the next lane (asynchronous); -> the lane index it went to"""
+        k = self._next
+        self.handles[k].classify_device(x_dev, n, logits_dev)
+        self._next = (k + 1) % len(self.handles)
+        return k
+
+    def sync(self):
+        for h in self.handles:
+            h.sync()
+
+    def close(self):
+        for h in self._owned:
+            h.close()
+        self._owned = []

@@ -156,3 +156,29 @@ def test_config4_one_workload_1080p_x64_forensics_bf16(pkg, big):
             assert r["flipped_votes"] == 0 and r["flipped_verdict_frames"] == 0, r
         assert r["flipped_votes"] <= r["frames_within_bf16_error"], r
     assert gate["per_threshold"][0]["threshold"] == 0.5 and gate["per_threshold"][1]["threshold"] == 0.55
+
+
+def test_two_forwards_in_flight_return_the_single_forward_bits(pkg, big, crops, seeded_sd, ssd_sd):
+    """bench.py's headline loop keeps two batch-256 forwards in flight (`ClassifierLanes`: a second handle with its own
+    stream and workspace).  Different inputs per lane, interleaved without a wait between them: every lane's logits equal
+    the single-handle run of the same crops bit for bit (other workspace, concurrent kernels, shared tile table)."""
+    x = crops.numpy()
+    xs = [x, np.ascontiguousarray(x[::-1]), x * np.float32(0.5)]
+    want = [big.classify(a) for a in xs]
+    lanes = pkg._lib.ClassifierLanes(pkg.weights.pack_all(seeded_sd, ssd_sd), device=0, max_batch=256, lanes=2, first=big)
+    bufs = []
+    try:
+        lanes.warmup(256)
+        assert lanes.handles[1].tiles_export() == big.tiles_export()
+        xd = [big.alloc(a.nbytes).upload(a) for a in xs]
+        yd = [big.alloc(256 * 4) for _ in range(6)]
+        bufs = xd + yd
+        went = [lanes.submit(xd[i % 3].ptr, 256, yd[i].ptr) for i in range(6)]       # six forwards, no wait in between
+        lanes.sync()
+        assert went == [0, 1, 0, 1, 0, 1]
+        for i in range(6):
+            assert np.array_equal(yd[i].download((256, 1)), want[i % 3]), i
+    finally:
+        for b in bufs:
+            b.free()
+        lanes.close()
