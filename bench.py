@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 BATCH = 256
 LANES = max(1, int(os.environ.get("DFD_BENCH_LANES", "2")))     # classifier forwards in flight in the headline loop
-PROFILE_EVERY = 20        # every 20th timed step (the first one of a default run) carries the per-launch events
+PROFILE_EVERY = 20        # every 20th timed step carries the per-launch events and runs alone (~0.7 ms of lost overlap each)
 E2E_FRAMES = 64
 
 
@@ -134,7 +134,7 @@ def _red_dev(local_rank):
     return "cpu" if REHEARSE else f"cuda:{local_rank}"
 
 
-def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, warmup=3):
+def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, warmup=3, blob=None):
     """BASELINE.json configs[2]/[3] as an extra: 1080p synthetic frames resident in HBM ->
     SSD detect (every frame) + 4 forced >=224x224 boxes per frame -> CLAHE -> 224x224 -> B0, without and
     with the six forensic signals.  Frames: np.random.default_rng(7 + rank).integers(50, 200)."""
@@ -180,6 +180,49 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, w
                     "ms_per_frame": round(dt / (frames_per_step * steps) * 1e3, 3),
                     "repeats_frames_per_s": [round(frames_per_step * steps * world / d, 1) for d in dts]}
     h.set_option("bf16_activations", 0)
+    # the same call with TWO of them in flight: a second handle (its own streams and workspaces, the same tile table) driven
+    # by a second host thread (the library calls release the GIL) - a server with two workers on one GPU.  One call is a
+    # chain of ~150 dependent launches and three stream waits; the other call's kernels fill its gaps and under-filled tails.
+    if world == 1 and blob is not None:
+        import threading
+
+        import rtdfd_amd
+
+        h2 = rtdfd_amd._lib.Handle(blob, device=local_rank, max_batch=h.max_batch)
+        try:
+            h2.tiles_import(h.tiles_export())
+            h2.warmup(h.max_batch, frames_per_step)
+
+            def calls(hh, forensic, k, keep):
+                r = None
+                for _ in range(k):
+                    r = hh.analyze_batch_device(fd.ptr, frames_per_step, H, W, forced_boxes=boxes, max_faces=K, with_forensics=forensic)
+                keep.append(r)
+
+            for key, forensic in (("detect_classify_two_calls_in_flight", False), ("detect_classify_forensics_two_calls_in_flight", True)):
+                want = []
+                calls(h, forensic, 1, want)
+                calls(h2, forensic, warmup, [])
+                dts, same = [], True
+                for _ in range(3):
+                    got = [[], []]
+                    th = [threading.Thread(target=calls, args=(hh, forensic, steps, got[i])) for i, hh in enumerate((h, h2))]
+                    h.sync(); h2.sync()
+                    t0 = time.perf_counter()
+                    for t in th:
+                        t.start()
+                    for t in th:
+                        t.join()
+                    dts.append(time.perf_counter() - t0)
+                    for g in got:
+                        same = same and g[0][0] == want[0][0] and np.array_equal(
+                            np.asarray(g[0][1], np.float32), np.asarray(want[0][1], np.float32), equal_nan=True)
+                dts.sort()
+                res[key] = {"frames_per_s": round(frames_per_step * steps * 2 / dts[1], 1), "calls_in_flight": 2,
+                            "repeats_frames_per_s": [round(frames_per_step * steps * 2 / d, 1) for d in dts],
+                            "boxes_and_logits_equal_the_single_call": bool(same)}
+        finally:
+            h2.close()
     # JPEG BYTES across PCIe instead of raw frames (reference backend_server.py:139-145 receives JPEG):
     # dfd_analyze_jpegs_host - the scans of chunk k + 1 are uploaded while chunk k is entropy-decoded ON THE DEVICE
     # (csrc/jpeg_gpu_entropy.h), turned into frames and analysed.  Two kinds of quality-85 4:2:0 frames, byte sizes stated:
@@ -720,22 +763,24 @@ def main():
     lanes._next = 0
     barrier()
     # HIP events after every launch, on the library's stream, live in the timed region: on every step they cost 5 % of it
-    # (3.85 vs 3.66 ms per batch-256 step), so every PROFILE_EVERY-th step carries them.  An instrumented step runs ALONE
-    # (the lanes drain before it and it drains before the next step is queued): its events then time isolated kernels,
-    # which is what the roofline object must describe; the drains are inside the timed region and `value` pays for them.
+    # (3.85 vs 3.66 ms per batch-256 step), so every PROFILE_EVERY-th step carries them.  An instrumented step runs ALONE:
+    # ClassifierLanes.submit_alone orders it on the device (dfd_wait_for: it starts when the other lane has finished its
+    # step, the other lane's next step starts when it has finished; no host wait, so the host stays ahead of the GPU and
+    # the gaps between its events are kernel time).  Its events then time isolated kernels, which is what the roofline
+    # object must describe; the time the other lane idles beside it is inside the timed region and `value` pays for it.
     nl = len(lanes)
     every = PROFILE_EVERY if args.steps >= PROFILE_EVERY else max(nl, args.steps // nl * nl)
-    every = (every + nl - 1) // nl * nl                          # instrumented steps fall on lane 0
+    every = (every + nl - 1) // nl * nl                          # instrumented steps fall on lane 0 ...
+    first = every // 2 // nl * nl                                # ... in the middle of each window of `every` steps
     h.set_option("profile_stride", every // nl)
-    h.profile_begin()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        marked = i % every == 0
-        if marked and nl > 1:
-            lanes.sync()
-        lanes.submit(xd.ptr, args.batch, ys[i % nl].ptr)
-        if marked and nl > 1:
-            h.sync()
+        if i == first:
+            h.profile_begin()                                    # host-side only: lane 0's next forward is sample 0
+        if i >= first and (i - first) % every == 0:
+            lanes.submit_alone(xd.ptr, args.batch, ys[i % nl].ptr)
+        else:
+            lanes.submit(xd.ptr, args.batch, ys[i % nl].ptr)
     lanes.sync()
     barrier()
     dt = time.perf_counter() - t0
@@ -808,9 +853,9 @@ def main():
         "config": {"workload": "configs[1]: batch=256 random 224x224 crops, EfficientNet-B0 fp32 inference",
                    "batch_per_gpu": args.batch, "parallelism": f"frame-shard x{world}, no data-path collective",
                    "forwards_in_flight": nl,
-                   "instrumented_steps": f"every {every}th step carries per-launch HIP events and runs alone (the lanes "
-                                         "drain around it, inside the timed region): roofline durations are those of "
-                                         "isolated kernels",
+                   "instrumented_steps": f"every {every}th step (from step {first}) carries per-launch HIP events and runs "
+                                         "alone (the other lane waits for it on the device, inside the timed region): "
+                                         "roofline durations are those of isolated kernels",
                    "arithmetic": "fp32 storage and accumulation; 1x1-conv products are fp32-exact (each operand = exact sum "
                                  "of three bf16 terms, six cross terms on the bf16 MFMA; the dropped terms are < 2^-24 "
                                  "relative); DFD_SPLIT_GEMM=0 runs the same GEMMs on the fp32 MFMA instead"},
@@ -842,7 +887,7 @@ def main():
         out["one_forward_in_flight"] = one_forward_in_flight(h, xd, yd, args.batch, min(args.steps, 20), logits)
         out["bf16"] = bf16_classify(h, xd, yd, args.batch, min(args.steps, 20), logits, b0_arch.depthwise_bytes_per_image(2) * args.batch)
     if not args.no_e2e:
-        out["e2e"] = e2e_frames(h, rank, dist, local_rank)
+        out["e2e"] = e2e_frames(h, rank, dist, local_rank, blob=blob)
     if not args.no_streams:
         # the extra must never cost the main line: if the collective set-up wedges, rank 0 prints what it has
         import threading

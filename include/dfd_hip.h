@@ -117,6 +117,10 @@ int dfd_device_free(dfd_handle* h, void* dptr);
 int dfd_memcpy_h2d(dfd_handle* h, void* dst_dev, const void* src_host, size_t bytes);
 int dfd_memcpy_d2h(dfd_handle* h, void* dst_host, const void* src_dev, size_t bytes);
 int dfd_sync(dfd_handle* h);
+/* Device-side ordering between two handles on the same device, without a host wait: everything queued on `h` after this
+ * call starts only when the work queued on `other` so far has finished (an event recorded on other's stream, waited for by
+ * h's stream).  bench.py orders its two classifier lanes with it around the step that carries per-launch events. */
+int dfd_wait_for(dfd_handle* h, dfd_handle* other);
 /* device address of the handle's frame buffer: the last frame uploaded by a host-frame entry point or decoded by
  * dfd_decode_jpeg (packed BGR); valid until the next such call */
 void* dfd_frame_ptr(dfd_handle* h);

@@ -7,7 +7,7 @@
 #    passes, SQ counters in two passes of 8 - of the classifier-only driver (fp32 and bf16).
 set -u
 TAG=${1:-r02}
-MODE=${2:-all}          # all | e2e (kernel stats of bench / e2e / MTCNN only: what changes when the classifier kernels do not)
+MODE=${2:-all}          # all | bench (kernel stats of bench.py only) | e2e (kernel stats of bench / e2e / MTCNN only: what changes when the classifier kernels do not)
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -23,7 +23,14 @@ MT_DENSE=1 python3 profiles/mtcnn_profile_driver.py > "$OUT/warm_mtcnn_dense.log
 E2E_STEPS=2 python3 profiles/e2e_profile_driver.py > "$OUT/warm_e2e.log" 2>&1 || exit 1
 cd /tmp
 run() { name=$1; shift; rocprofv3 "$@" > "$OUT/$name.log" 2>&1 || { echo "rocprofv3 $name failed"; tail -5 "$OUT/$name.log"; exit 1; }; }
+# bench.py keeps two forwards in flight (its instrumented step runs alone): the trace of the default command averages
+# kernels that overlap another forward's; DFD_BENCH_LANES=1 is the same loop with one forward in flight - the isolated
+# durations bench.py's events (and its roofline object) report.  Both summaries are kept.
+run stats_bench_lanes2 --kernel-trace --stats -d "$OUT/stats_bench_lanes2" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-e2e --no-streams --no-cpu-baseline
+export DFD_BENCH_LANES=1
 run stats_bench --kernel-trace --stats -d "$OUT/stats_bench" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-e2e --no-streams --no-cpu-baseline
+unset DFD_BENCH_LANES
+if [ "$MODE" = "bench" ]; then cd "$ROOT"; find "$OUT" -name "*.csv" | sort; exit 0; fi
 export MT_FRAMES=64
 run stats_mtcnn_selective --kernel-trace --stats -d "$OUT/stats_mtcnn_selective" -o s --output-format csv -- python3 "$ROOT/profiles/mtcnn_profile_driver.py"
 unset MT_FRAMES

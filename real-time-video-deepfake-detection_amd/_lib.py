@@ -44,6 +44,7 @@ SIGNATURES = {
     "dfd_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dfd_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dfd_sync": (C.c_int, [C.c_void_p]),
+    "dfd_wait_for": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dfd_frame_ptr": (C.c_void_p, [C.c_void_p]),
     "dfd_timer_begin": (C.c_int, [C.c_void_p]),
     "dfd_timer_end": (C.c_int, [C.c_void_p, c_float_p]),
@@ -264,6 +265,10 @@ class Handle:
 
     def sync(self):
         self._check(self._lib.dfd_sync(self._p))
+
+    def wait_for(self, other: "Handle"):
+        """work queued on this handle from now on starts after what `other` has queued so far (no host wait)"""
+        self._check(self._lib.dfd_wait_for(self._p, other._p))
 
     def timer_begin(self):
         self._check(self._lib.dfd_timer_begin(self._p))
@@ -780,6 +785,22 @@ class ClassifierLanes:
         """queue one forward on the next lane (asynchronous); -> the lane index it went to"""
         k = self._next
         self.handles[k].classify_device(x_dev, n, logits_dev)
+        self._next = (k + 1) % len(self.handles)
+        return k
+
+    def submit_alone(self, x_dev: int, n: int, logits_dev: int) -> int:
+        """queue one forward that runs with NO other lane's kernels beside it, ordered on the device (dfd_wait_for: no
+        host wait, the host stays ahead of the GPU): it starts when the other lanes have finished what they hold, and they
+        continue when it has finished.  bench.py's instrumented step - per-launch events then time isolated kernels."""
+        k = self._next
+        me = self.handles[k]
+        for o in self.handles:
+            if o is not me:
+                me.wait_for(o)
+        me.classify_device(x_dev, n, logits_dev)
+        for o in self.handles:
+            if o is not me:
+                o.wait_for(me)
         self._next = (k + 1) % len(self.handles)
         return k
 

@@ -130,6 +130,7 @@ void destroy_impl(dfd_handle* h) {
     for (char* p : h->mailbox_old) hipHostFree(p);
     for (char* p : h->mailbox_old_prev) hipHostFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->order_ev) hipEventDestroy(h->order_ev);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -280,6 +281,19 @@ int dfd_memcpy_d2h(dfd_handle* h, void* dst, const void* src, size_t bytes) {
 int dfd_sync(dfd_handle* h) {
     if (!h) return DFD_ERR_ARG;
     DFD_HIP_TRY(h, stream_sync(h));
+    return DFD_OK;
+}
+
+int dfd_wait_for(dfd_handle* h, dfd_handle* other) {
+    if (!h || !other) return DFD_ERR_ARG;
+    if (h == other) return DFD_OK;                               // a stream is ordered with itself
+    if (h->device != other->device) return fail(h, DFD_ERR_ARG, "wait_for: handles on devices %d and %d", h->device, other->device);
+    DFD_HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->order_ev) DFD_HIP_TRY(h, hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming));
+    // the event is re-recorded per call: a stream wait captures the record that precedes it (HIP semantics), so an
+    // earlier wait on the same event object keeps its own point
+    DFD_HIP_TRY(h, hipEventRecord(h->order_ev, other->stream));
+    DFD_HIP_TRY(h, hipStreamWaitEvent(h->stream, h->order_ev, 0));
     return DFD_OK;
 }
 

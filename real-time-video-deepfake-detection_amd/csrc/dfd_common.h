@@ -82,6 +82,7 @@ struct dfd_handle {
     int max_batch = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t order_ev = nullptr;       // dfd_wait_for: recorded on another handle's stream, waited for by this one
     // dfd_analyze_frames_host: copy stream + two staging slots (uploads overlap the previous batch's compute)
     // pinned mailbox for the small host<->device transfers of the batch path (mailbox_* below)
     char* mailbox = nullptr;

@@ -173,7 +173,9 @@ def test_two_forwards_in_flight_return_the_single_forward_bits(pkg, big, crops, 
         xd = [big.alloc(a.nbytes).upload(a) for a in xs]
         yd = [big.alloc(256 * 4) for _ in range(6)]
         bufs = xd + yd
-        went = [lanes.submit(xd[i % 3].ptr, 256, yd[i].ptr) for i in range(6)]       # six forwards, no wait in between
+        # six forwards, no host wait in between; the third one ordered alone on the device (dfd_wait_for both ways: what
+        # bench.py does with the step that carries its per-launch events)
+        went = [(lanes.submit_alone if i == 2 else lanes.submit)(xd[i % 3].ptr, 256, yd[i].ptr) for i in range(6)]
         lanes.sync()
         assert went == [0, 1, 0, 1, 0, 1]
         for i in range(6):
@@ -182,3 +184,36 @@ def test_two_forwards_in_flight_return_the_single_forward_bits(pkg, big, crops, 
         for b in bufs:
             b.free()
         lanes.close()
+
+
+def test_wait_for_orders_two_handles_on_the_device(pkg, big, crops, seeded_sd, ssd_sd):
+    """dfd_wait_for: handle B's work starts after what handle A has queued.  A writes logits into a buffer, B is told to
+    wait for A and then classifies INTO THE SAME buffer from other crops: the buffer ends with B's result every time; the
+    reverse order ends with A's.  (Without the ordering the two forwards run side by side and either could finish last.)"""
+    x = crops.numpy()
+    xa, xb = x, x * np.float32(0.25)
+    wa, wb = big.classify(xa), big.classify(xb)
+    assert not np.array_equal(wa, wb)
+    other = pkg._lib.Handle(pkg.weights.pack_all(seeded_sd, ssd_sd), device=0, max_batch=256)
+    bufs = []
+    try:
+        other.tiles_import(big.tiles_export())
+        other.warmup(256, 0)
+        da, db, y = big.alloc(xa.nbytes).upload(xa), big.alloc(xb.nbytes).upload(xb), big.alloc(256 * 4)
+        bufs = [da, db, y]
+        for _ in range(3):
+            big.classify_device(da.ptr, 256, y.ptr)
+            other.wait_for(big)
+            other.classify_device(db.ptr, 256, y.ptr)
+            other.sync()
+            assert np.array_equal(y.download((256, 1)), wb)
+            big.wait_for(other)
+            big.classify_device(da.ptr, 256, y.ptr)
+            big.sync()
+            assert np.array_equal(y.download((256, 1)), wa)
+        big.wait_for(big)                                         # a handle and itself: no-op
+    finally:
+        big.sync(); other.sync()
+        for b in bufs:
+            b.free()
+        other.close()
