@@ -183,46 +183,21 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, w
     # the same call with TWO of them in flight: a second handle (its own streams and workspaces, the same tile table) driven
     # by a second host thread (the library calls release the GIL) - a server with two workers on one GPU.  One call is a
     # chain of ~150 dependent launches and three stream waits; the other call's kernels fill its gaps and under-filled tails.
-    if world == 1 and blob is not None:
-        import threading
+    h2 = None
 
+    def second_handle():
+        # its main stream at HIGH priority: streams of one priority share a small pool of hardware queues, and in this
+        # process (seven streams made before this one) a second normal-priority main stream ended up in line with h's -
+        # 12.6 k frames/s with two calls in flight instead of 14.4 k (profiles/e2e_lanes_probe.py, PROBE_PRELUDE=ABCD).
+        # Created for these rows only and closed after them: the single-call rows run in a process without it.
         import rtdfd_amd
 
-        h2 = rtdfd_amd._lib.Handle(blob, device=local_rank, max_batch=h.max_batch)
-        try:
-            h2.tiles_import(h.tiles_export())
-            h2.warmup(h.max_batch, frames_per_step)
+        hh = rtdfd_amd._lib.Handle(blob, device=local_rank, max_batch=h.max_batch)
+        hh.set_option("stream_priority", 1)
+        hh.tiles_import(h.tiles_export())
+        hh.warmup(h.max_batch, frames_per_step)
+        return hh
 
-            def calls(hh, forensic, k, keep):
-                r = None
-                for _ in range(k):
-                    r = hh.analyze_batch_device(fd.ptr, frames_per_step, H, W, forced_boxes=boxes, max_faces=K, with_forensics=forensic)
-                keep.append(r)
-
-            for key, forensic in (("detect_classify_two_calls_in_flight", False), ("detect_classify_forensics_two_calls_in_flight", True)):
-                want = []
-                calls(h, forensic, 1, want)
-                calls(h2, forensic, warmup, [])
-                dts, same = [], True
-                for _ in range(3):
-                    got = [[], []]
-                    th = [threading.Thread(target=calls, args=(hh, forensic, steps, got[i])) for i, hh in enumerate((h, h2))]
-                    h.sync(); h2.sync()
-                    t0 = time.perf_counter()
-                    for t in th:
-                        t.start()
-                    for t in th:
-                        t.join()
-                    dts.append(time.perf_counter() - t0)
-                    for g in got:
-                        same = same and g[0][0] == want[0][0] and np.array_equal(
-                            np.asarray(g[0][1], np.float32), np.asarray(want[0][1], np.float32), equal_nan=True)
-                dts.sort()
-                res[key] = {"frames_per_s": round(frames_per_step * steps * 2 / dts[1], 1), "calls_in_flight": 2,
-                            "repeats_frames_per_s": [round(frames_per_step * steps * 2 / d, 1) for d in dts],
-                            "boxes_and_logits_equal_the_single_call": bool(same)}
-        finally:
-            h2.close()
     # JPEG BYTES across PCIe instead of raw frames (reference backend_server.py:139-145 receives JPEG):
     # dfd_analyze_jpegs_host - the scans of chunk k + 1 are uploaded while chunk k is entropy-decoded ON THE DEVICE
     # (csrc/jpeg_gpu_entropy.h), turned into frames and analysed.  Two kinds of quality-85 4:2:0 frames, byte sizes stated:
@@ -251,6 +226,7 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, w
 
         reps = 8
         rows = {}
+        deferred_jpeg = []
         for kind, src in (("natural_texture", [natural_texture(40 + i) for i in range(8)]), ("random_texture", [frames[i] for i in range(8)])):
             files = [encode(f) for f in src]
             datas = [files[i % len(files)] for i in range(reps * frames_per_step)]
@@ -273,6 +249,7 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, w
                           "frames_per_chunk": best[0], "jpeg_bytes_per_frame": int(np.mean([len(f) for f in files])),
                           "MB_per_s_over_pcie": round(sum(len(d) for d in datas) / best[1] / 1e6, 1)}
             h.host_free(packed[0])
+            deferred_jpeg.append((kind, datas, hb, best[0]))
         rows["frames_entropy_decoded_on_device_vs_host_decoder"] = list(h.jpeg_decode_counts())
         rows["note"] = (f"{reps * frames_per_step} x 1080p quality-85 4:2:0 JPEG files from pinned host memory per call, SSD detect + {K} "
                         "forced boxes -> CLAHE -> 224 -> B0 fp32 as the rows above; decoded frames equal Pillow's bit for bit "
@@ -374,9 +351,73 @@ def e2e_frames(h, rank, dist, local_rank, frames_per_step=E2E_FRAMES, steps=6, w
         "configs[3]: classifier activations stored as bf16 (fp32 accumulate, fp32-exact weights); detector, CLAHE and "
         "forensic kernels unchanged (integer / fp32: box indices must stay bit-exact); vote-equality gate: "
         "tests/test_b0_bf16_gpu.py::test_config4_gate_votes_equal_fp32_oracle_on_200_frames")
-    fd.free()
     if rank == 0 and world == 1:
         res["detect_classify_mtcnn"] = e2e_mtcnn(frames, boxes, K)
+    # ---- the rows with TWO calls in flight, after every single-call row (their extra handle, its streams and their
+    # hardware queues must not be part of the process the single-call rows are measured in)
+    if world == 1 and blob is not None:
+        import threading
+
+        h2 = second_handle()
+        if True:
+            def calls(hh, forensic, k, keep):
+                r = None
+                for _ in range(k):
+                    r = hh.analyze_batch_device(fd.ptr, frames_per_step, H, W, forced_boxes=boxes, max_faces=K, with_forensics=forensic)
+                keep.append(r)
+
+            for key, forensic in (("detect_classify_two_calls_in_flight", False), ("detect_classify_forensics_two_calls_in_flight", True)):
+                want = []
+                calls(h, forensic, 1, want)
+                calls(h2, forensic, warmup, [])
+                dts, same = [], True
+                for _ in range(3):
+                    got = [[], []]
+                    th = [threading.Thread(target=calls, args=(hh, forensic, steps, got[i])) for i, hh in enumerate((h, h2))]
+                    h.sync(); h2.sync()
+                    t0 = time.perf_counter()
+                    for t in th:
+                        t.start()
+                    for t in th:
+                        t.join()
+                    dts.append(time.perf_counter() - t0)
+                    for g in got:
+                        same = same and g[0][0] == want[0][0] and np.array_equal(
+                            np.asarray(g[0][1], np.float32), np.asarray(want[0][1], np.float32), equal_nan=True)
+                dts.sort()
+                res[key] = {"frames_per_s": round(frames_per_step * steps * 2 / dts[1], 1), "calls_in_flight": 2,
+                            "repeats_frames_per_s": [round(frames_per_step * steps * 2 / d, 1) for d in dts],
+                            "boxes_and_logits_equal_the_single_call": bool(same)}
+        for kind, datas, hb, chunk in (deferred_jpeg if "detect_classify_jpeg_h2d" in res else []):
+            # the same files as TWO calls in flight (two handles, two host threads, half of the files each): one call's
+            # decode passes are latency-bound chains; the other call's kernels run beside them
+            half = len(datas) // 2
+            parts = [(hh, datas[k * half:(k + 1) * half], hb[k * half:(k + 1) * half]) for k, hh in enumerate((h, h2))]
+            packs = [hh.pack_jpegs(d) for hh, d, _ in parts]
+
+            def jcall(k, keep):
+                hh, d, b = parts[k]
+                keep.append(hh.analyze_jpegs_host(d, chunk, forced_boxes=b, max_faces=K, packed=packs[k]))
+
+            def both():
+                keep = [[], []]
+                th = [threading.Thread(target=jcall, args=(k, keep[k])) for k in range(2)]
+                t0 = time.perf_counter()
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                return time.perf_counter() - t0, keep
+
+            for _ in range(3):
+                both()
+            dts = sorted(both()[0] for _ in range(5))
+            res["detect_classify_jpeg_h2d"][kind]["two_calls_in_flight_frames_per_s"] = round(2 * half / dts[2], 1)
+            for k, (hh, _, _) in enumerate(parts):
+                hh.host_free(packs[k][0])
+        h2.close()
+        h2 = None
+    fd.free()
     return res
 
 
@@ -796,6 +837,12 @@ def main():
     logits = yd.download((args.batch, 1))
     if not np.all(np.isfinite(logits)):
         sys.exit("non-finite logits in the timed run")
+    # the second lane is closed here: the rows below (other options, the 1080p extras with their copy / second compute
+    # streams) run in a process that holds the first handle's streams only, as in the earlier rounds
+    for b in ys[1:]:
+        b.free()
+    ys = ys[:1]
+    lanes.close()
     # SURVEY 8(d) Config 2: parity on the first 8 rows of the timed run's own output, against the CPU oracle
     parity = None
     if rank == 0:
@@ -921,9 +968,6 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, with_e2e=not args.no_e2e)
         print(json.dumps(out), file=json_out, flush=True)
-    for b in ys[1:]:
-        b.free()
-    lanes.close()
     xd.free()
     yd.free()
     h.close()

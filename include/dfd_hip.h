@@ -78,7 +78,11 @@ int dfd_max_batch(const dfd_handle* h);
  *   "overlap_forensics" (default 1): dfd_analyze_batch_device / dfd_analyze_frames_host run the six forensic signals of
  *   a batch on the handle's second stream beside the detector and the classifier and collect them at the end of the call;
  *   0 = in front of the detector on the main stream.  Same results.
- *   "profile_stride" (default 1): between dfd_b0_profile_begin/end only every k-th forward records events. */
+ *   "profile_stride" (default 1): between dfd_b0_profile_begin/end only every k-th forward records events.
+ *   "stream_priority" (1 high, 0 normal - the default -, -1 low): re-creates the handle's main stream at that priority
+ *   (the handle is drained first).  For a process that keeps two handles busy on one device (two batches in flight): the
+ *   runtime maps streams of ONE priority onto a small pool of hardware queues and two main streams that land on the same
+ *   queue run in line; streams of different priorities come from different pools. */
 int dfd_set_option(dfd_handle* h, const char* name, int value);
 /*   "fuse_se" (default 0): the squeeze-excite gate is computed by the last-arriving block of each image inside the
  *   depthwise launch (measured slower than the separate launch: DESIGN.md section 5; kept for the measurement).

@@ -8,6 +8,9 @@ import time
 
 import numpy as np
 
+if int(os.environ.get("PROBE_TORCH", "0")):       # as bench.py: torch first, so that the process runs on the HIP runtime
+    import torch  # noqa: F401                     # bundled with the wheel (7.0) instead of /opt/rocm's (7.2)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import rtdfd_amd  # noqa: E402
@@ -15,7 +18,14 @@ import rtdfd_amd  # noqa: E402
 N, H, W, K = 64, 1080, 1920, 4
 forensic = bool(int(sys.argv[1])) if len(sys.argv) > 1 else True
 blob = rtdfd_amd.weights.pack_all(rtdfd_amd.weights.seeded_state_dict(0), rtdfd_amd.weights.seeded_ssd_state_dict(0))
-hs = [rtdfd_amd._lib.Handle(blob, device=0, max_batch=256) for _ in range(2)]
+extra = []
+if int(os.environ.get("PROBE_EXTRA", "0")):      # handles created (and used) BEFORE the two under test, as in bench.py: do the
+    for _ in range(int(os.environ["PROBE_EXTRA"])):  # later streams still get hardware queues of their own?
+        e = rtdfd_amd._lib.Handle(blob, device=0, max_batch=256)
+        e.warmup(256, N)
+        extra.append(e)
+hs = ([extra[0]] if int(os.environ.get("PROBE_REUSE", "0")) else []) + [rtdfd_amd._lib.Handle(blob, device=0, max_batch=256) for _ in range(2)]
+hs = hs[:2]
 hs[0].warmup(256, N)
 hs[1].tiles_import(hs[0].tiles_export())
 hs[1].warmup(256, N)
@@ -31,6 +41,35 @@ def loop(h, k, out=None):
         out.append(r)
 
 
+# what bench.py has done on its first handle before it reaches the two-call rows (PROBE_PRELUDE = letters):
+#   A a second classifier handle (ClassifierLanes) and a few batch-256 forwards on both   B forensic calls on handle 0
+#   C the bf16 rows (option on, warm-up, calls, option off)   D handle 1 is created only now (as bench.py's h2)
+pre = os.environ.get("PROBE_PRELUDE", "")
+if "D" in pre:
+    hs[1].close()
+if "A" in pre:
+    lanes = rtdfd_amd._lib.ClassifierLanes(blob, device=0, max_batch=256, lanes=2, first=hs[0])
+    lanes.warmup(256)
+    x = np.random.default_rng(1).standard_normal((256, 3, 224, 224)).astype(np.float32)
+    xd, y0, y1 = hs[0].alloc(x.nbytes).upload(x), hs[0].alloc(1024), hs[0].alloc(1024)
+    for i in range(10):
+        lanes.submit(xd.ptr, 256, (y0 if i % 2 == 0 else y1).ptr)
+    lanes.sync()
+if "B" in pre:
+    for _ in range(3):
+        hs[0].analyze_batch_device(fd.ptr, N, H, W, forced_boxes=boxes, max_faces=K, with_forensics=True)
+if "C" in pre:
+    hs[0].set_option("bf16_activations", 1)
+    hs[0].warmup(256, 0)
+    for _ in range(3):
+        hs[0].analyze_batch_device(fd.ptr, N, H, W, forced_boxes=boxes, max_faces=K, with_forensics=True)
+    hs[0].set_option("bf16_activations", 0)
+if "D" in pre:
+    hs[1] = rtdfd_amd._lib.Handle(blob, device=0, max_batch=256)
+    hs[1].tiles_import(hs[0].tiles_export())
+    hs[1].warmup(256, N)
+if int(os.environ.get("PROBE_PRIO", "0")):          # handle 1's main stream from the high-priority queue pool
+    hs[1].set_option("stream_priority", 1)
 for h in hs:
     loop(h, 3)
 ref = []

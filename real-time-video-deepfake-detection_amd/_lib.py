@@ -764,6 +764,8 @@ class ClassifierLanes:
             self.handles.append(Handle(blob, device=device, max_batch=max_batch))
         self._owned = self.handles[1:] if first is not None else list(self.handles)
         self._next = 0
+        # (if the lanes do not overlap in a process that has made many streams - two main streams mapped onto one hardware
+        # queue run in line - give one lane another priority: handles[1].set_option("stream_priority", 1))
 
     def __len__(self):
         return len(self.handles)

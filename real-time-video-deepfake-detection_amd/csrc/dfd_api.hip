@@ -191,6 +191,22 @@ int dfd_set_option(dfd_handle* h, const char* name, int value) {
         h->jpeg_chunk_bytes = value;
         return DFD_OK;
     }
+    if (strcmp(name, "stream_priority") == 0) {
+        // the handle's main stream re-created at another priority (1 high, 0 normal, -1 low).  The runtime draws the
+        // hardware queue of a stream from a pool per priority: two handles whose main streams have different priorities
+        // can never be mapped onto one hardware queue (where their launches would run in line)
+        if (value < -1 || value > 1) return fail(h, DFD_ERR_ARG, "stream_priority must be -1, 0 or 1");
+        DFD_HIP_TRY(h, hipSetDevice(h->device));
+        DFD_HIP_TRY(h, stream_sync(h));
+        int least = 0, greatest = 0;
+        DFD_HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int prio = value > 0 ? greatest : (value < 0 ? least : (least + greatest) / 2);
+        hipStream_t fresh = nullptr;
+        DFD_HIP_TRY(h, hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, prio));
+        hipStreamDestroy(h->stream);
+        h->stream = fresh;
+        return DFD_OK;
+    }
     if (strcmp(name, "profile_stride") == 0) { h->prof_stride = value > 0 ? value : 1; return DFD_OK; }
     return fail(h, DFD_ERR_ARG, "unknown option '%s'", name);
 }
