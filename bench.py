@@ -545,6 +545,34 @@ def bf16_classify(h, xd, yd, batch, steps, logits_fp32, dw_bytes_bf16):
     return out
 
 
+def bf16_two_lanes(lanes, xd, ys, batch, steps):
+    """configs[3]'s classifier half with TWO forwards in flight (the headline loop with bf16 activation storage), before
+    the second lane is closed: {weights variant: crops/s}.  The per-launch numbers of the bf16 rows come from the
+    one-forward loop of `bf16_classify`."""
+    out = {}
+    try:
+        for key, planes in (("weights_fp32_exact", 3), ("weights_bf16", 1)):
+            lanes.set_option("bf16_activations", 1)
+            lanes.set_option("bf16_weight_planes", planes)
+            lanes.warmup(batch)
+            lanes._next = 0
+            for i in range(4):
+                lanes.submit(xd.ptr, batch, ys[i % len(lanes)].ptr)
+            lanes.sync()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                lanes.submit(xd.ptr, batch, ys[i % len(lanes)].ptr)
+            lanes.sync()
+            dt = time.perf_counter() - t0
+            same = all(np.array_equal(ys[k].download((batch, 1)), ys[0].download((batch, 1))) for k in range(1, len(lanes)))
+            out[key] = {"crops_per_s": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+                        "forwards_in_flight": len(lanes), "lanes_agree_bitwise": bool(same)}
+    finally:
+        lanes.set_option("bf16_activations", 0)
+        lanes.set_option("bf16_weight_planes", 3)
+    return out
+
+
 def separate_late_launches(h, xd, yd, batch, steps, logits_fp32):
     """The same fp32 step with option "fuse_late" OFF (round 3's headline configuration): blocks 6-15 as expand GEMM +
     depthwise kernel, the expanded tensor through memory.  Slower per step; its 16 depthwise launches hold no expand work
@@ -837,6 +865,10 @@ def main():
     logits = yd.download((args.batch, 1))
     if not np.all(np.isfinite(logits)):
         sys.exit("non-finite logits in the timed run")
+    bf16_lanes = None
+    if rank == 0 and world == 1 and nl > 1:
+        bf16_lanes = bf16_two_lanes(lanes, xd, ys, args.batch, min(args.steps, 20) // nl * nl)
+        h.warmup(args.batch, 0)                                  # (fp32 again: nothing to measure, the table has the entries)
     # the second lane is closed here: the rows below (other options, the 1080p extras with their copy / second compute
     # streams) run in a process that holds the first handle's streams only, as in the earlier rounds
     for b in ys[1:]:
@@ -933,6 +965,8 @@ def main():
         out["fuse_late_off"] = separate_late_launches(h, xd, yd, args.batch, min(args.steps, 20), logits)
         out["one_forward_in_flight"] = one_forward_in_flight(h, xd, yd, args.batch, min(args.steps, 20), logits)
         out["bf16"] = bf16_classify(h, xd, yd, args.batch, min(args.steps, 20), logits, b0_arch.depthwise_bytes_per_image(2) * args.batch)
+        if bf16_lanes:
+            out["bf16"]["two_forwards_in_flight"] = bf16_lanes
     if not args.no_e2e:
         out["e2e"] = e2e_frames(h, rank, dist, local_rank, blob=blob)
     if not args.no_streams:
