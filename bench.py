@@ -431,6 +431,7 @@ def e2e_mtcnn(frames, boxes, K):
     H, Wd = frames.shape[1:3]
     out = {}
     handles = {}
+    blobs = {}
     # (key, option "mtcnn", head-bias recipe, frames per call): the 8-frame rows are per-call latency figures (every stage
     # of a call runs at a small batch), the 64-frame rows the batched throughput of the same path
     # "..._forensics": every stage of the reference's per-frame flow on (detect, CLAHE, MTCNN, classify, six signals)
@@ -440,8 +441,8 @@ def e2e_mtcnn(frames, boxes, K):
                                ("mtcnn_off_64", 0, W.MTCNN_SELECTIVE, len(frames))):
         tag = "sel" if bias else "dense"
         if tag not in handles:
-            hh = pkg._lib.Handle(W.pack_all(W.seeded_state_dict(0), W.seeded_ssd_state_dict(0),
-                                            W.seeded_mtcnn_state_dict(0, bias)), device=0, max_batch=len(frames) * K)
+            blobs[tag] = W.pack_all(W.seeded_state_dict(0), W.seeded_ssd_state_dict(0), W.seeded_mtcnn_state_dict(0, bias))
+            hh = pkg._lib.Handle(blobs[tag], device=0, max_batch=len(frames) * K)
             hh.warmup(len(frames) * K, len(frames))             # classifier / detector GEMM tiles, as for the main handle
             hh.warmup(8 * K, 8)
             handles[tag] = (hh, hh.alloc(frames.nbytes).upload(frames))
@@ -464,6 +465,47 @@ def e2e_mtcnn(frames, boxes, K):
         out[key] = {"frames_per_s": round(n / dt, 1), "ms_per_crop": round(dt / (n * K) * 1e3, 3),
                     "ms_per_call_min_median_max": [round(min(calls) * 1e3, 2), round(dt * 1e3, 2), round(max(calls) * 1e3, 2)],
                     "crops_with_a_face": int((~np.isnan(flat)).sum()), "crops": int(flat.size), "frames_per_call": n}
+    # every stage of the reference flow on, TWO calls in flight (second handle on a high-priority main stream, second host
+    # thread), after the single-call rows of this section
+    import threading
+
+    h, fd = handles["sel"]
+    h.set_option("mtcnn", 1)
+    h2 = pkg._lib.Handle(blobs["sel"], device=0, max_batch=len(frames) * K)
+    try:
+        h2.set_option("stream_priority", 1)
+        h2.tiles_import(h.tiles_export())
+        h2.warmup(len(frames) * K, len(frames))
+        n = len(frames)
+
+        def worker(hh, k, keep):
+            r = None
+            for _ in range(k):
+                r = hh.analyze_batch_device(fd.ptr, n, H, Wd, forced_boxes=boxes[:n], max_faces=K, with_forensics=True)
+            keep.append(r)
+
+        want = []
+        worker(h, 1, want)
+        worker(h2, 2, [])
+        dts, same = [], True
+        for _ in range(3):
+            got = [[], []]
+            th = [threading.Thread(target=worker, args=(hh, 5, got[i])) for i, hh in enumerate((h, h2))]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            dts.append(time.perf_counter() - t0)
+            for g in got:
+                same = same and g[0][0] == want[0][0] and all(
+                    np.array_equal(np.asarray(a, np.float32), np.asarray(b, np.float32), equal_nan=True) for a, b in zip(g[0][1], want[0][1]))
+        dts.sort()
+        out["mtcnn_on_selective_64_forensics_two_calls_in_flight"] = {
+            "frames_per_s": round(n * 10 / dts[1], 1), "calls_in_flight": 2, "frames_per_call": n,
+            "repeats_frames_per_s": [round(n * 10 / d, 1) for d in dts], "boxes_and_logits_equal_the_single_call": bool(same)}
+    finally:
+        h2.close()
     n = 8
     out["workload"] = (f"1080p frames, {K} forced boxes each, frames_per_call as listed; seeded random-init cascade: 'mtcnn_on' = "
                        "stress cascade (~20 % of the P-Net cells and ~99 % of the R-Net candidates pass: hundreds of windows per "

@@ -199,6 +199,12 @@ def test_wait_for_orders_two_handles_on_the_device(pkg, big, crops, seeded_sd, s
     try:
         other.tiles_import(big.tiles_export())
         other.warmup(256, 0)
+        # the main stream re-created in the high-priority queue pool (what a second worker's handle is given so that it
+        # cannot share a hardware queue with the first): results and ordering unchanged; other values are rejected
+        other.set_option("stream_priority", 1)
+        with pytest.raises(pkg._lib.DfdError):
+            other.set_option("stream_priority", 2)
+        assert np.array_equal(other.classify(xb), wb)
         da, db, y = big.alloc(xa.nbytes).upload(xa), big.alloc(xb.nbytes).upload(xb), big.alloc(256 * 4)
         bufs = [da, db, y]
         for _ in range(3):
