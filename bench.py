@@ -866,6 +866,11 @@ def main():
     # kernels fill the launch gaps and under-filled late layers of the first.  DFD_BENCH_LANES=1 is
     # round 3's single-forward loop.
     lanes = rtdfd_amd._lib.ClassifierLanes(blob, device=local_rank, max_batch=args.batch, lanes=LANES, first=h)
+    # (both lanes at normal priority: a high-priority stream made this early changes how the handle's low-priority second
+    # stream is scheduled for the rest of the process - the forensic / JPEG rows lost their overlap, 11.9 -> 11.1 k and
+    # 10.3 -> 8.8 k frames/s, even with the lane closed before them; DFD_BENCH_LANE_PRIORITY=1 tries it)
+    if len(lanes) > 1 and os.environ.get("DFD_BENCH_LANE_PRIORITY", "0") == "1":
+        lanes.handles[1].set_option("stream_priority", 1)
     lanes.warmup(args.batch)
     ys = [yd] + [h.alloc(args.batch * 4) for _ in range(len(lanes) - 1)]
     for i in range(max(args.warmup, 1)):
