@@ -672,7 +672,7 @@ def stream_frame(base, t):
 
 
 def config5_streams(h, rank, world, dist, local_rank, waves=32, n_streams=8, verify_frames=None, lookahead=8,
-                    size=(1080, 1920)):
+                    size=(1080, 1920), extra_handles=()):
     """BASELINE.json configs[4] / SURVEY 8(d) Config 5: 8 seeded 1080p streams (seeds 100-107), frame t of every
     stream on rank t % G (weak scaling: 8 frames per GPU per wave), per wave ONE all-gather of 80-byte records
     (dfd_vote_allgather = ncclAllGather over RCCL through the C ABI; torch.distributed as a fallback) inside the
@@ -722,8 +722,13 @@ def config5_streams(h, rank, world, dist, local_rank, waves=32, n_streams=8, ver
     if not ok:
         transport = "torch" if world > 1 else "local"
         note = note or "dfd_comm_init failed on another rank"
-    sh = S.ShardedStreams(h, n_streams, rank, world, transport=transport)
+    # `extra_handles`: further handles on this rank's device - the look-ahead groups are computed two at a time (one per
+    # handle, on host threads: ShardedStreams.local_records_groups), the exchange and the replay stay in wave order
+    sh = S.ShardedStreams(h, n_streams, rank, world, transport=transport, extra_handles=extra_handles)
     h.warmup(min(n_streams * lookahead, h.max_batch), n_streams * lookahead)     # GEMM tiles of this batch shape (untimed)
+    for e in extra_handles:
+        e.tiles_import(h.tiles_export())
+        e.warmup(min(n_streams * lookahead, e.max_batch), n_streams * lookahead)
 
     def batch(t):
         cur = [stream_frame(bases[s], t) for s in range(n_streams)]
@@ -744,17 +749,22 @@ def config5_streams(h, rank, world, dist, local_rank, waves=32, n_streams=8, ver
         arr = np.stack(cur + prev)
         staged.append((h.alloc(arr.nbytes).upload(arr), items))
     # untimed warm-up on a throw-away driver (workspace growth, first-use costs), incl. one collective
-    warm = S.ShardedStreams(h, n_streams, rank, world, transport=transport)
-    warm.finish_waves(warm.local_records_waves(staged[0][0].ptr, Hh, Ww, staged[0][1]))
+    warm = S.ShardedStreams(h, n_streams, rank, world, transport=transport, extra_handles=extra_handles)
+    par = len(warm.workers)
+    for blocks in warm.local_records_groups([(fd.ptr, Hh, Ww, items) for fd, items in staged[:par]]):
+        warm.finish_waves(blocks)
     fence()
     seq = {s: [] for s in range(n_streams)}
     t0 = time.perf_counter()
-    for fd, items in staged:
-        blocks = sh.local_records_waves(fd.ptr, Hh, Ww, items)                 # one device pass for `lookahead` waves
-        for out in sh.finish_waves(blocks):                                      # one collective per wave, in wave order
-            for s, rows in out.items():
-                seq[s] += [(r['frame'], r['confidence_level'], r['fake_probability']) for r in rows]
+    for g0 in range(0, len(staged), par):
+        # one device pass per look-ahead group, `par` groups side by side (one per handle)
+        for blocks in sh.local_records_groups([(fd.ptr, Hh, Ww, items) for fd, items in staged[g0:g0 + par]]):
+            for out in sh.finish_waves(blocks):                                  # one collective per wave, in wave order
+                for s, rows in out.items():
+                    seq[s] += [(r['frame'], r['confidence_level'], r['fake_probability']) for r in rows]
     fence()
+    for e in extra_handles:
+        e.sync()
     dt = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=_red_dev(local_rank) if on_gpu else "cpu")
@@ -770,6 +780,7 @@ def config5_streams(h, rank, world, dist, local_rank, waves=32, n_streams=8, ver
                        "(one upload / download / stream wait per group), the exchange itself stays one all-gather per wave",
            "frames_per_s": round(frames / dt, 1), "ms_per_wave": round(dt / waves * 1e3, 3), "waves": waves,
            "frames_per_wave_per_gpu": n_streams, "lookahead_waves": lookahead, "transport": transport,
+           "groups_in_flight_per_gpu": par,
            "collective": "dfd_vote_allgather_waves (one ncclAllGather per wave, RCCL)" if transport == "rccl" else transport,
            "record_bytes": S.RECORD_FLOATS * 8, "bytes_gathered_per_wave": S.RECORD_FLOATS * 8 * n_streams * world}
     if note:
@@ -1029,13 +1040,22 @@ def main():
         guard = threading.Timer(240.0, bail)
         guard.daemon = True
         guard.start()
+        extra = []
         try:
-            out["config5"] = config5_streams(h, rank, world, dist, local_rank)
+            if os.environ.get("DFD_BENCH_STREAM_HANDLES", "2") != "1":
+                # a second handle per rank for the look-ahead groups (its main stream from the high-priority pool, made
+                # after every single-call row: DESIGN section 5)
+                e2 = rtdfd_amd._lib.Handle(blob, device=local_rank, max_batch=args.batch)
+                e2.set_option("stream_priority", 1)
+                extra.append(e2)
+            out["config5"] = config5_streams(h, rank, world, dist, local_rank, extra_handles=extra)
         except SystemExit:
             raise
         except Exception as e:                                   # noqa: BLE001
             out["config5"] = {"error": f"{type(e).__name__}: {e}"}
         guard.cancel()
+        for e2 in extra:
+            e2.close()
     if rank == 0:
         if args.layers:
             agg = {}

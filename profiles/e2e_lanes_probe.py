@@ -68,8 +68,8 @@ if "D" in pre:
     hs[1] = rtdfd_amd._lib.Handle(blob, device=0, max_batch=256)
     hs[1].tiles_import(hs[0].tiles_export())
     hs[1].warmup(256, N)
-if int(os.environ.get("PROBE_PRIO", "0")):          # handle 1's main stream from the high-priority queue pool
-    hs[1].set_option("stream_priority", 1)
+if int(os.environ.get("PROBE_PRIO", "0")):          # handle 1 main stream from another priority pool (1 high, -1 low)
+    hs[1].set_option("stream_priority", int(os.environ["PROBE_PRIO"]))
 for h in hs:
     loop(h, 3)
 ref = []

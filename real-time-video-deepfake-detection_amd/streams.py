@@ -154,8 +154,11 @@ class ShardedStreams:
     """Per-rank driver.  A wave = one frame of every stream on every rank (frame index wave * G + rank)."""
 
     def __init__(self, handle, n_streams: int, rank: int = 0, world: int = 1, transport: Optional[str] = None,
-                 detection_threshold: float = 0.55, group=None, calibrator=None):
+                 detection_threshold: float = 0.55, group=None, calibrator=None, extra_handles: Sequence = ()):
         self.h, self.n_streams, self.rank, self.world, self.group = handle, n_streams, rank, world, group
+        # further handles on the same device (each with its own streams and workspaces): `local_records_groups` runs
+        # look-ahead groups on them side by side.  The exchange always goes through `handle` (it owns the communicator).
+        self.workers = [handle, *extra_handles]
         self.transport = transport or ("local" if world == 1 else "torch")
         self.replicas = [StreamReplica(detection_threshold) for _ in range(n_streams)]
         # `DeepfakeDetector.calibrator` of the single-GPU flow (reference deepfake_detection.py:336-342,445-455): a
@@ -182,7 +185,38 @@ class ShardedStreams:
         pass over the current frames (faces[0] per frame, as the server does) and one forensic pass."""
         return self.local_records_waves(frames_dev, height, width, [items], conf_thr)[0]
 
-    def local_records_waves(self, frames_dev: int, height: int, width: int, waves_items, conf_thr: float = 0.5) -> List[np.ndarray]:
+    def local_records_groups(self, groups, conf_thr: float = 0.5) -> List[List[np.ndarray]]:
+        """Several look-ahead groups - [(frames_dev, height, width, waves_items), ...] - each as `local_records_waves`, group
+        k on worker handle k % len(workers), the groups of one round side by side on host threads (the library calls release
+        the GIL; one device pass is a chain of dependent launches and stream waits, a second pass's kernels fill its gaps:
+        DESIGN section 5).  A record is a pure function of its frame and the predecessor, so which handle computes a group
+        does not matter; returns the groups' record blocks in the order given."""
+        nw = len(self.workers)
+        if nw == 1 or len(groups) == 1:
+            return [self.local_records_waves(*g, conf_thr=conf_thr) for g in groups]
+        import threading
+
+        out: List = [None] * len(groups)
+        errs: List = []
+
+        def run(k0):
+            try:
+                for k in range(k0, len(groups), nw):
+                    out[k] = self.local_records_waves(*groups[k], conf_thr=conf_thr, handle=self.workers[k0])
+            except BaseException as e:                              # noqa: BLE001 - re-raised on the calling thread
+                errs.append(e)
+
+        th = [threading.Thread(target=run, args=(k0,)) for k0 in range(min(nw, len(groups)))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        return out
+
+    def local_records_waves(self, frames_dev: int, height: int, width: int, waves_items, conf_thr: float = 0.5,
+                            handle=None) -> List[np.ndarray]:
         """Several waves of this rank in ONE device pass (look-ahead batching: what a frame contributes to its record is a
         pure function of the frame and its predecessor, only the replay is sequential, so the frames of the next L waves can
         share a detector / classifier / forensic batch; the exchange stays one all-gather per wave, in wave order).
@@ -197,9 +231,10 @@ class ShardedStreams:
         prev_index[m:] = -2                                   # predecessor-only frames: a gray plane, no signals
         for k, i in enumerate(prevs):
             prev_index[i] = m + k
-        boxes, logits, _ = self.h.analyze_batch_device(frames_dev, m, height, width, forced_boxes=None,
-                                                       confidence_threshold=conf_thr, max_faces=1, with_forensics=False)
-        scores, mdiff = self.h.forensic_signals_device(frames_dev, m + len(prevs), height, width, prev_index)
+        dev = handle if handle is not None else self.h
+        boxes, logits, _ = dev.analyze_batch_device(frames_dev, m, height, width, forced_boxes=None,
+                                                    confidence_threshold=conf_thr, max_faces=1, with_forensics=False)
+        scores, mdiff = dev.forensic_signals_device(frames_dev, m + len(prevs), height, width, prev_index)
         small = height < 30 or width < 30
         blocks, i = [], 0
         for items in waves_items:

@@ -168,6 +168,18 @@ class _CpuStandInHandle:
     def warmup(self, *a):
         pass
 
+    def tiles_export(self):
+        return ""
+
+    def tiles_import(self, text):
+        return 0
+
+    def sibling(self):
+        """a second handle on the same 'device': its own object, the same device memory"""
+        other = _CpuStandInHandle()
+        other.store = self.store
+        return other
+
     def sync(self):
         pass
 
@@ -213,7 +225,10 @@ def _bench_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = bench.config5_streams(_CpuStandInHandle(), rank, world, dist, rank, waves=6, n_streams=3, lookahead=4, size=(320, 352))
+    h = _CpuStandInHandle()
+    # with a second handle per rank: the look-ahead groups are computed two at a time on host threads (the bench's default)
+    res = bench.config5_streams(h, rank, world, dist, rank, waves=6, n_streams=3, lookahead=4, size=(320, 352),
+                                extra_handles=[h.sibling()])
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -244,6 +259,39 @@ def test_bench_config5_driver_runs_at_world_2_over_gloo(pkg):
     # the same driver unsharded gives the same verdict sequence for stream 0
     one = bench.config5_streams(_CpuStandInHandle(), 0, 1, None, 0, waves=12, n_streams=3, lookahead=4, size=(320, 352))
     assert one["verdicts_stream0"] == r0["verdicts_stream0"] and one["transport"] == "local"
+    assert r0["groups_in_flight_per_gpu"] == 2 and one["groups_in_flight_per_gpu"] == 1
+
+
+def test_look_ahead_groups_side_by_side_equal_one_after_the_other(pkg):
+    """`ShardedStreams.local_records_groups`: groups computed on two handles by two host threads give the record blocks of
+    the one-handle loop, in the order given (three groups on two handles: the first handle takes groups 0 and 2); an
+    exception on a worker thread reaches the caller."""
+    S = pkg.streams
+    h = _CpuStandInHandle()
+    rs = np.random.RandomState(5)
+    groups = []
+    for g in range(3):
+        cur = rs.randint(0, 255, (6, 64, 96, 3)).astype(np.uint8)              # two waves of three streams
+        prev = rs.randint(0, 255, (6, 64, 96, 3)).astype(np.uint8)
+        buf = h.alloc(0).upload(np.concatenate([cur, prev]))
+        items = [[(s_, 2 * g + w, True) for s_ in range(3)] for w in range(2)]
+        groups.append((buf.ptr, 64, 96, items))
+    one = S.ShardedStreams(h, 3).local_records_groups(groups)
+    two = S.ShardedStreams(h, 3, extra_handles=[h.sibling()]).local_records_groups(groups)
+    assert len(one) == len(two) == 3
+    for a, b in zip(one, two):
+        assert len(a) == len(b) == 2
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True)
+
+    class Broken(_CpuStandInHandle):
+        def analyze_batch_device(self, *a, **k):
+            raise RuntimeError("worker failed")
+
+    bad = Broken()
+    bad.store = h.store
+    with pytest.raises(RuntimeError, match="worker failed"):
+        S.ShardedStreams(h, 3, extra_handles=[bad]).local_records_groups(groups)
 
 
 def test_sharded_streams_apply_the_calibrator(pkg):

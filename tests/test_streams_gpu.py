@@ -156,3 +156,39 @@ def test_predecessor_only_frames_skip_the_signals_not_the_differences(pkg, b0_ha
     with pytest.raises(pkg._lib.DfdError):
         h.forensic_signals_device(fd.ptr, 5, H, W, np.array([3, -2, -1, -1, -1], np.int32))
     fd.free()
+
+
+def test_groups_on_two_handles_give_the_one_handle_records(pkg, b0_handle, seeded_sd):
+    """`local_records_groups` on the device: three look-ahead groups computed two at a time (second handle: its own
+    streams and workspaces, main stream from the high-priority pool, a second host thread) return the record blocks of the
+    one-handle loop bit for bit - a record is a pure function of its frame and the predecessor, whichever handle runs it."""
+    S = pkg.streams
+    h = b0_handle
+    streams = [_stream(5, 7), _stream(6, 7)]
+    n_streams = len(streams)
+    bufs, groups = [], []
+    for t0 in (0, 2, 4):                                          # groups of two waves (frames t0, t0 + 1)
+        cur, prev, items = [], [], []
+        for t in (t0, t0 + 1):
+            cur += [streams[s][t] for s in range(n_streams)]
+            if t > 0:
+                prev += [streams[s][t - 1] for s in range(n_streams)]
+            items.append([(s, t, t > 0) for s in range(n_streams)])
+        arr = np.stack(cur + prev)
+        bufs.append(h.alloc(arr.nbytes).upload(arr))
+        groups.append((bufs[-1].ptr, H, W, items))
+    other = pkg._lib.Handle(pkg.weights.pack_all(seeded_sd, pkg.weights.seeded_ssd_state_dict(0)), device=0, max_batch=16)
+    try:
+        other.set_option("stream_priority", 1)
+        one = S.ShardedStreams(h, n_streams).local_records_groups(groups)
+        two = S.ShardedStreams(h, n_streams, extra_handles=[other]).local_records_groups(groups)
+        assert len(one) == len(two) == 3
+        for a, b in zip(one, two):
+            assert len(a) == len(b) == 2
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y, equal_nan=True)
+        assert any(np.isfinite(blk[:, S.F_FACE_PROB]).any() for a in one for blk in a)      # faces were classified
+    finally:
+        for b in bufs:
+            b.free()
+        other.close()
