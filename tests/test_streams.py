@@ -226,9 +226,10 @@ def _bench_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     h = _CpuStandInHandle()
-    # with a second handle per rank: the look-ahead groups are computed two at a time on host threads (the bench's default)
+    # with a second handle the look-ahead groups are computed two at a time on host threads (the bench's default) - here
+    # on rank 0 ONLY: a rank that could not make its second handle must still meet the others in every collective
     res = bench.config5_streams(h, rank, world, dist, rank, waves=6, n_streams=3, lookahead=4, size=(320, 352),
-                                extra_handles=[h.sibling()])
+                                extra_handles=[h.sibling()] if rank == 0 else [])
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
