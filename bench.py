@@ -885,6 +885,9 @@ def main():
         lanes.handles[1].set_option("stream_priority", 1)
     lanes.warmup(args.batch)
     ys = [yd] + [h.alloc(args.batch * 4) for _ in range(len(lanes) - 1)]
+    # untimed, before the warm-up steps: do the two lanes overlap in THIS process?  (after torch.distributed / RCCL have made
+    # their streams the runtime may put both lanes on one hardware queue; the check then moves lane 1 to another pool)
+    overlap = lanes.check_overlap(xd.ptr, args.batch, ys) if len(lanes) > 1 and os.environ.get("DFD_BENCH_LANE_PRIORITY") is None else None
     for i in range(max(args.warmup, 1)):
         lanes.submit(xd.ptr, args.batch, ys[i % len(lanes)].ptr)
     lanes.sync()
@@ -990,7 +993,7 @@ def main():
         "data": "synthetic (torch.manual_seed(1) randn crops, seeded random-init weights)",
         "config": {"workload": "configs[1]: batch=256 random 224x224 crops, EfficientNet-B0 fp32 inference",
                    "batch_per_gpu": args.batch, "parallelism": f"frame-shard x{world}, no data-path collective",
-                   "forwards_in_flight": nl,
+                   "forwards_in_flight": nl, "lanes_overlap_check_untimed": overlap,
                    "instrumented_steps": f"every {every}th step (from step {first}) carries per-launch HIP events and runs "
                                          "alone (the other lane waits for it on the device, inside the timed region): "
                                          "roofline durations are those of isolated kernels",

@@ -790,6 +790,36 @@ class ClassifierLanes:
         self._next = (k + 1) % len(self.handles)
         return k
 
+    def check_overlap(self, x_dev: int, n: int, outs, steps: int = 6, gain: float = 0.97):
+        """Untimed check that the lanes really run side by side (the runtime may have mapped their main streams onto one
+        hardware queue - then they run in line and two lanes are no faster than one).  Times `steps`
+        forwards on lane 0 alone and on all lanes; if the lanes are not at least 3 % faster, lane 1's main stream is
+        re-created in the high-priority pool and the measurement repeated, and whichever setting was faster stays.
+        -> {"one_lane_ms", "lanes_ms", "lane1_priority", ...} (per forward)."""
+        import time
+
+        def run(handles):
+            for h in handles:
+                h.sync()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                handles[i % len(handles)].classify_device(x_dev, n, outs[i % len(handles)].ptr)
+            for h in handles:
+                h.sync()
+            return (time.perf_counter() - t0) / steps * 1e3
+
+        run(self.handles)                                           # clocks, first-use costs
+        rep = {"one_lane_ms": round(run(self.handles[:1]), 4), "lanes_ms": round(run(self.handles), 4), "lane1_priority": 0}
+        if len(self.handles) > 1 and rep["lanes_ms"] > gain * rep["one_lane_ms"]:
+            self.handles[1].set_option("stream_priority", 1)
+            rep["lanes_ms_high_priority"] = round(run(self.handles), 4)
+            if rep["lanes_ms_high_priority"] < rep["lanes_ms"]:
+                rep["lane1_priority"] = 1
+            else:
+                self.handles[1].set_option("stream_priority", 0)
+        self._next = 0
+        return rep
+
     def submit_alone(self, x_dev: int, n: int, logits_dev: int) -> int:
         """queue one forward that runs with NO other lane's kernels beside it, ordered on the device (dfd_wait_for: no
         host wait, the host stays ahead of the GPU): it starts when the other lanes have finished what they hold, and they

@@ -223,3 +223,33 @@ def test_wait_for_orders_two_handles_on_the_device(pkg, big, crops, seeded_sd, s
         for b in bufs:
             b.free()
         other.close()
+
+
+def test_lanes_overlap_check_keeps_the_faster_setting_and_the_bits(pkg, big, crops, seeded_sd, ssd_sd):
+    """`ClassifierLanes.check_overlap` (bench.py runs it untimed): the normal path reports both timings and leaves lane 1
+    alone; with a threshold no measurement can meet (gain 0) it tries the high-priority pool and keeps whichever was faster.
+    Either way the lanes' logits stay the single-handle bits."""
+    x = crops.numpy()
+    want = big.classify(x)
+    lanes = pkg._lib.ClassifierLanes(pkg.weights.pack_all(seeded_sd, ssd_sd), device=0, max_batch=256, lanes=2, first=big)
+    bufs = []
+    try:
+        lanes.warmup(256)
+        xd = big.alloc(x.nbytes).upload(x)
+        ys = [big.alloc(256 * 4) for _ in range(2)]
+        bufs = [xd] + ys
+        rep = lanes.check_overlap(xd.ptr, 256, ys, steps=4)
+        assert rep["one_lane_ms"] > 0 and rep["lanes_ms"] > 0 and rep["lane1_priority"] in (0, 1)
+        forced = lanes.check_overlap(xd.ptr, 256, ys, steps=4, gain=0.0)
+        assert "lanes_ms_high_priority" in forced and forced["lane1_priority"] in (0, 1)
+        assert (forced["lane1_priority"] == 1) == (forced["lanes_ms_high_priority"] < forced["lanes_ms"])
+        for i in range(4):
+            lanes.submit(xd.ptr, 256, ys[i % 2].ptr)
+        lanes.sync()
+        for y in ys:
+            assert np.array_equal(y.download((256, 1)), want)
+    finally:
+        lanes.handles[1].set_option("stream_priority", 0)
+        for b in bufs:
+            b.free()
+        lanes.close()
