@@ -123,7 +123,8 @@ int dfd_memcpy_d2h(dfd_handle* h, void* dst_host, const void* src_dev, size_t by
 int dfd_sync(dfd_handle* h);
 /* Device-side ordering between two handles on the same device, without a host wait: everything queued on `h` after this
  * call starts only when the work queued on `other` so far has finished (an event recorded on other's stream, waited for by
- * h's stream).  bench.py orders its two classifier lanes with it around the step that carries per-launch events. */
+ * h's stream).  bench.py orders its two classifier lanes with it around the step that carries per-launch events.
+ * Threading: as every entry point, one caller thread per handle - no other thread may be inside a call on `h` or `other`. */
 int dfd_wait_for(dfd_handle* h, dfd_handle* other);
 /* device address of the handle's frame buffer: the last frame uploaded by a host-frame entry point or decoded by
  * dfd_decode_jpeg (packed BGR); valid until the next such call */

@@ -198,6 +198,9 @@ int dfd_set_option(dfd_handle* h, const char* name, int value) {
         if (value < -1 || value > 1) return fail(h, DFD_ERR_ARG, "stream_priority must be -1, 0 or 1");
         DFD_HIP_TRY(h, hipSetDevice(h->device));
         DFD_HIP_TRY(h, stream_sync(h));
+        // the handle's other streams exchange events with the main one (forensic set, uploads, JPEG decode): drained too
+        if (h->aux_stream) DFD_HIP_TRY(h, hipStreamSynchronize(h->aux_stream));
+        if (h->copy_stream) DFD_HIP_TRY(h, hipStreamSynchronize(h->copy_stream));
         int least = 0, greatest = 0;
         DFD_HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
         const int prio = value > 0 ? greatest : (value < 0 ? least : (least + greatest) / 2);
