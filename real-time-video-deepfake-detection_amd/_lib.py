@@ -841,6 +841,9 @@ class ClassifierLanes:
             h.sync()
 
     def close(self):
+        """closes the handles this object made; a `first` handle passed in stays open and remains the only lane"""
         for h in self._owned:
             h.close()
+        self.handles = [h for h in self.handles if not any(h is o for o in self._owned)]
         self._owned = []
+        self._next = 0

@@ -64,8 +64,10 @@ def test_lanes_rotate_share_the_tile_table_and_close_only_what_they_made(lanes_m
     assert went == [0, 1, 2, 0, 1, 2, 0]
     lanes.set_option("bf16_activations", 1)
     assert all(h.options["bf16_activations"] == 1 for h in lanes.handles)
+    made = lanes.handles[1:]
     lanes.close()
-    assert not first.closed and all(h.closed for h in lanes.handles[1:])
+    assert not first.closed and all(h.closed for h in made)
+    assert lanes.handles == [first] and lanes.submit(1, 8, 200) == 0          # what is left is the caller's handle
     with pytest.raises(ValueError):
         lanes_mod.ClassifierLanes(b"", lanes=0)
 
