@@ -7,6 +7,14 @@ step = one forward over one 256-crop batch per GPU; frames shard with no data-pa
 collective, so N GPUs run N independent batches ("weak" scaling) and `value` is the
 whole-job crops/s.  Rank 0 prints ONE JSON line.
 
+The K timed steps are taken in turn by TWO classifier lanes per GPU (two handles of the
+library = two streams and workspaces, `rtdfd_amd._lib.ClassifierLanes`): two forwards are
+in flight, every forward is still one whole 256-crop batch with the same kernels and the
+same result bits.  One step in 20 carries the per-launch HIP events and is ordered ALONE on
+the device (`dfd_wait_for`), so the roofline durations are those of isolated kernels; the
+overlap that step gives up is inside the timed region.  `DFD_BENCH_LANES=1` = one forward
+in flight (the loop of rounds 1-3; reported as `one_forward_in_flight` either way).
+
 Extra objects on that line:
   roofline      depthwise-conv kernel family against the HBM roofline: algorithmic bytes
                 (25.11 MB per crop) x crops per launch-set / the 16 depthwise
